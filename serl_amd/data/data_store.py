@@ -1,0 +1,242 @@
+"""HBM-resident replay buffer with the reference's data-store interface.
+
+Mirrors (same names, argument meaning and error behaviour):
+  serl_launcher/data/memory_efficient_replay_buffer.py:12-164  MemoryEfficientReplayBuffer
+  serl_launcher/data/replay_buffer.py:77-90                    get_iterator (prefetch queue)
+  serl_launcher/data/data_store.py:83-144                      MemoryEfficientReplayBufferDataStore
+  serl_launcher/data/dataset.py:66-74                          seed / np_random
+  serl_launcher/utils/train_utils.py:16-31                     concat_batches
+
+Storage and sampling live in libserl_mi355.so (serl_amd/csrc/replay.hip); this file only adapts
+Python dicts to the C ABI.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _space_shape(space):
+    return tuple(space.shape)
+
+
+class LazyBatch:
+    """A sampled-but-not-yet-gathered batch: (buffer, slot indices) parts in concat order.
+
+    The agent's update turns it into device tensors with ONE fused gather+concat+unpack+crop
+    kernel (serl_rb_gather_crop).  `materialize()` gives the reference's packed dict instead.
+    """
+
+    def __init__(self, parts):
+        self.parts = list(parts)  # [(buffer, np.int64[n])]
+
+    @property
+    def batch_size(self):
+        return sum(len(ix) for _, ix in self.parts)
+
+    def materialize(self):
+        out = None
+        for buf, ix in self.parts:
+            d = buf.gather(ix)
+            out = d if out is None else concat_batches(out, d, axis=0)
+        return out
+
+
+def concat_batches(offline_batch, online_batch, axis=1):
+    """train_utils.py:16-31 (first argument first).  Works on dict batches of torch tensors and
+    on LazyBatch (axis must be 0 there)."""
+    if isinstance(offline_batch, LazyBatch) or isinstance(online_batch, LazyBatch):
+        assert isinstance(offline_batch, LazyBatch) and isinstance(online_batch, LazyBatch)
+        assert axis == 0, "lazy batches concatenate along the batch axis only"
+        return LazyBatch(offline_batch.parts + online_batch.parts)
+    batch = {}
+    for k, v in offline_batch.items():
+        if isinstance(v, dict):
+            batch[k] = concat_batches(v, online_batch[k], axis=axis)
+        else:
+            batch[k] = torch.cat((v, online_batch[k]), dim=axis)
+    return batch
+
+
+class MemoryEfficientReplayBufferDataStore:
+    """Drop-in for the reference class of the same name (data_store.py:83-144)."""
+
+    def __init__(self, observation_space, action_space, capacity: int,
+                 image_keys: Iterable[str] = ("image",), rlds_logger=None, device: int = 0):
+        if rlds_logger is not None:
+            raise NotImplementedError("RLDS logging is outside the MI355X hot path")
+        self.pixel_keys = tuple(image_keys)
+        spaces = observation_space.spaces
+        self._num_stack = None
+        for k in self.pixel_keys:
+            shp = _space_shape(spaces[k])
+            if self._num_stack is None:
+                self._num_stack = shp[0]
+            else:
+                assert self._num_stack == shp[0]
+            self._img_shape = shp[1:]
+        other = [k for k in spaces.keys() if k not in self.pixel_keys]
+        if other != ["state"]:
+            raise NotImplementedError(f"non-pixel observation keys must be exactly ['state'], got {other}")
+        sshape = _space_shape(spaces["state"])
+        assert len(sshape) == 2 and sshape[0] == self._num_stack, sshape
+        self._S = sshape[1]
+        self._A = _space_shape(action_space)[0]
+        self._capacity = int(capacity)
+        self.device = device
+        self._torch_device = torch.device("cuda", device)
+        H, W, Cc = self._img_shape
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().serl_rb_create(device, self._capacity, len(self.pixel_keys), H, W, Cc,
+                                             self._num_stack, self._S, self._A, C.byref(self._h)))
+        self._np_random = None
+        self._seed = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().serl_rb_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # -- Dataset.seed / np_random (dataset.py:66-74)
+    def seed(self, seed: Optional[int] = None) -> list:
+        ss = np.random.SeedSequence(seed)
+        self._np_random = np.random.Generator(np.random.PCG64(ss))
+        self._seed = ss.entropy
+        st = self._np_random.bit_generator.state
+        s, inc = st["state"]["state"], st["state"]["inc"]
+        m = (1 << 64) - 1
+        _lib.check(_lib.lib().serl_rb_seed(self._h, s >> 64, s & m, inc >> 64, inc & m,
+                                           st["has_uint32"], st["uinteger"]))
+        return [self._seed]
+
+    def _ensure_seeded(self):
+        if self._seed is None:
+            self.seed()  # lazy OS-entropy seed like the reference (dataset.py:66-70)
+
+    def __len__(self) -> int:
+        return int(_lib.lib().serl_rb_len(self._h))
+
+    def latest_data_id(self):  # data_store.py:138-140
+        return int(_lib.lib().serl_rb_insert_index(self._h))
+
+    def get_latest_data(self, from_id: int):  # data_store.py:142-144
+        raise NotImplementedError  # same as the reference
+
+    def valid_mask(self) -> np.ndarray:
+        out = np.zeros(self._capacity, np.uint8)
+        _lib.check(_lib.lib().serl_rb_valid_mask(self._h, out.ctypes.data))
+        return out.astype(bool)
+
+    # -- insert (memory_efficient_replay_buffer.py:53-89; thread-safe, data_store.py:104-106)
+    def insert(self, data_dict):
+        obs, nobs = data_dict["observations"], data_dict["next_observations"]
+        n = len(self.pixel_keys)
+        keep = []
+        obs_p, next_p = (C.c_void_p * n)(), (C.c_void_p * n)()
+        T = self._num_stack
+        for i, k in enumerate(self.pixel_keys):
+            a = np.ascontiguousarray(obs[k], dtype=np.uint8)
+            b = np.ascontiguousarray(nobs[k], dtype=np.uint8)
+            assert a.shape == (T,) + tuple(self._img_shape), (k, a.shape)
+            assert b.shape == a.shape, (k, b.shape)
+            keep += [a, b]
+            obs_p[i], next_p[i] = a.ctypes.data, b.ctypes.data
+        st = np.ascontiguousarray(obs["state"], dtype=np.float32).reshape(-1)
+        nst = np.ascontiguousarray(nobs["state"], dtype=np.float32).reshape(-1)
+        act = np.ascontiguousarray(data_dict["actions"], dtype=np.float32).reshape(-1)
+        assert st.size == T * self._S and nst.size == T * self._S and act.size == self._A
+        _lib.check(_lib.lib().serl_rb_insert(
+            self._h, obs_p, next_p, st.ctypes.data, nst.ctypes.data, act.ctypes.data,
+            float(data_dict["rewards"]), float(data_dict["masks"]), int(bool(data_dict["dones"]))))
+
+    # -- index draw (memory_efficient_replay_buffer.py:111-122)
+    def sample_indices(self, batch_size: int) -> np.ndarray:
+        self._ensure_seeded()
+        idx = np.empty(batch_size, np.int64)
+        _lib.check(_lib.lib().serl_rb_sample_indices(self._h, batch_size, idx.ctypes.data))
+        return idx
+
+    # -- gather (memory_efficient_replay_buffer.py:126-164), packed frames on the device
+    def gather(self, indx: np.ndarray, stream=None):
+        indx = np.ascontiguousarray(indx, dtype=np.int64)
+        B, T = len(indx), self._num_stack
+        H, W, Cc = self._img_shape
+        dev = self._torch_device
+        frames = {k: torch.empty((B, T + 1, H, W, Cc), dtype=torch.uint8, device=dev) for k in self.pixel_keys}
+        st = torch.empty((B, T, self._S), dtype=torch.float32, device=dev)
+        nst = torch.empty_like(st)
+        act = torch.empty((B, self._A), dtype=torch.float32, device=dev)
+        rew = torch.empty((B,), dtype=torch.float32, device=dev)
+        msk = torch.empty((B,), dtype=torch.float32, device=dev)
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+        fp = (C.c_void_p * len(self.pixel_keys))(*[frames[k].data_ptr() for k in self.pixel_keys])
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().serl_rb_gather_packed(
+            self._h, indx.ctypes.data, B, fp, st.data_ptr(), nst.data_ptr(), act.data_ptr(),
+            rew.data_ptr(), msk.data_ptr(), done.data_ptr(), C.c_void_p(s)))
+        obs = {"state": st}
+        obs.update(frames)
+        return {"observations": obs, "next_observations": {"state": nst}, "actions": act,
+                "rewards": rew, "masks": msk, "dones": done.bool()}
+
+    def sample(self, batch_size: int, keys=None, indx=None, pack_obs_and_next_obs: bool = False,
+               lazy: bool = False):
+        if indx is not None:
+            raise NotImplementedError()  # memory_efficient_replay_buffer.py:123-124
+        if keys is not None:
+            raise NotImplementedError("key sub-selection is not used on the hot path")
+        idx = self.sample_indices(batch_size)
+        if lazy:
+            return LazyBatch([(self, idx)])
+        batch = self.gather(idx)
+        if not pack_obs_and_next_obs:  # memory_efficient_replay_buffer.py:159-162
+            for k in self.pixel_keys:
+                packed = batch["observations"][k]
+                batch["observations"][k] = packed[:, :-1]
+                batch["next_observations"][k] = packed[:, 1:]
+        return batch
+
+    # -- replay_buffer.py:77-90: depth-`queue_size` prefetch; `device` is accepted and ignored
+    # (data never leaves HBM)
+    def get_iterator(self, queue_size: int = 2, sample_args: dict = {}, device=None):
+        queue = collections.deque()
+
+        def enqueue(n):
+            for _ in range(n):
+                queue.append(self.sample(**sample_args))
+
+        enqueue(queue_size)
+        while queue:
+            yield queue.popleft()
+            enqueue(1)
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def gather_crop(parts, crop_obs: Optional[np.ndarray], crop_next: Optional[np.ndarray], out, stream=None):
+    """Fused K2+K3+K4 into a DeviceBatch `out` (serl_amd.agents.batch.DeviceBatch)."""
+    n = len(parts)
+    assert 1 <= n <= _lib.MAX_BUFFERS
+    rbs = (C.c_void_p * n)(*[p[0].handle.value for p in parts])
+    idxs = [np.ascontiguousarray(p[1], dtype=np.int64) for p in parts]
+    idp = (C.c_void_p * n)(*[ix.ctypes.data for ix in idxs])
+    counts = (C.c_int * n)(*[len(ix) for ix in idxs])
+    co = None if crop_obs is None else np.ascontiguousarray(crop_obs, dtype=np.int32)
+    cn = None if crop_next is None else np.ascontiguousarray(crop_next, dtype=np.int32)
+    dev = parts[0][0]._torch_device
+    s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _lib.check(_lib.lib().serl_rb_gather_crop(
+        rbs, n, idp, counts, None if co is None else co.ctypes.data,
+        None if cn is None else cn.ctypes.data, C.byref(out.cstruct), C.c_void_p(s)))
