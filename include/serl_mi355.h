@@ -115,6 +115,100 @@ int serl_crop_packed(int device, const uint8_t* const* dev_packed, int n_cam, in
                      int W, int C, const int32_t* host_crop_obs, const int32_t* host_crop_next,
                      uint8_t* dev_frames_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DrQ / SAC agent  (agents/continuous/drq.py, agents/continuous/sac.py, common/common.py)
+ * One handle = JaxRLTrainState (params, target_params, 3 Adam states, step) + all activations.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct serl_agent serl_agent;
+
+/* hyper-parameters of make_drq_agent / DrQAgent.create_drq (utils/launcher.py:79-116,
+ * agents/continuous/drq.py:24-242) with encoder_type == "resnet-pretrained". */
+typedef struct serl_agent_cfg {
+  int device;
+  int n_cam, H, W;         /* image_keys order is the caller's; C == 3 */
+  int state_dim, act_dim;
+  int batch;               /* max samples per update call on THIS rank */
+  int ensemble;            /* critic_ensemble_size (10) */
+  int hidden;              /* MLP width (256) */
+  int bottleneck;          /* encoder bottleneck_dim (256) */
+  int sle_features;        /* num_spatial_blocks (8) */
+  int proprio_dim;         /* proprio_latent_dim (64) */
+  int warmup_steps;        /* optimizers.py:23-30 (0 for DrQ) */
+  float discount, tau, lr;
+  float dropout;           /* 0.1, resnet_v1.py:351 */
+  float std_min, std_max;  /* 1e-5, 5 */
+  float target_entropy;    /* -act_dim/2, drq.py:88-89 */
+  uint64_t seed;           /* device noise stream (production mode) */
+} serl_agent_cfg;
+
+int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out);
+int serl_agent_destroy(serl_agent* a);
+
+/* Parameter tree access (flat leaf names, see DESIGN.md "parameter arena"; the Python shim maps
+ * them to the flax tree of agent.state.params for publish_network / checkpoints).
+ * section: "params" | "target_params" | "opt/<tx>/mu" | "opt/<tx>/nu", tx in actor|critic|temperature */
+int serl_agent_num_leaves(serl_agent* a);
+int serl_agent_leaf_info(serl_agent* a, int i, char* name_out, int name_cap, int64_t* count);
+int serl_agent_set(serl_agent* a, const char* section, const char* leaf, const float* host, int64_t count);
+int serl_agent_get(serl_agent* a, const char* section, const char* leaf, float* host_out, int64_t count);
+int serl_agent_set_step(serl_agent* a, int64_t step); /* JaxRLTrainState.step and the Adam counts */
+int64_t serl_agent_get_step(serl_agent* a);
+
+/* Explicit randomness (parity mode).  All pointers are DEVICE addresses; NULL members (or a NULL
+ * struct) are generated on the device from cfg.seed.  Shapes use the batch of the call:
+ *   eps_*  f32[batch][act_dim];  mask_* u8[n_cam][batch][512*sle_features] keep-masks (1 = keep)
+ * redq_idx is a HOST pointer: int32[utd_ratio][2] (sac.py:150-157). */
+typedef struct serl_noise {
+  const float* eps_next;          /* critic loss: policy sample at next_obs (sac.py:118-132) */
+  const uint8_t* mask_next;       /* Dropout(0.1) masks of that policy forward */
+  const int32_t* redq_idx;        /* host */
+  const float* eps_pi;            /* policy loss sample at obs (sac.py:197-201) */
+  const uint8_t* mask_obs_pi;
+  const float* eps_temp;          /* temperature loss sample at next_obs (sac.py:224-227) */
+  const uint8_t* mask_next_temp;
+} serl_noise;
+
+/* sac.py:185-189,215-219,234,291-297 */
+typedef struct serl_info {
+  float critic_loss, predicted_qs, target_qs;
+  float actor_loss, temperature, entropy, temperature_loss;
+  float actor_lr, critic_lr, temperature_lr;
+} serl_info;
+
+/* DrQAgent.update_critics (drq.py:296-328) on an augmented device batch: one critic grad-step
+ * (REDQ target, 10-member ensemble MSE), 3x Adam (actor/temperature with zero gradients), target EMA. */
+int serl_agent_update_critics(serl_agent* a, const serl_batch* batch, const serl_noise* noise, void* stream);
+/* DrQAgent.update_high_utd (drq.py:255-294 -> sac.py:544-596): utd_ratio critic updates on
+ * consecutive minibatches, then one actor + temperature update on the full batch. */
+int serl_agent_update_high_utd(serl_agent* a, const serl_batch* batch, int utd_ratio,
+                               const serl_noise* noise, void* stream);
+/* info of the last update call (synchronises `stream`) */
+int serl_agent_read_info(serl_agent* a, serl_info* host_out, void* stream);
+
+/* Data-parallel phases (common.py:213-214 lax.pmean made real).  Rank r holds samples
+ * [r*B/P,(r+1)*B/P) of the global batch; the caller all-reduces (SUM) the gradient view between
+ * *_grads and apply.  global_count = samples of this (mini)batch over all ranks (loss normaliser). */
+int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream); /* frozen trunk, both passes */
+int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
+                            const serl_noise* noise, int redq_row, void* stream);
+int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* noise, void* stream);
+#define SERL_APPLY_CRITIC 1
+#define SERL_APPLY_ACTOR_TEMP 2
+int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream);
+int serl_agent_begin_update(serl_agent* a, void* stream); /* clears the info accumulator */
+/* which = SERL_APPLY_CRITIC: [critic grads | scalars]; SERL_APPLY_ACTOR_TEMP: [scalars | actor grads] */
+int serl_agent_grad_view(serl_agent* a, int which, float** dev_ptr, int64_t* count);
+
+/* SACAgent.sample_actions (sac.py:301-320): policy forward with train=False on `n` observations
+ * (frames u8[n_cam][n][H][W][3], state f32[n][S], both device); eps f32[n][A] device or NULL for
+ * argmax (= distribution mode).  out_actions f32[n][A] device. */
+int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const float* dev_state, int n,
+                              const float* dev_eps, float* dev_out_actions, void* stream);
+
+/* Debug / test taps (device->host copies of internal activations). */
+int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream);
+int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

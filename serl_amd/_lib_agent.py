@@ -1,0 +1,62 @@
+"""ctypes declarations of the agent half of the C ABI (include/serl_mi355.h)."""
+import ctypes as C
+
+from ._lib import SerlBatch
+
+
+class SerlAgentCfg(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("n_cam", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("state_dim", C.c_int), ("act_dim", C.c_int), ("batch", C.c_int), ("ensemble", C.c_int),
+        ("hidden", C.c_int), ("bottleneck", C.c_int), ("sle_features", C.c_int),
+        ("proprio_dim", C.c_int), ("warmup_steps", C.c_int),
+        ("discount", C.c_float), ("tau", C.c_float), ("lr", C.c_float), ("dropout", C.c_float),
+        ("std_min", C.c_float), ("std_max", C.c_float), ("target_entropy", C.c_float),
+        ("seed", C.c_uint64),
+    ]
+
+
+class SerlNoise(C.Structure):
+    _fields_ = [
+        ("eps_next", C.c_void_p), ("mask_next", C.c_void_p), ("redq_idx", C.c_void_p),
+        ("eps_pi", C.c_void_p), ("mask_obs_pi", C.c_void_p),
+        ("eps_temp", C.c_void_p), ("mask_next_temp", C.c_void_p),
+    ]
+
+
+class SerlInfo(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "critic_loss", "predicted_qs", "target_qs", "actor_loss", "temperature", "entropy",
+        "temperature_loss", "actor_lr", "critic_lr", "temperature_lr")]
+
+
+def declare(lib):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    P = C.POINTER
+    sigs = {
+        "serl_agent_create": [P(SerlAgentCfg), P(vp)],
+        "serl_agent_destroy": [vp],
+        "serl_agent_num_leaves": [vp],
+        "serl_agent_leaf_info": [vp, i32, C.c_char_p, i32, P(i64)],
+        "serl_agent_set": [vp, C.c_char_p, C.c_char_p, vp, i64],
+        "serl_agent_get": [vp, C.c_char_p, C.c_char_p, vp, i64],
+        "serl_agent_set_step": [vp, i64],
+        "serl_agent_update_critics": [vp, P(SerlBatch), P(SerlNoise), vp],
+        "serl_agent_update_high_utd": [vp, P(SerlBatch), i32, P(SerlNoise), vp],
+        "serl_agent_read_info": [vp, P(SerlInfo), vp],
+        "serl_agent_encode": [vp, P(SerlBatch), vp],
+        "serl_agent_critic_grads": [vp, i32, i32, i32, P(SerlNoise), i32, vp],
+        "serl_agent_actor_grads": [vp, i32, P(SerlNoise), vp],
+        "serl_agent_apply": [vp, i32, f32, vp],
+        "serl_agent_begin_update": [vp, vp],
+        "serl_agent_grad_view": [vp, i32, P(vp), P(i64)],
+        "serl_agent_sample_actions": [vp, vp, vp, i32, vp, vp, vp],
+        "serl_agent_trunk_forward": [vp, vp, i32, vp, vp],
+        "serl_agent_debug_get": [vp, C.c_char_p, vp, i64],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    lib.serl_agent_get_step.argtypes = [vp]
+    lib.serl_agent_get_step.restype = i64

@@ -1,0 +1,172 @@
+"""Thin Python handle around the C ABI's `serl_agent` (no numerics here)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib_agent import SerlAgentCfg, SerlInfo, SerlNoise
+
+APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 2
+TX_NAMES = ("actor", "critic", "temperature")
+
+
+class AgentCore:
+    def __init__(self, *, device=0, n_cam, H, W, state_dim, act_dim, batch, ensemble=10, hidden=256,
+                 bottleneck=256, sle_features=8, proprio_dim=64, warmup_steps=0, discount=0.96,
+                 tau=0.005, lr=3e-4, dropout=0.1, std_min=1e-5, std_max=5.0, target_entropy=None,
+                 seed=0):
+        if target_entropy is None:
+            target_entropy = -act_dim / 2
+        self.cfg = SerlAgentCfg(device, n_cam, H, W, state_dim, act_dim, batch, ensemble, hidden,
+                                bottleneck, sle_features, proprio_dim, warmup_steps, discount, tau,
+                                lr, dropout, std_min, std_max, target_entropy, seed)
+        self._h = C.c_void_p()
+        self.L = _lib.lib()
+        _lib.check(self.L.serl_agent_create(C.byref(self.cfg), C.byref(self._h)))
+        self.device = torch.device("cuda", device)
+        self.leaves = {}
+        buf = C.create_string_buffer(128)
+        cnt = C.c_int64()
+        for i in range(self.L.serl_agent_num_leaves(self._h)):
+            _lib.check(self.L.serl_agent_leaf_info(self._h, i, buf, 128, C.byref(cnt)))
+            self.leaves[buf.value.decode()] = int(cnt.value)
+        self._keep = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self.L.serl_agent_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- parameters ------------------------------------------------------------------------
+    def set(self, section: str, leaf: str, value):
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(-1))
+        _lib.check(self.L.serl_agent_set(self._h, section.encode(), leaf.encode(), v.ctypes.data, v.size))
+
+    def get(self, section: str, leaf: str) -> np.ndarray:
+        out = np.empty(self.leaves[leaf], np.float32)
+        _lib.check(self.L.serl_agent_get(self._h, section.encode(), leaf.encode(), out.ctypes.data, out.size))
+        return out
+
+    def load_flat(self, section: str, tree: Dict[str, np.ndarray]):
+        for k, v in tree.items():
+            self.set(section, k, v)
+
+    @property
+    def step(self):
+        return int(self.L.serl_agent_get_step(self._h))
+
+    @step.setter
+    def step(self, v):
+        _lib.check(self.L.serl_agent_set_step(self._h, int(v)))
+
+    # ---- updates ---------------------------------------------------------------------------
+    def _noise(self, noise: Optional[dict]):
+        """noise: dict of torch device tensors (eps_*, mask_*) and np.int32 redq_idx, or None."""
+        if noise is None:
+            self._keep = None
+            return None
+        keep = []
+
+        def dev(name, dtype):
+            t = noise.get(name)
+            if t is None:
+                return None
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        redq = noise.get("redq_idx")
+        rp = None
+        if redq is not None:
+            redq = np.ascontiguousarray(redq, dtype=np.int32)
+            keep.append(redq)
+            rp = redq.ctypes.data
+        n = SerlNoise(dev("eps_next", torch.float32), dev("mask_next", torch.uint8), rp,
+                      dev("eps_pi", torch.float32), dev("mask_obs_pi", torch.uint8),
+                      dev("eps_temp", torch.float32), dev("mask_next_temp", torch.uint8))
+        self._keep = (keep, n)
+        return C.byref(n)
+
+    def update_critics(self, batch, noise=None):
+        _lib.check(self.L.serl_agent_update_critics(self._h, C.byref(batch.cstruct), self._noise(noise), self._stream()))
+
+    def update_high_utd(self, batch, utd_ratio=1, noise=None):
+        _lib.check(self.L.serl_agent_update_high_utd(self._h, C.byref(batch.cstruct), utd_ratio,
+                                                     self._noise(noise), self._stream()))
+
+    def read_info(self) -> dict:
+        info = SerlInfo()
+        _lib.check(self.L.serl_agent_read_info(self._h, C.byref(info), self._stream()))
+        return {n: getattr(info, n) for n, _ in SerlInfo._fields_}
+
+    # ---- data-parallel phases --------------------------------------------------------------
+    def begin_update(self):
+        _lib.check(self.L.serl_agent_begin_update(self._h, self._stream()))
+
+    def encode(self, batch):
+        _lib.check(self.L.serl_agent_encode(self._h, C.byref(batch.cstruct), self._stream()))
+
+    def critic_grads(self, offset, count, global_count, noise=None, redq_row=0):
+        _lib.check(self.L.serl_agent_critic_grads(self._h, offset, count, global_count, self._noise(noise),
+                                                  redq_row, self._stream()))
+
+    def actor_grads(self, global_count, noise=None):
+        _lib.check(self.L.serl_agent_actor_grads(self._h, global_count, self._noise(noise), self._stream()))
+
+    def apply(self, which, info_weight=1.0):
+        _lib.check(self.L.serl_agent_apply(self._h, which, info_weight, self._stream()))
+
+    def grad_view(self, which) -> torch.Tensor:
+        """The contiguous [grads | scalars] (critic) or [scalars | grads] (actor) device range as a
+        torch tensor (zero-copy) for torch.distributed.all_reduce."""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.L.serl_agent_grad_view(self._h, which, C.byref(p), C.byref(n)))
+        return _wrap_device_f32(p.value, int(n.value), self.device)
+
+    # ---- misc --------------------------------------------------------------------------------
+    def trunk_forward(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        n = frames_u8.shape[0]
+        H, W = self.cfg.H, self.cfg.W
+        fh = fw = None
+        h, w = H, W
+        for _ in range(5):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        out = torch.empty((n, h, w, 512), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.serl_agent_trunk_forward(self._h, frames_u8.contiguous().data_ptr(), n,
+                                                   out.data_ptr(), self._stream()))
+        return out
+
+    def sample_actions(self, frames_u8, state, eps=None):
+        n = state.shape[0]
+        out = torch.empty((n, self.cfg.act_dim), dtype=torch.float32, device=self.device)
+        _lib.check(self.L.serl_agent_sample_actions(
+            self._h, frames_u8.contiguous().data_ptr(), state.contiguous().data_ptr(), n,
+            None if eps is None else eps.contiguous().data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def debug(self, what: str, count: int) -> np.ndarray:
+        out = np.empty(count, np.float32)
+        _lib.check(self.L.serl_agent_debug_get(self._h, what.encode(), out.ctypes.data, count))
+        return out
+
+
+class _DevPtr:
+    """Minimal __cuda_array_interface__ carrier so torch can alias library-owned HBM."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+
+
+def _wrap_device_f32(ptr, n, device):
+    return torch.as_tensor(_DevPtr(ptr, n), device=device)

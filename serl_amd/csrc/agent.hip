@@ -1,0 +1,940 @@
+// DrQ / SAC agent: parameter arena, step orchestration and the agent half of the C ABI.
+// Reference semantics (paths relative to serl_launcher/serl_launcher/):
+//   agents/continuous/drq.py:255-328      update_high_utd / update_critics
+//   agents/continuous/sac.py:118-299      losses, update(); :544-596 update_high_utd
+//   common/common.py:124-221              3 Adam txs over the full tree, summed updates, target EMA
+//   common/encoding.py:26-72              per-camera encode + proprio branch
+// The frozen trunk is evaluated twice per update (augmented obs, augmented next_obs); the reference
+// evaluates it a third time with target_params, whose trunk leaves equal the online ones up to
+// EMA round-off (<= 1e-6 relative) -- the target copy is still maintained for export.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "heads.h"
+
+using namespace serl;
+
+namespace {
+
+struct Leaf {
+  std::string name;
+  long off, count;
+};
+
+struct CamOff { long sle, dW, db, lng, lnb; };
+struct Offs {
+  CamOff cam[SERL_MAX_CAMS];
+  long cam_stride;
+  long c_w1, c_b1, c_g1, c_be1, c_w2, c_b2, c_g2, c_be2, c_hw, c_hb;
+  long p_W, p_b, p_g, p_be;
+  long a_w1, a_b1, a_g1, a_be1, a_w2, a_b2, a_g2, a_be2, a_Wm, a_bm, a_Ws, a_bs;
+  long lam;
+  long P, Pc, Pa0, Pa1;
+};
+
+struct EncBuf {     // activations of one EncodingWrapper forward
+  float* f;         // [n_cam][B][D] SLE output (after dropout)
+  float* xhat;      // [n_cam*B][256]
+  float* rstd;      // [n_cam*B]
+  float* pxhat;     // [B][64]
+  float* prstd;     // [B]
+  float* enc;       // [B][ld] output slice base
+  long ld;
+};
+struct MlpBuf {  // 2-layer LN/tanh MLP activations (ensemble: rows = E*B)
+  float *h1, *xh1, *rs1, *h2, *xh2, *rs2;
+};
+struct CritBuf {
+  float* x;  // [B][E+A]
+  MlpBuf m;
+  float* q;  // [ens][B]
+};
+struct PolBuf {
+  MlpBuf m;
+  float *pre, *std, *logp;  // [2][B][A], [B][A], [B]
+};
+
+constexpr int kScalars = 32;
+// scalar slots (device): local sums that are all-reduced together with the gradients
+enum { S_D2 = 0, S_Q = 1, S_Y = 2, S_QPI = 3, S_LOGP = 4, S_LOGP_NEXT = 5 };
+// aux slots (device, rank-local, never all-reduced)
+enum { X_ALPHA = 0, X_TGRAD = 1, X_N = 8 };
+// info accumulator slots
+enum { I_CL = 0, I_PQ, I_TQ, I_AL, I_TEMP, I_ENT, I_TL, I_N };
+
+}  // namespace
+
+struct serl_agent {
+  serl_agent_cfg cfg{};
+  int E = 0, D = 0, HW = 0, XA = 0;  // enc dim, sle dim, feature pixels, E + A
+  Offs o{};
+  std::vector<Leaf> theta_leaves, trunk_leaves;
+  long trunk_count = 0;
+  // device memory
+  void* arena = nullptr;
+  float *trunk = nullptr, *trunk_t = nullptr, *theta = nullptr, *theta_t = nullptr;
+  float *m_c = nullptr, *v_c = nullptr, *m_a = nullptr, *v_a = nullptr, *m_t = nullptr, *v_t = nullptr;
+  float* G = nullptr;  // [Gc (Pc) | scalars (32) | Ga (Pa1-Pa0)]
+  float *Gc = nullptr, *SC = nullptr, *Ga = nullptr;
+  float* info_acc = nullptr;  // [I_N]
+  float* aux = nullptr;       // [X_N]
+  TrunkWeights tw{};
+  TrunkWorkspace tws{};
+  float* feats = nullptr;  // [2][n_cam][B][HW][512]
+  EncBuf encP{}, encT{}, encO{};
+  CritBuf critT{}, crit{};
+  PolBuf pol{};
+  float* slabs = nullptr; long slabs_cap = 0;
+  float *dq = nullptr, *ytgt = nullptr;
+  float *dh2 = nullptr, *da2 = nullptr, *dg2 = nullptr, *dh1 = nullptr, *da1 = nullptr, *dg1 = nullptr;
+  float *dx = nullptr, *dz = nullptr, *dgz = nullptr, *df = nullptr, *sle_part = nullptr;
+  float *dp = nullptr, *dgp = nullptr, *dpre = nullptr, *dprop_y = nullptr;
+  float *eps_buf[3] = {nullptr, nullptr, nullptr};
+  uint8_t* mask_buf[3] = {nullptr, nullptr, nullptr};
+  float* act_tmp = nullptr;  // [B][A] sample_actions scratch
+  // batch of the current update (caller-owned device memory)
+  serl_batch cur{};
+  bool has_batch = false;
+  // optimizer bookkeeping
+  int64_t step = 0;
+  uint64_t noise_ctr = 0;
+  serl_info last_info{};
+  float lr_last = 0.f;
+  int last_global = 0;
+};
+
+namespace {
+
+constexpr int kSleSplit = 8;
+
+size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Bump {
+  uint8_t* base;
+  size_t off = 0;
+  explicit Bump(void* b) : base((uint8_t*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += al(n * sizeof(T));
+    return p;
+  }
+};
+
+void build_layout(serl_agent* a) {
+  const serl_agent_cfg& c = a->cfg;
+  const TrunkDims d = trunk_dims(c.H, c.W);
+  a->HW = d.h[5] * d.w[5];
+  a->D = 512 * c.sle_features;
+  a->E = c.bottleneck * c.n_cam + c.proprio_dim;
+  a->XA = a->E + c.act_dim;
+  long off = 0;
+  auto leaf = [&](std::vector<Leaf>& v, const std::string& n, long cnt) {
+    v.push_back({n, off, cnt});
+    const long at = off;
+    off += cnt;
+    return at;
+  };
+  Offs& o = a->o;
+  std::vector<Leaf>& L = a->theta_leaves;
+  const long Hd = c.hidden, A = c.act_dim, N = c.ensemble;
+  for (int k = 0; k < c.n_cam; ++k) {
+    const std::string p = "enc/" + std::to_string(k) + "/";
+    o.cam[k].sle = leaf(L, p + "sle", (long)a->HW * 512 * c.sle_features);
+    o.cam[k].dW = leaf(L, p + "dense/kernel", (long)a->D * c.bottleneck);
+    o.cam[k].db = leaf(L, p + "dense/bias", c.bottleneck);
+    o.cam[k].lng = leaf(L, p + "ln/scale", c.bottleneck);
+    o.cam[k].lnb = leaf(L, p + "ln/bias", c.bottleneck);
+  }
+  o.cam_stride = c.n_cam > 1 ? o.cam[1].sle - o.cam[0].sle : off;
+  o.c_w1 = leaf(L, "critic/w1", N * a->XA * Hd);
+  o.c_b1 = leaf(L, "critic/b1", N * Hd);
+  o.c_g1 = leaf(L, "critic/ln1/scale", N * Hd);
+  o.c_be1 = leaf(L, "critic/ln1/bias", N * Hd);
+  o.c_w2 = leaf(L, "critic/w2", N * Hd * Hd);
+  o.c_b2 = leaf(L, "critic/b2", N * Hd);
+  o.c_g2 = leaf(L, "critic/ln2/scale", N * Hd);
+  o.c_be2 = leaf(L, "critic/ln2/bias", N * Hd);
+  o.c_hw = leaf(L, "critic/head/kernel", Hd);
+  o.c_hb = leaf(L, "critic/head/bias", 1);
+  o.Pa0 = off;
+  o.p_W = leaf(L, "enc/proprio/dense/kernel", (long)c.state_dim * c.proprio_dim);
+  o.p_b = leaf(L, "enc/proprio/dense/bias", c.proprio_dim);
+  o.p_g = leaf(L, "enc/proprio/ln/scale", c.proprio_dim);
+  o.p_be = leaf(L, "enc/proprio/ln/bias", c.proprio_dim);
+  o.Pc = off;
+  o.a_w1 = leaf(L, "actor/w1", (long)a->E * Hd);
+  o.a_b1 = leaf(L, "actor/b1", Hd);
+  o.a_g1 = leaf(L, "actor/ln1/scale", Hd);
+  o.a_be1 = leaf(L, "actor/ln1/bias", Hd);
+  o.a_w2 = leaf(L, "actor/w2", Hd * Hd);
+  o.a_b2 = leaf(L, "actor/b2", Hd);
+  o.a_g2 = leaf(L, "actor/ln2/scale", Hd);
+  o.a_be2 = leaf(L, "actor/ln2/bias", Hd);
+  o.a_Wm = leaf(L, "actor/mean/kernel", Hd * A);
+  o.a_bm = leaf(L, "actor/mean/bias", A);
+  o.a_Ws = leaf(L, "actor/logstd/kernel", Hd * A);
+  o.a_bs = leaf(L, "actor/logstd/bias", A);
+  o.Pa1 = off;
+  o.lam = leaf(L, "temp/lagrange", 1);
+  o.P = off;
+  // trunk
+  off = 0;
+  std::vector<Leaf>& T = a->trunk_leaves;
+  leaf(T, "trunk/conv_init", 7 * 7 * 3 * 64);
+  leaf(T, "trunk/norm_init/scale", 64);
+  leaf(T, "trunk/norm_init/bias", 64);
+  int cin = 64;
+  for (int i = 0; i < kTrunkStages; ++i) {
+    const int f = kStageFilters[i];
+    const std::string p = "trunk/block" + std::to_string(i) + "/";
+    leaf(T, p + "conv0", 9L * cin * f);
+    leaf(T, p + "gn0/scale", f);
+    leaf(T, p + "gn0/bias", f);
+    leaf(T, p + "conv1", 9L * f * f);
+    leaf(T, p + "gn1/scale", f);
+    leaf(T, p + "gn1/bias", f);
+    if (kStageStride[i] != 1 || cin != f) {
+      leaf(T, p + "proj", (long)cin * f);
+      leaf(T, p + "gnp/scale", f);
+      leaf(T, p + "gnp/bias", f);
+    }
+    cin = f;
+  }
+  a->trunk_count = off;
+}
+
+const Leaf* find_leaf(const std::vector<Leaf>& v, const char* name) {
+  for (const Leaf& l : v)
+    if (l.name == name) return &l;
+  return nullptr;
+}
+
+void bind_trunk_weights(serl_agent* a) {
+  auto p = [&](const std::string& n) -> const float* {
+    const Leaf* l = find_leaf(a->trunk_leaves, n.c_str());
+    return l ? a->trunk + l->off : nullptr;
+  };
+  a->tw.conv_init = p("trunk/conv_init");
+  a->tw.gn_init_s = p("trunk/norm_init/scale");
+  a->tw.gn_init_b = p("trunk/norm_init/bias");
+  for (int i = 0; i < kTrunkStages; ++i) {
+    const std::string q = "trunk/block" + std::to_string(i) + "/";
+    TrunkWeights::Block& b = a->tw.blk[i];
+    b.conv0 = p(q + "conv0"); b.gn0_s = p(q + "gn0/scale"); b.gn0_b = p(q + "gn0/bias");
+    b.conv1 = p(q + "conv1"); b.gn1_s = p(q + "gn1/scale"); b.gn1_b = p(q + "gn1/bias");
+    b.proj = p(q + "proj"); b.gnp_s = p(q + "gnp/scale"); b.gnp_b = p(q + "gnp/bias");
+  }
+}
+
+// carve everything (pass 1 with base == nullptr measures)
+size_t carve(serl_agent* a, void* base) {
+  const serl_agent_cfg& c = a->cfg;
+  const long B = c.batch, N = c.ensemble, Hd = c.hidden, A = c.act_dim;
+  const Offs& o = a->o;
+  Bump b(base);
+  a->trunk = b.take<float>(a->trunk_count);
+  a->trunk_t = b.take<float>(a->trunk_count);
+  a->theta = b.take<float>(o.P);
+  a->theta_t = b.take<float>(o.P);
+  a->m_c = b.take<float>(o.Pc); a->v_c = b.take<float>(o.Pc);
+  a->m_a = b.take<float>(o.Pa1 - o.Pa0); a->v_a = b.take<float>(o.Pa1 - o.Pa0);
+  a->m_t = b.take<float>(1); a->v_t = b.take<float>(1);
+  a->G = b.take<float>(o.Pc + kScalars + (o.Pa1 - o.Pa0));
+  a->Gc = a->G; a->SC = a->G ? a->G + o.Pc : nullptr; a->Ga = a->G ? a->G + o.Pc + kScalars : nullptr;
+  a->info_acc = b.take<float>(I_N);
+  a->aux = b.take<float>(X_N);
+  const size_t persistent = b.off;  // zero-initialised region ends here
+  a->feats = b.take<float>(2L * c.n_cam * B * a->HW * 512);
+  auto enc = [&](EncBuf& e) {
+    e.f = b.take<float>((long)c.n_cam * B * a->D);
+    e.xhat = b.take<float>((long)c.n_cam * B * c.bottleneck);
+    e.rstd = b.take<float>((long)c.n_cam * B);
+    e.pxhat = b.take<float>(B * c.proprio_dim);
+    e.prstd = b.take<float>(B);
+    e.enc = nullptr; e.ld = 0;
+  };
+  enc(a->encP); enc(a->encT); enc(a->encO);
+  float* encP_out = b.take<float>(B * a->E);
+  a->encP.enc = encP_out; a->encP.ld = a->E;
+  auto mlp = [&](MlpBuf& m, long rows) {
+    m.h1 = b.take<float>(rows * Hd); m.xh1 = b.take<float>(rows * Hd); m.rs1 = b.take<float>(rows);
+    m.h2 = b.take<float>(rows * Hd); m.xh2 = b.take<float>(rows * Hd); m.rs2 = b.take<float>(rows);
+  };
+  auto crit = [&](CritBuf& cb) {
+    cb.x = b.take<float>(B * a->XA);
+    mlp(cb.m, N * B);
+    cb.q = b.take<float>(N * B);
+  };
+  crit(a->critT); crit(a->crit);
+  a->encT.enc = a->critT.x; a->encT.ld = a->XA;
+  a->encO.enc = a->crit.x; a->encO.ld = a->XA;
+  mlp(a->pol.m, B);
+  a->pol.pre = b.take<float>(2 * B * A); a->pol.std = b.take<float>(B * A); a->pol.logp = b.take<float>(B);
+  long cap = std::max<long>({(long)c.n_cam * 8 * B * c.bottleneck, N * B * (long)a->XA, 4 * B * Hd, N * B * Hd});
+  a->slabs_cap = cap;
+  a->slabs = b.take<float>(cap);
+  a->dq = b.take<float>(N * B); a->ytgt = b.take<float>(B);
+  a->dh2 = b.take<float>(N * B * Hd); a->da2 = b.take<float>(N * B * Hd); a->dg2 = b.take<float>(N * B * Hd);
+  a->dh1 = b.take<float>(N * B * Hd); a->da1 = b.take<float>(N * B * Hd); a->dg1 = b.take<float>(N * B * Hd);
+  a->dx = b.take<float>(B * a->XA);
+  a->dz = b.take<float>((long)c.n_cam * B * c.bottleneck);
+  a->dgz = b.take<float>((long)c.n_cam * B * c.bottleneck);
+  a->df = b.take<float>((long)c.n_cam * B * a->D);
+  a->sle_part = b.take<float>((long)kSleSplit * a->HW * 512 * c.sle_features);
+  a->dp = b.take<float>(B * c.proprio_dim); a->dgp = b.take<float>(B * c.proprio_dim);
+  a->dpre = b.take<float>(2 * B * A); a->dprop_y = b.take<float>(B * c.proprio_dim);
+  for (int k = 0; k < 3; ++k) {
+    a->eps_buf[k] = b.take<float>(B * A);
+    a->mask_buf[k] = b.take<uint8_t>((long)c.n_cam * B * a->D);
+  }
+  a->act_tmp = b.take<float>(B * A);
+  const int nimg = 2 * c.n_cam * c.batch;
+  void* tmem = b.take<uint8_t>(trunk_workspace_bytes(nimg, c.H, c.W));
+  if (base) trunk_workspace_bind(a->tws, tmem, nimg, c.H, c.W);
+  (void)persistent;
+  return b.off;
+}
+
+#define RC(x)            \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+// ---- EncodingWrapper forward on precomputed trunk features (encoding.py:26-72) ------------------
+// which: 0 = observations, 1 = next_observations; samples [off, off+cnt) of the current batch.
+int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uint8_t* mask, EncBuf& e,
+           hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const long Bfull = a->cur.batch;
+  for (int k = 0; k < c.n_cam; ++k) {
+    const float* x = a->feats + (((long)which * c.n_cam + k) * c.batch + off) * a->HW * 512;
+    const uint8_t* m = mask ? mask + ((long)k * Bfull + off) * a->D : nullptr;
+    RC(sle_fwd(x, P + o.cam[k].sle, m, 1.0f / (1.0f - c.dropout), e.f + (long)k * c.batch * a->D, cnt, a->HW,
+               512, st));
+  }
+  const int S = 8;
+  GemmDesc g{};
+  g.A = e.f; g.sAm = a->D; g.sAk = 1; g.sAb = (long)c.batch * a->D;
+  g.B = P + o.cam[0].dW; g.sBk = c.bottleneck; g.sBn = 1; g.sBb = o.cam_stride;
+  g.C = a->slabs; g.ldc = c.bottleneck; g.sCz = (long)cnt * c.bottleneck;
+  g.M = cnt; g.N = c.bottleneck; g.K = a->D; g.nbatch = c.n_cam; g.splitk = S;
+  RC(gemm_f32(g, st));
+  LnFwdArgs l{};
+  l.slabs = a->slabs; l.S = S; l.slab_stride = g.sCz;
+  l.bias = P + o.cam[0].db; l.gamma = P + o.cam[0].lng; l.beta = P + o.cam[0].lnb; l.pstride = o.cam_stride;
+  l.rows = c.n_cam * cnt; l.rows_per_group = cnt;
+  l.y = e.enc; l.ld_y = e.ld; l.y_goff = c.bottleneck;
+  l.xhat = e.xhat; l.rstd = e.rstd;
+  RC(ln_tanh_fwd(l, c.bottleneck, st));
+  // proprio branch (encoding.py:55-70)
+  GemmDesc p{};
+  p.A = a->cur.state + ((long)which * Bfull + off) * c.state_dim; p.sAm = c.state_dim; p.sAk = 1; p.sAb = 0;
+  p.B = P + o.p_W; p.sBk = c.proprio_dim; p.sBn = 1; p.sBb = 0;
+  p.C = a->slabs; p.ldc = c.proprio_dim; p.sCz = (long)cnt * c.proprio_dim;
+  p.M = cnt; p.N = c.proprio_dim; p.K = c.state_dim; p.nbatch = 1; p.splitk = 1;
+  RC(gemm_f32(p, st));
+  LnFwdArgs lp{};
+  lp.slabs = a->slabs; lp.S = 1; lp.slab_stride = p.sCz;
+  lp.bias = P + o.p_b; lp.gamma = P + o.p_g; lp.beta = P + o.p_be; lp.pstride = 0;
+  lp.rows = cnt; lp.rows_per_group = cnt;
+  lp.y = e.enc + (long)c.n_cam * c.bottleneck; lp.ld_y = e.ld; lp.y_goff = 0;
+  lp.xhat = e.pxhat; lp.rstd = e.prstd;
+  RC(ln_tanh_fwd(lp, c.proprio_dim, st));
+  return SERL_OK;
+}
+
+// generic Dense -> LN -> tanh layer on `rows_per_group` rows for `groups` parameter groups
+int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const float* W, long w_gstride,
+                  const float* bias, const float* gamma, const float* beta, long p_gstride, int groups,
+                  int rows_per_group, int K, int splitk, float* y, float* xhat, float* rstd, hipStream_t st) {
+  const int Hd = a->cfg.hidden;
+  GemmDesc g{};
+  g.A = X; g.sAm = ldx; g.sAk = 1; g.sAb = x_gstride;
+  g.B = W; g.sBk = Hd; g.sBn = 1; g.sBb = w_gstride;
+  g.C = a->slabs; g.ldc = Hd; g.sCz = (long)rows_per_group * Hd;
+  g.M = rows_per_group; g.N = Hd; g.K = K; g.nbatch = groups; g.splitk = splitk;
+  RC(gemm_f32(g, st));
+  LnFwdArgs l{};
+  l.slabs = a->slabs; l.S = splitk; l.slab_stride = g.sCz;
+  l.bias = bias; l.gamma = gamma; l.beta = beta; l.pstride = p_gstride;
+  l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
+  l.y = y; l.ld_y = Hd; l.y_goff = (long)rows_per_group * Hd;
+  l.xhat = xhat; l.rstd = rstd;
+  return ln_tanh_fwd(l, Hd, st);
+}
+
+// Policy forward + tanh-Gaussian sample (actor_critic_nets.py:179-227)
+int policy_fwd(serl_agent* a, const float* P, const float* enc, long ld_enc, int cnt, const float* eps,
+               float* act_out, long ld_act, float* sum_logp, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  PolBuf& pb = a->pol;
+  const int Hd = c.hidden, A = c.act_dim;
+  RC(dense_ln_tanh(a, enc, ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0, 1, cnt, a->E, 4,
+                   pb.m.h1, pb.m.xh1, pb.m.rs1, st));
+  RC(dense_ln_tanh(a, pb.m.h1, Hd, 0, P + o.a_w2, 0, P + o.a_b2, P + o.a_g2, P + o.a_be2, 0, 1, cnt, Hd, 2,
+                   pb.m.h2, pb.m.xh2, pb.m.rs2, st));
+  GemmDesc g{};
+  g.A = pb.m.h2; g.sAm = Hd; g.sAk = 1; g.sAb = 0;
+  g.B = P + o.a_Wm; g.sBk = A; g.sBn = 1; g.sBb = o.a_Ws - o.a_Wm;
+  g.C = a->slabs; g.ldc = A; g.sCz = (long)cnt * A;
+  g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 1;
+  RC(gemm_f32(g, st));
+  RC(reduce_slabs(a->slabs, 1, g.sCz, 2, cnt, A, P + o.a_bm, o.a_bs - o.a_bm, pb.pre, A, (long)cnt * A, false, st));
+  return policy_dist_fwd(pb.pre, eps, cnt, A, c.std_min, c.std_max, act_out, ld_act, pb.logp, pb.std, sum_logp, st);
+}
+
+// Critic ensemble forward on x = [enc | action] (actor_critic_nets.py:56-73, drq.py:201-207)
+int critic_fwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const int Hd = c.hidden, N = c.ensemble;
+  RC(dense_ln_tanh(a, cb.x, a->XA, 0, P + o.c_w1, (long)a->XA * Hd, P + o.c_b1, P + o.c_g1, P + o.c_be1, Hd, N,
+                   cnt, a->XA, 1, cb.m.h1, cb.m.xh1, cb.m.rs1, st));
+  RC(dense_ln_tanh(a, cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2,
+                   P + o.c_be2, Hd, N, cnt, Hd, 1, cb.m.h2, cb.m.xh2, cb.m.rs2, st));
+  return critic_head_fwd(cb.m.h2, P + o.c_hw, P + o.c_hb, cb.q, N * cnt, st);
+}
+
+// backward of one Dense->LN->tanh layer.  dy: [groups*rows][Hd] gradient wrt the layer output.
+// Produces dpre (a->da*) and, if G != nullptr, parameter gradients into G at the given offsets
+// (W grads are written directly by the GEMM: splitk == 1).
+int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, const float* y, long ld_y,
+                      long y_goff, const float* xhat, const float* rstd, const float* gamma, long p_gstride,
+                      int groups, int rows_per_group, int D, float* dpre, float* dg, float* G, long g_off,
+                      long be_off, long b_off, long pg_gstride, hipStream_t st) {
+  LnBwdArgs l{};
+  l.dy = dy; l.ld_dy = ld_dy; l.dy_goff = dy_goff;
+  l.y = y; l.ld_y = ld_y; l.y_goff = y_goff;
+  l.xhat = xhat; l.rstd = rstd; l.gamma = gamma; l.pstride = p_gstride;
+  l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
+  l.dx = dpre; l.dg = dg;
+  RC(ln_tanh_bwd(l, D, st));
+  if (G) {
+    RC(colsum(dg, xhat, groups, rows_per_group, D, G + g_off, pg_gstride, false, st));
+    RC(colsum(dg, nullptr, groups, rows_per_group, D, G + be_off, pg_gstride, false, st));
+    RC(colsum(dpre, nullptr, groups, rows_per_group, D, G + b_off, pg_gstride, false, st));
+  }
+  return SERL_OK;
+}
+
+// C[g] = X[g]^T * dY[g]  (weight gradient, written directly)   X: [rows][K-dim as M], dY: [rows][N]
+int wgrad(const float* X, long ldx, long x_gstride, const float* dY, long ldy, long dy_gstride, float* out,
+          long ldo, long out_gstride, int groups, int Mx, int Ny, int rows, hipStream_t st) {
+  GemmDesc g{};
+  g.A = X; g.sAm = 1; g.sAk = ldx; g.sAb = x_gstride;
+  g.B = dY; g.sBk = ldy; g.sBn = 1; g.sBb = dy_gstride;
+  g.C = out; g.ldc = ldo; g.sCz = out_gstride;
+  g.M = Mx; g.N = Ny; g.K = rows; g.nbatch = groups; g.splitk = 1;
+  return gemm_f32(g, st);
+}
+
+// dX[g] = dY[g] * W[g]^T   (input gradient)   W: [Kin][Nout] row-major
+int igrad(const float* dY, long ldy, long dy_gstride, const float* W, long ldw, long w_gstride, float* out,
+          long ldo, long out_zstride, int groups, int rows, int Kin, int Nout, hipStream_t st) {
+  GemmDesc g{};
+  g.A = dY; g.sAm = ldy; g.sAk = 1; g.sAb = dy_gstride;
+  g.B = W; g.sBk = 1; g.sBn = ldw; g.sBb = w_gstride;
+  g.C = out; g.ldc = ldo; g.sCz = out_zstride;
+  g.M = rows; g.N = Kin; g.K = Nout; g.nbatch = groups; g.splitk = 1;
+  return gemm_f32(g, st);
+}
+
+// Critic backward from dq [ens][cnt] down to dx [cnt][E+A]; parameter grads into Gc when `pg`.
+int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const int Hd = c.hidden, N = c.ensemble;
+  float* G = pg ? a->Gc : nullptr;
+  if (pg) {  // shared head kernel: dw[j] = sum_{e,b} dq*h2
+    GemmDesc g{};
+    g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = 0;
+    g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = 0;
+    g.C = a->slabs; g.ldc = Hd; g.sCz = Hd;
+    g.M = 1; g.N = Hd; g.K = N * cnt; g.nbatch = 1; g.splitk = 8;
+    RC(gemm_f32(g, st));
+    RC(reduce_slabs(a->slabs, 8, Hd, 1, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, 0, false, st));
+  }
+  RC(critic_head_bwd_input(a->dq, P + o.c_hw, a->dh2, N * cnt, st));
+  RC(dense_ln_tanh_bwd(a, a->dh2, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
+                       N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st));
+  if (pg)
+    RC(wgrad(cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
+             cnt, st));
+  RC(igrad(a->da2, Hd, (long)cnt * Hd, P + o.c_w2, Hd, (long)Hd * Hd, a->dh1, Hd, (long)cnt * Hd, N, cnt, Hd, Hd, st));
+  RC(dense_ln_tanh_bwd(a, a->dh1, Hd, (long)cnt * Hd, cb.m.h1, Hd, (long)cnt * Hd, cb.m.xh1, cb.m.rs1, P + o.c_g1, Hd,
+                       N, cnt, Hd, a->da1, a->dg1, G, o.c_g1, o.c_be1, o.c_b1, Hd, st));
+  if (pg)
+    RC(wgrad(cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, st));
+  // dx = sum_e da1[e] * W1[e]^T
+  RC(igrad(a->da1, Hd, (long)cnt * Hd, P + o.c_w1, Hd, (long)a->XA * Hd, a->slabs, a->XA, (long)cnt * a->XA, N, cnt,
+           a->XA, Hd, st));
+  return reduce_slabs(a->slabs, N, (long)cnt * a->XA, 1, cnt, a->XA, nullptr, 0, a->dx, a->XA, 0, false, st);
+}
+
+// Encoder-head backward for the critic path: d_enc = dx[:, :E] -> camera heads (SLE kernel, Dense,
+// LayerNorm) and the proprio branch, into Gc.
+int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const int Bn = c.bottleneck;
+  RC(dense_ln_tanh_bwd(a, a->dx, a->XA, Bn, e.enc, e.ld, Bn, e.xhat, e.rstd, P + o.cam[0].lng, o.cam_stride,
+                       c.n_cam, cnt, Bn, a->dz, a->dgz, a->Gc, o.cam[0].lng, o.cam[0].lnb, o.cam[0].db,
+                       o.cam_stride, st));
+  RC(wgrad(e.f, a->D, (long)c.batch * a->D, a->dz, Bn, (long)cnt * Bn, a->Gc + o.cam[0].dW, Bn, o.cam_stride,
+           c.n_cam, a->D, Bn, cnt, st));
+  RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
+           a->D, Bn, st));
+  const long sle_n = (long)a->HW * 512 * c.sle_features;
+  for (int k = 0; k < c.n_cam; ++k) {
+    const float* x = a->feats + (((long)0 * c.n_cam + k) * c.batch + off) * a->HW * 512;
+    RC(sle_bwd(x, a->df + (long)k * cnt * a->D, a->sle_part, cnt, a->HW, 512, kSleSplit, st));
+    RC(reduce_slabs(a->sle_part, kSleSplit, sle_n, 1, 1, (int)sle_n, nullptr, 0, a->Gc + o.cam[k].sle, sle_n, 0,
+                    false, st));
+  }
+  return SERL_OK;
+}
+
+// proprio-branch backward: dy = gradient wrt the proprio code (ld/offset given), into G (Gc or Ga)
+int proprio_bwd(serl_agent* a, const float* P, const float* dy, long ld_dy, const float* y, long ld_y, EncBuf& e,
+                int which, int off, int cnt, float* G, long base_off, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const int Pd = c.proprio_dim;
+  RC(dense_ln_tanh_bwd(a, dy, ld_dy, 0, y, ld_y, 0, e.pxhat, e.prstd, P + o.p_g, 0, 1, cnt, Pd, a->dp, a->dgp, G,
+                       o.p_g - base_off, o.p_be - base_off, o.p_b - base_off, 0, st));
+  const float* s = a->cur.state + ((long)which * a->cur.batch + off) * c.state_dim;
+  return wgrad(s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, st);
+}
+
+int fetch_noise(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot, int cnt_total,
+                const float** eps, const uint8_t** mask, hipStream_t st) {
+  const serl_agent_cfg& c = a->cfg;
+  if (given_eps) *eps = given_eps;
+  else {
+    RC(gen_normal(a->eps_buf[slot], (long)cnt_total * c.act_dim, c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr)), st));
+    *eps = a->eps_buf[slot];
+  }
+  if (given_mask) *mask = given_mask;
+  else {
+    RC(gen_mask(a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D, c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)),
+                1.0f - c.dropout, st));
+    *mask = a->mask_buf[slot];
+  }
+  return SERL_OK;
+}
+
+float lr_at(const serl_agent_cfg& c, int64_t count) {  // optimizers.py:23-30
+  if (count < c.warmup_steps) return c.lr * (float)count / (float)c.warmup_steps;
+  return c.lr;
+}
+
+__global__ void info_critic_kernel(const float* sc, float* acc, float inv_eb, float inv_b, float w) {
+  acc[I_CL] += w * sc[S_D2] * inv_eb;
+  acc[I_PQ] += w * sc[S_Q] * inv_eb;
+  acc[I_TQ] += w * sc[S_Y] * inv_b;
+}
+__global__ void info_actor_kernel(const float* sc, float* acc, float inv_b, float target_entropy, const float* aux) {
+  const float alpha = aux[X_ALPHA];
+  acc[I_AL] = -(sc[S_QPI] - alpha * sc[S_LOGP]) * inv_b;
+  acc[I_TEMP] = alpha;
+  acc[I_ENT] = -sc[S_LOGP] * inv_b;
+  acc[I_TL] = alpha * (-sc[S_LOGP_NEXT] * inv_b - target_entropy);
+}
+
+}  // namespace
+
+extern "C" {
+
+int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
+  SERL_REQUIRE(cfg && out, "NULL argument");
+  SERL_REQUIRE(cfg->n_cam >= 1 && cfg->n_cam <= SERL_MAX_CAMS, "n_cam %d not in [1,%d]", cfg->n_cam, SERL_MAX_CAMS);
+  SERL_REQUIRE(cfg->H >= 32 && cfg->W >= 32, "images must be at least 32x32");
+  SERL_REQUIRE(cfg->hidden == 256 && cfg->bottleneck == 256, "hidden/bottleneck must be 256 (got %d/%d)", cfg->hidden, cfg->bottleneck);
+  SERL_REQUIRE(cfg->proprio_dim == 64, "proprio_dim must be 64");
+  SERL_REQUIRE(cfg->sle_features == 8, "sle_features must be 8");
+  SERL_REQUIRE(cfg->batch >= 1 && cfg->ensemble >= 2 && cfg->state_dim >= 1 && cfg->act_dim >= 1 && cfg->act_dim <= 64, "bad dims");
+  SERL_HIP(hipSetDevice(cfg->device));
+  serl_agent* a = new serl_agent();
+  a->cfg = *cfg;
+  build_layout(a);
+  const size_t bytes = carve(a, nullptr);
+  hipError_t e = hipMalloc(&a->arena, bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the agent arena failed: %s", bytes, hipGetErrorString(e));
+    delete a;
+    return SERL_ERR_HIP;
+  }
+  carve(a, a->arena);
+  SERL_HIP(hipMemset(a->arena, 0, bytes));
+  bind_trunk_weights(a);
+  *out = a;
+  return SERL_OK;
+}
+
+int serl_agent_destroy(serl_agent* a) {
+  if (!a) return SERL_OK;
+  (void)hipSetDevice(a->cfg.device);
+  (void)hipDeviceSynchronize();
+  if (a->arena) (void)hipFree(a->arena);
+  delete a;
+  return SERL_OK;
+}
+
+int serl_agent_num_leaves(serl_agent* a) {
+  return a ? (int)(a->theta_leaves.size() + a->trunk_leaves.size()) : -1;
+}
+
+int serl_agent_leaf_info(serl_agent* a, int i, char* name_out, int name_cap, int64_t* count) {
+  SERL_REQUIRE(a && name_out && count, "NULL argument");
+  const int nt = (int)a->theta_leaves.size();
+  SERL_REQUIRE(i >= 0 && i < serl_agent_num_leaves(a), "leaf index %d out of range", i);
+  const Leaf& l = i < nt ? a->theta_leaves[i] : a->trunk_leaves[i - nt];
+  snprintf(name_out, name_cap, "%s", l.name.c_str());
+  *count = l.count;
+  return SERL_OK;
+}
+
+// resolves (section, leaf) -> device pointer (nullptr = outside that optimizer's support)
+static int resolve(serl_agent* a, const char* section, const char* leaf, float** ptr, long* count, bool* zero) {
+  *zero = false;
+  const Leaf* t = find_leaf(a->trunk_leaves, leaf);
+  const Leaf* l = t ? t : find_leaf(a->theta_leaves, leaf);
+  SERL_REQUIRE(l != nullptr, "unknown leaf '%s'", leaf);
+  *count = l->count;
+  const std::string s(section);
+  const Offs& o = a->o;
+  if (s == "params") { *ptr = (t ? a->trunk : a->theta) + l->off; return SERL_OK; }
+  if (s == "target_params") { *ptr = (t ? a->trunk_t : a->theta_t) + l->off; return SERL_OK; }
+  const bool mu = s.size() > 3 && s.substr(s.size() - 3) == "/mu";
+  const bool nu = s.size() > 3 && s.substr(s.size() - 3) == "/nu";
+  SERL_REQUIRE(s.rfind("opt/", 0) == 0 && (mu || nu), "unknown section '%s'", section);
+  const std::string tx = s.substr(4, s.size() - 7);
+  *ptr = nullptr;
+  *zero = true;  // exact zeros outside the support (the gradient there is always exactly zero)
+  if (t) return SERL_OK;
+  if (tx == "critic") {
+    if (l->off < o.Pc) { *ptr = (mu ? a->m_c : a->v_c) + l->off; *zero = false; }
+  } else if (tx == "actor") {
+    if (l->off >= o.Pa0 && l->off < o.Pa1) { *ptr = (mu ? a->m_a : a->v_a) + (l->off - o.Pa0); *zero = false; }
+  } else if (tx == "temperature") {
+    if (l->off == o.lam) { *ptr = mu ? a->m_t : a->v_t; *zero = false; }
+  } else {
+    set_error("unknown optimizer '%s'", tx.c_str());
+    return SERL_ERR_INVALID;
+  }
+  return SERL_OK;
+}
+
+int serl_agent_set(serl_agent* a, const char* section, const char* leaf, const float* host, int64_t count) {
+  SERL_REQUIRE(a && section && leaf && host, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  float* p; long n; bool zero;
+  int rc = resolve(a, section, leaf, &p, &n, &zero);
+  if (rc) return rc;
+  SERL_REQUIRE(n == count, "leaf '%s' has %ld elements, got %lld", leaf, n, (long long)count);
+  if (zero) {
+    for (long i = 0; i < n; ++i)
+      SERL_REQUIRE(host[i] == 0.0f, "'%s' of '%s' lies outside the optimizer's support and must be zero", section, leaf);
+    return SERL_OK;
+  }
+  SERL_HIP(hipMemcpy(p, host, sizeof(float) * n, hipMemcpyHostToDevice));
+  return SERL_OK;
+}
+
+int serl_agent_get(serl_agent* a, const char* section, const char* leaf, float* host_out, int64_t count) {
+  SERL_REQUIRE(a && section && leaf && host_out, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  float* p; long n; bool zero;
+  int rc = resolve(a, section, leaf, &p, &n, &zero);
+  if (rc) return rc;
+  SERL_REQUIRE(n == count, "leaf '%s' has %ld elements, got %lld", leaf, n, (long long)count);
+  if (zero) { std::memset(host_out, 0, sizeof(float) * n); return SERL_OK; }
+  SERL_HIP(hipDeviceSynchronize());
+  SERL_HIP(hipMemcpy(host_out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return SERL_OK;
+}
+
+int serl_agent_set_step(serl_agent* a, int64_t step) {
+  SERL_REQUIRE(a && step >= 0, "bad argument");
+  a->step = step;
+  return SERL_OK;
+}
+int64_t serl_agent_get_step(serl_agent* a) { return a ? a->step : -1; }
+
+int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream) {
+  SERL_REQUIRE(a && dev_frames && dev_feats_out, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  return trunk_forward(a->tw, a->tws, dev_frames, n, dev_feats_out, (hipStream_t)stream);
+}
+
+static int check_batch(serl_agent* a, const serl_batch* b) {
+  const serl_agent_cfg& c = a->cfg;
+  SERL_REQUIRE(b && b->frames && b->state && b->action && b->reward && b->mask, "serl_batch has NULL members");
+  SERL_REQUIRE(b->batch >= 1 && b->batch <= c.batch, "batch %d not in [1,%d]", b->batch, c.batch);
+  SERL_REQUIRE(b->n_cam == c.n_cam && b->H == c.H && b->W == c.W && b->C == 3 && b->state_dim == c.state_dim &&
+                   b->act_dim == c.act_dim, "serl_batch shape does not match the agent");
+  return SERL_OK;
+}
+
+int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream) {
+  SERL_REQUIRE(a, "NULL agent");
+  int rc = check_batch(a, batch);
+  if (rc) return rc;
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  hipStream_t st = (hipStream_t)stream;
+  a->cur = *batch;
+  a->has_batch = true;
+  const serl_agent_cfg& c = a->cfg;
+  const int B = batch->batch;
+  const size_t fbytes = (size_t)c.H * c.W * 3;
+  if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
+    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, a->feats, st);
+  }
+  for (int w = 0; w < 2; ++w)
+    for (int k = 0; k < c.n_cam; ++k)
+      RC(trunk_forward(a->tw, a->tws, batch->frames + ((size_t)(w * c.n_cam + k) * B) * fbytes, B,
+                       a->feats + (((long)w * c.n_cam + k) * c.batch) * a->HW * 512, st));
+  return SERL_OK;
+}
+
+int serl_agent_begin_update(serl_agent* a, void* stream) {
+  SERL_REQUIRE(a, "NULL agent");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  SERL_HIP(hipMemsetAsync(a->info_acc, 0, sizeof(float) * I_N, (hipStream_t)stream));
+  return SERL_OK;
+}
+
+int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, const serl_noise* noise,
+                            int redq_row, void* stream) {
+  SERL_REQUIRE(a && a->has_batch, "serl_agent_encode must run first");
+  SERL_REQUIRE(off >= 0 && cnt >= 1 && off + cnt <= a->cur.batch && global_count >= cnt, "bad minibatch range");
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  hipStream_t st = (hipStream_t)stream;
+  SERL_HIP(hipSetDevice(c.device));
+  int i0, i1;
+  if (noise && noise->redq_idx) {
+    i0 = noise->redq_idx[2 * redq_row];
+    i1 = noise->redq_idx[2 * redq_row + 1];
+  } else {  // sac.py:150-157 randint(0, ensemble) x2, with replacement
+    uint64_t r = c.seed * 0x9E3779B97F4A7C15ull + (++a->noise_ctr) * 0xBF58476D1CE4E5B9ull;
+    r ^= r >> 29; r *= 0x94D049BB133111EBull; r ^= r >> 32;
+    i0 = (int)(r % c.ensemble);
+    i1 = (int)((r >> 32) % c.ensemble);
+  }
+  SERL_REQUIRE(i0 >= 0 && i0 < c.ensemble && i1 >= 0 && i1 < c.ensemble, "REDQ index out of range");
+  const float* eps; const uint8_t* mask;
+  RC(fetch_noise(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask, st));
+  const int A = c.act_dim;
+  // next actions from the online policy at next_obs (train=True: dropout) -> critT.x[:, E:]
+  RC(encode(a, a->theta, 1, off, cnt, mask, a->encP, st));
+  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, st));
+  // target critic at next_obs with target_params (encoder train=False)
+  RC(encode(a, a->theta_t, 1, off, cnt, nullptr, a->encT, st));
+  RC(critic_fwd(a, a->theta_t, a->critT, cnt, st));
+  // online critic at obs, batch actions
+  RC(encode(a, a->theta, 0, off, cnt, nullptr, a->encO, st));
+  RC(copy_cols(a->cur.action + (long)off * A, A, a->crit.x + a->E, a->XA, cnt, A, st));
+  RC(critic_fwd(a, a->theta, a->crit, cnt, st));
+  const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
+  RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
+                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, true, st));
+  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
+  RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
+                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
+  a->last_global = global_count;
+  return SERL_OK;
+}
+
+int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* noise, void* stream) {
+  SERL_REQUIRE(a && a->has_batch, "serl_agent_encode must run first");
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  hipStream_t st = (hipStream_t)stream;
+  SERL_HIP(hipSetDevice(c.device));
+  const int cnt = a->cur.batch, A = c.act_dim, Hd = c.hidden;
+  SERL_REQUIRE(global_count >= cnt, "global_count < local batch");
+  const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
+  RC(fetch_noise(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi, st));
+  RC(fetch_noise(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t, st));
+  RC(temperature_alpha(a->theta + o.lam, a->aux + X_ALPHA, st));
+  // temperature loss first (its activations are not needed afterwards): entropy of pi(next_obs)
+  RC(encode(a, a->theta, 1, 0, cnt, mask_t, a->encP, st));
+  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps_t, a->act_tmp, A, a->SC + S_LOGP_NEXT, st));
+  // policy loss: a ~ pi_params(obs) (dropout), Q_theta(obs, a) with theta constant (sac.py:193-221)
+  RC(encode(a, a->theta, 0, 0, cnt, mask_pi, a->encP, st));
+  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps_pi, a->crit.x + a->E, a->XA, a->SC + S_LOGP, st));
+  RC(encode(a, a->theta, 0, 0, cnt, nullptr, a->encO, st));
+  RC(critic_fwd(a, a->theta, a->crit, cnt, st));
+  RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, st));
+  RC(fill(a->dq, -1.0f / ((float)c.ensemble * (float)global_count), (long)c.ensemble * cnt, st));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, false, st));
+  RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
+                     1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, st));
+  // policy heads (mean, log_std): nbatch = 2 with uniform stride
+  const long hs = o.a_Ws - o.a_Wm;
+  float* Ga = a->Ga;
+  const long b0 = o.Pa0;
+  RC(wgrad(a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, st));
+  RC(colsum(a->dpre, nullptr, 2, cnt, A, Ga + (o.a_bm - b0), hs, false, st));
+  RC(igrad(a->dpre, A, (long)cnt * A, a->theta + o.a_Wm, A, hs, a->slabs, Hd, (long)cnt * Hd, 2, cnt, Hd, A, st));
+  RC(reduce_slabs(a->slabs, 2, (long)cnt * Hd, 1, cnt, Hd, nullptr, 0, a->dh2, Hd, 0, false, st));
+  RC(dense_ln_tanh_bwd(a, a->dh2, Hd, 0, a->pol.m.h2, Hd, 0, a->pol.m.xh2, a->pol.m.rs2, a->theta + o.a_g2, 0, 1, cnt, Hd,
+                       a->da2, a->dg2, Ga, o.a_g2 - b0, o.a_be2 - b0, o.a_b2 - b0, 0, st));
+  RC(wgrad(a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, st));
+  RC(igrad(a->da2, Hd, 0, a->theta + o.a_w2, Hd, 0, a->dh1, Hd, 0, 1, cnt, Hd, Hd, st));
+  RC(dense_ln_tanh_bwd(a, a->dh1, Hd, 0, a->pol.m.h1, Hd, 0, a->pol.m.xh1, a->pol.m.rs1, a->theta + o.a_g1, 0, 1, cnt, Hd,
+                       a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, st));
+  RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, st));
+  // image codes are stop-gradiented (encoding.py:48-49); only the proprio slice of d_enc is needed
+  const long pc = (long)c.n_cam * c.bottleneck;
+  RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, st));
+  RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, st));
+  a->last_global = global_count;
+  return SERL_OK;
+}
+
+int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) {
+  SERL_REQUIRE(a, "NULL agent");
+  SERL_REQUIRE(which == SERL_APPLY_CRITIC || which == SERL_APPLY_ACTOR_TEMP, "bad `which`");
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  hipStream_t st = (hipStream_t)stream;
+  SERL_HIP(hipSetDevice(c.device));
+  const bool crit = which == SERL_APPLY_CRITIC;
+  AdamArgs ad{};
+  ad.theta = a->theta; ad.theta_target = a->theta_t;
+  ad.P = o.P; ad.Pc = o.Pc; ad.Pa0 = o.Pa0; ad.Pa1 = o.Pa1;
+  ad.g_critic = a->Gc; ad.g_actor = a->Ga;
+  ad.m_c = a->m_c; ad.v_c = a->v_c; ad.m_a = a->m_a; ad.v_a = a->v_a; ad.m_t = a->m_t; ad.v_t = a->v_t;
+  ad.sum_logp_next = a->SC + S_LOGP_NEXT; ad.temp_grad_out = a->aux + X_TGRAD;
+  ad.critic_on = crit ? 1 : 0; ad.actor_on = crit ? 0 : 1; ad.temp_on = crit ? 0 : 1;
+  const float lr = lr_at(c, a->step);  // all three txs share count == step and the same schedule
+  ad.lr_c = ad.lr_a = ad.lr_t = lr;
+  const int64_t t = a->step + 1;
+  ad.bc1 = 1.0f - powf(0.9f, (float)t);
+  ad.bc2 = 1.0f - powf(0.999f, (float)t);
+  ad.tau = c.tau; ad.target_entropy = c.target_entropy;
+  ad.inv_batch = a->last_global > 0 ? 1.0f / (float)a->last_global : 0.f;
+  if (crit) {
+    hipLaunchKernelGGL(info_critic_kernel, dim3(1), dim3(1), 0, st, a->SC, a->info_acc,
+                       1.0f / ((float)c.ensemble * (float)a->last_global), 1.0f / (float)a->last_global, info_weight);
+  } else {
+    hipLaunchKernelGGL(info_actor_kernel, dim3(1), dim3(1), 0, st, a->SC, a->info_acc, 1.0f / (float)a->last_global,
+                       c.target_entropy, a->aux);
+  }
+  SERL_HIP(hipGetLastError());
+  RC(adam_ema(ad, st));
+  if (crit) RC(ema(a->trunk, a->trunk_t, c.tau, a->trunk_count, st));  // common.py:124-134 covers every leaf
+  a->step += 1;
+  a->lr_last = lr;
+  return SERL_OK;
+}
+
+int serl_agent_grad_view(serl_agent* a, int which, float** dev_ptr, int64_t* count) {
+  SERL_REQUIRE(a && dev_ptr && count, "NULL argument");
+  const Offs& o = a->o;
+  if (which == SERL_APPLY_CRITIC) { *dev_ptr = a->Gc; *count = o.Pc + kScalars; }
+  else if (which == SERL_APPLY_ACTOR_TEMP) { *dev_ptr = a->SC; *count = kScalars + (o.Pa1 - o.Pa0); }
+  else { set_error("bad `which`"); return SERL_ERR_INVALID; }
+  return SERL_OK;
+}
+
+int serl_agent_update_critics(serl_agent* a, const serl_batch* batch, const serl_noise* noise, void* stream) {
+  RC(serl_agent_begin_update(a, stream));
+  RC(serl_agent_encode(a, batch, stream));
+  RC(serl_agent_critic_grads(a, 0, batch->batch, batch->batch, noise, 0, stream));
+  return serl_agent_apply(a, SERL_APPLY_CRITIC, 1.0f, stream);
+}
+
+int serl_agent_update_high_utd(serl_agent* a, const serl_batch* batch, int utd_ratio, const serl_noise* noise,
+                               void* stream) {
+  SERL_REQUIRE(a && batch, "NULL argument");
+  SERL_REQUIRE(utd_ratio >= 1 && batch->batch % utd_ratio == 0,
+               "Batch size %d must be divisible by UTD ratio %d", batch->batch, utd_ratio);  // sac.py:561-563
+  RC(serl_agent_begin_update(a, stream));
+  RC(serl_agent_encode(a, batch, stream));
+  const int mb = batch->batch / utd_ratio;
+  for (int i = 0; i < utd_ratio; ++i) {
+    RC(serl_agent_critic_grads(a, i * mb, mb, mb, noise, i, stream));
+    RC(serl_agent_apply(a, SERL_APPLY_CRITIC, 1.0f / (float)utd_ratio, stream));
+  }
+  RC(serl_agent_actor_grads(a, batch->batch, noise, stream));
+  return serl_agent_apply(a, SERL_APPLY_ACTOR_TEMP, 1.0f, stream);
+}
+
+int serl_agent_read_info(serl_agent* a, serl_info* out, void* stream) {
+  SERL_REQUIRE(a && out, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  float acc[I_N];
+  SERL_HIP(hipMemcpyAsync(acc, a->info_acc, sizeof(acc), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SERL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  out->critic_loss = acc[I_CL]; out->predicted_qs = acc[I_PQ]; out->target_qs = acc[I_TQ];
+  out->actor_loss = acc[I_AL]; out->temperature = acc[I_TEMP]; out->entropy = acc[I_ENT];
+  out->temperature_loss = acc[I_TL];
+  out->actor_lr = out->critic_lr = out->temperature_lr = a->lr_last;
+  return SERL_OK;
+}
+
+int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const float* dev_state, int n,
+                              const float* dev_eps, float* dev_out_actions, void* stream) {
+  SERL_REQUIRE(a && dev_frames && dev_state && dev_out_actions, "NULL argument");
+  const serl_agent_cfg& c = a->cfg;
+  SERL_REQUIRE(n >= 1 && n <= c.batch, "n %d not in [1,%d]", n, c.batch);
+  hipStream_t st = (hipStream_t)stream;
+  SERL_HIP(hipSetDevice(c.device));
+  // trunk on [n_cam][n] images -> feats slot 0; state goes through a temporary serl_batch view
+  const size_t fbytes = (size_t)c.H * c.W * 3;
+  for (int k = 0; k < c.n_cam; ++k)
+    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats + ((long)k * c.batch) * a->HW * 512, st));
+  serl_batch saved = a->cur;
+  const bool had = a->has_batch;
+  a->cur = serl_batch{};
+  a->cur.batch = n;
+  a->cur.state = const_cast<float*>(dev_state);
+  RC(encode(a, a->theta, 0, 0, n, nullptr, a->encP, st));  // train=False: no dropout
+  if (!dev_eps) {  // argmax -> mode = tanh(mean): zero noise
+    RC(fill(a->eps_buf[0], 0.f, (long)n * c.act_dim, st));
+    dev_eps = a->eps_buf[0];
+  }
+  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, n, dev_eps, dev_out_actions, c.act_dim, nullptr, st));
+  a->cur = saved;
+  a->has_batch = had;
+  return SERL_OK;
+}
+
+int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64_t count) {
+  SERL_REQUIRE(a && what && host_out, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  const Offs& o = a->o;
+  const std::string w(what);
+  const float* p = nullptr;
+  long n = 0;
+  const serl_agent_cfg& c = a->cfg;
+  if (w == "g_critic") { p = a->Gc; n = o.Pc; }
+  else if (w == "g_actor") { p = a->Ga; n = o.Pa1 - o.Pa0; }
+  else if (w == "scalars") { p = a->SC; n = kScalars; }
+  else if (w == "q") { p = a->crit.q; n = (long)c.ensemble * c.batch; }
+  else if (w == "q_target") { p = a->critT.q; n = (long)c.ensemble * c.batch; }
+  else if (w == "target_q") { p = a->ytgt; n = c.batch; }
+  else if (w == "x") { p = a->crit.x; n = (long)c.batch * a->XA; }
+  else if (w == "x_target") { p = a->critT.x; n = (long)c.batch * a->XA; }
+  else if (w == "feats") { p = a->feats; n = 2L * c.n_cam * c.batch * a->HW * 512; }
+  else if (w == "logp") { p = a->pol.logp; n = c.batch; }
+  else if (w == "dx") { p = a->dx; n = (long)c.batch * a->XA; }
+  else { set_error("unknown debug tap '%s'", what); return SERL_ERR_INVALID; }
+  SERL_REQUIRE(count <= n && count > 0, "tap '%s' holds %ld floats, asked for %lld", what, n, (long long)count);
+  SERL_HIP(hipDeviceSynchronize());
+  SERL_HIP(hipMemcpy(host_out, p, sizeof(float) * count, hipMemcpyDeviceToHost));
+  return SERL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Host-callable launchers of heads.hip (internal, not part of the C ABI).
+#pragma once
+#include "internal.h"
+
+namespace serl {
+
+int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int rows, int N, const float* bias,
+                 long bias_gstride, float* out, long ld_out, long out_gstride, bool accumulate,
+                 hipStream_t stream, float scale = 1.0f);
+
+// rows are grouped (group g = row / rows_per_group) and every group has its own bias/gamma/beta at
+// `pstride` floats apart; the pre-activation is bias + sum of S GEMM slabs laid out [g*S + s][local row][D]
+struct LnFwdArgs {
+  const float* slabs; int S; long slab_stride;
+  const float *bias, *gamma, *beta; long pstride;
+  int rows, rows_per_group;
+  float* y; long ld_y; long y_goff;  // y[local_row*ld_y + group*y_goff + col] (column slices / group blocks)
+  float* xhat;           // [rows][D] or nullptr
+  float* rstd;           // [rows] or nullptr
+};
+int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream);
+
+struct LnBwdArgs {
+  const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y
+  const float* y; long ld_y; long y_goff;
+  const float* xhat; const float* rstd;
+  const float* gamma; long pstride;
+  int rows, rows_per_group;
+  float* dx;  // [rows][D] gradient wrt the pre-activation
+  float* dg;  // [rows][D] dy*(1-y^2)  (-> dbeta = colsum(dg), dgamma = colsum(dg*xhat))
+};
+int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream);
+
+int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
+           long out_gstride, bool accumulate, hipStream_t stream);
+int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
+            int Cc, hipStream_t stream);
+int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,
+            hipStream_t stream);
+int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);
+int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream);
+int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
+                int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
+                hipStream_t stream);
+int policy_dist_fwd(const float* pre, const float* eps, int B, int A, float std_min, float std_max, float* act,
+                    long ld_act, float* logp, float* std_out, float* sum_logp, hipStream_t stream);
+int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
+                    const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
+                    float std_min, float std_max, float* dpre, hipStream_t stream);
+int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream);
+int fill(float* p, float v, long n, hipStream_t stream);
+int temperature_alpha(const float* lam, float* out, hipStream_t stream);
+int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream);
+
+struct AdamArgs {
+  float *theta, *theta_target;
+  long P, Pc, Pa0, Pa1;  // critic-tx support [0,Pc), actor-tx support [Pa0,Pa1), temperature = P-1
+  const float *g_critic, *g_actor;
+  float *m_c, *v_c, *m_a, *v_a, *m_t, *v_t;
+  const float* sum_logp_next;  // device scalar: local/all-reduced sum of log pi(next)
+  float* temp_grad_out;        // device scalar (debug/export)
+  int critic_on, actor_on, temp_on;
+  float lr_c, lr_a, lr_t, bc1, bc2, tau, target_entropy, inv_batch;
+};
+int adam_ema(const AdamArgs& a, hipStream_t stream);
+int ema(const float* p, float* tp, float tau, long n, hipStream_t stream);
+int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream);
+int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream);
+
+}  // namespace serl

@@ -1,0 +1,609 @@
+// Dense building blocks of the SAC/DrQ update on MI355X: strided/batched/split-K fp32 MFMA GEMM and
+// the fused elementwise/normalisation kernels around it (LayerNorm+tanh forward/backward,
+// SpatialLearnedEmbeddings, tanh-Gaussian policy head, REDQ target, losses, 3x Adam + target EMA).
+// Reference semantics are cited per kernel (paths relative to serl_launcher/serl_launcher/).
+#include "heads.h"
+
+namespace serl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =============================================================================================
+// GEMM  C[z] = A[b] * B[b] over K-split `s`   (z = b*splitk + s)
+// 64x64 tile per 256-thread workgroup (2x2 waves, one 32x32 MFMA tile each), BK = 16, arbitrary
+// element strides (transposes are free), zero-filled edges.  Slabs are summed by the consumer
+// (reduce_slabs / ln_tanh_fwd), which keeps the K-split deterministic.
+// =============================================================================================
+constexpr int kGBM = 64, kGBN = 64, kGBK = 16, kGP = 68;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
+  __shared__ float As[2][kGBK][kGP];
+  __shared__ float Bs[2][kGBK][kGP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z, batch = z / g.splitk, split = z - batch * g.splitk;
+  const int m0 = blockIdx.y * kGBM, n0 = blockIdx.x * kGBN;
+  const int kper = ((g.K + g.splitk - 1) / g.splitk + kGBK - 1) / kGBK * kGBK;
+  const int k_begin = split * kper, k_end = min(g.K, k_begin + kper);
+  const float* A = g.A + (long)batch * g.sAb;
+  const float* B = g.B + (long)batch * g.sBb;
+  float* C = g.C + (long)z * g.sCz;
+  const bool a_kfast = g.sAk == 1, b_nfast = g.sBn == 1;
+  float ra[4], rb[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < g.M && gk < k_end) ? A[(long)gm * g.sAm + (long)gk * g.sAk] : 0.f;
+      int n, kb;
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      rb[i] = (gn < g.N && gkb < k_end) ? B[(long)gkb * g.sBk + (long)gn * g.sBn] : 0.f;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+      As[buf][k][m] = ra[i];
+      int n, kb;
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+      Bs[buf][kb][n] = rb[i];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  if (k_begin < k_end) {
+    load(k_begin);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += kGBK) {
+      const bool more = k0 + kGBK < k_end;
+      if (more) load(k0 + kGBK);
+#pragma unroll
+      for (int ks = 0; ks < kGBK / 2; ++ks) {
+        const float a = As[buf][2 * ks + lh][wm * 32 + li];
+        const float b = Bs[buf][2 * ks + lh][wn * 32 + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      if (more) store(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int n = n0 + wn * 32 + li;
+    if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[r];
+  }
+}
+
+int gemm_f32(const GemmDesc& g, hipStream_t stream) {
+  SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
+  dim3 grid(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// out[g][row][col] (+)= bias[g][col] + sum_s slab[g*S + s][row][col]
+__global__ void reduce_slabs_kernel(const float* slabs, int S, long slab_stride, int rows, int N,
+                                    const float* bias, long bias_gstride, float* out, long ld_out,
+                                    long out_gstride, int accumulate, float scale) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (e >= (long)rows * N) return;
+  const int row = (int)(e / N), col = (int)(e - (long)row * N);
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slabs[((long)grp * S + s) * slab_stride + e];
+  v *= scale;
+  if (bias) v += bias[(long)grp * bias_gstride + col];
+  float* o = out + (long)grp * out_gstride + (long)row * ld_out + col;
+  *o = accumulate ? *o + v : v;
+}
+
+int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int rows, int N, const float* bias,
+                 long bias_gstride, float* out, long ld_out, long out_gstride, bool accumulate,
+                 hipStream_t stream, float scale) {
+  dim3 grid(cdiv((long)rows * N, 256), groups);
+  hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, stream, slabs, S, slab_stride, rows, N, bias,
+                     bias_gstride, out, ld_out, out_gstride, accumulate ? 1 : 0, scale);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// LayerNorm(eps 1e-6, fast variance) + tanh, one wave per row.   mlp.py:24-31, resnet_v1.py:371-374,
+// encoding.py:66-68.   pre = bias[g] + sum_s slab[s][row];  y = tanh(gamma[g]*xhat + beta[g])
+// =============================================================================================
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(LnFwdArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const int grp = row / a.rows_per_group;
+  constexpr int D = VPL * 64;
+  float v[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    float x = a.bias ? a.bias[(long)grp * a.pstride + col] : 0.f;
+    for (int s = 0; s < a.S; ++s)
+      x += a.slabs[(long)(grp * a.S + s) * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + col];
+    v[j] = x;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float mean = s1 * (1.0f / D), mean2 = s2 * (1.0f / D);
+  const float var = fmaxf(mean2 - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    const float xh = (v[j] - mean) * rstd;
+    const float y = tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]);
+    a.y[(long)(row - grp * a.rows_per_group) * a.ld_y + (long)grp * a.y_goff + col] = y;
+    if (a.xhat) a.xhat[(long)row * D + col] = xh;
+  }
+  if (a.rstd && lane == 0) a.rstd[row] = rstd;
+}
+
+int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream) {
+  SERL_REQUIRE(D == 256 || D == 64, "LayerNorm width %d unsupported (64 or 256)", D);
+  dim3 grid(cdiv(a.rows, 4));
+  if (D == 256) hipLaunchKernelGGL(ln_tanh_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(ln_tanh_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// backward of y = tanh(gamma*xhat + beta), xhat = (x-mean)*rstd:
+//   dg = dy*(1-y^2);  dxhat = dg*gamma;  dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(LnBwdArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const int grp = row / a.rows_per_group;
+  constexpr int D = VPL * 64;
+  float dg[VPL], dxh[VPL], xh[VPL];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    const long lr = row - grp * a.rows_per_group;
+    const float y = a.y[lr * a.ld_y + (long)grp * a.y_goff + col];
+    const float dy = a.dy[lr * a.ld_dy + (long)grp * a.dy_goff + col];
+    dg[j] = dy * (1.f - y * y);
+    xh[j] = a.xhat[(long)row * D + col];
+    dxh[j] = dg[j] * a.gamma[(long)grp * a.pstride + col];
+    s1 += dxh[j];
+    s2 += dxh[j] * xh[j];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float m1 = s1 * (1.0f / D), m2 = s2 * (1.0f / D), rstd = a.rstd[row];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    a.dx[(long)row * D + col] = rstd * (dxh[j] - m1 - xh[j] * m2);
+    a.dg[(long)row * D + col] = dg[j];
+  }
+}
+
+int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream) {
+  SERL_REQUIRE(D == 256 || D == 64, "LayerNorm width %d unsupported (64 or 256)", D);
+  dim3 grid(cdiv(a.rows, 4));
+  if (D == 256) hipLaunchKernelGGL(ln_tanh_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(ln_tanh_bwd_kernel<1>, grid, dim3(256), 0, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// out[g][col] (+)= sum_{r in group g} X[r][col] * (Y ? Y[r][col] : 1)     (bias / LN-param grads)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, const float* Y, int rows_per_group,
+                                                    int D, float* out, long out_gstride, int accumulate) {
+  __shared__ float red[4][64];
+  const int grp = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < D) {
+    const long base = (long)grp * rows_per_group;
+    for (int r = part; r < rows_per_group; r += 4) {
+      const float x = X[(base + r) * D + col];
+      s += Y ? x * Y[(base + r) * D + col] : x;
+    }
+  }
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && col < D) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* o = out + (long)grp * out_gstride + col;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
+           long out_gstride, bool accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64), groups), dim3(256), 0, stream, X, Y, rows_per_group, D,
+                     out, out_gstride, accumulate ? 1 : 0);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// SpatialLearnedEmbeddings (resnet_v1.py:94-111): f[n][c*F+j] = sum_hw x[n][hw][c]*K[hw][c][j]
+// (+ Dropout(0.1) keep-mask, resnet_v1.py:351).  F == 8.
+// =============================================================================================
+__global__ __launch_bounds__(256) void sle_fwd_kernel(const float* x, const float* K, const uint8_t* mask,
+                                                     float keep_scale, float* f, int N, int HW, int Cc) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * Cc) return;
+  const int n = (int)(e / Cc), c = (int)(e - (long)n * Cc);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int hw = 0; hw < HW; ++hw) {
+    const float xv = x[((long)n * HW + hw) * Cc + c];
+    const float4 k0 = *reinterpret_cast<const float4*>(K + ((long)hw * Cc + c) * 8);
+    const float4 k1 = *reinterpret_cast<const float4*>(K + ((long)hw * Cc + c) * 8 + 4);
+    acc[0] += xv * k0.x; acc[1] += xv * k0.y; acc[2] += xv * k0.z; acc[3] += xv * k0.w;
+    acc[4] += xv * k1.x; acc[5] += xv * k1.y; acc[6] += xv * k1.z; acc[7] += xv * k1.w;
+  }
+  float* o = f + (long)n * Cc * 8 + (long)c * 8;
+  if (mask) {
+    const uint8_t* m = mask + (long)n * Cc * 8 + (long)c * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = m[j] ? acc[j] * keep_scale : 0.f;
+  }
+  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
+            int Cc, hipStream_t stream) {
+  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256)), dim3(256), 0, stream, x, K, mask,
+                     keep_scale, f, N, HW, Cc);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// dK partial[split][hw][c][j] = sum_{n in split} x[n][hw][c] * df[n][c*8+j]
+__global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const float* df, float* partial, int N,
+                                                     int HW, int Cc, int nsplit) {
+  const int c = blockIdx.x * 256 + threadIdx.x, hw = blockIdx.y, sp = blockIdx.z;
+  if (c >= Cc) return;
+  const int per = (N + nsplit - 1) / nsplit;
+  const int nb = sp * per, ne = min(N, nb + per);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int n = nb; n < ne; ++n) {
+    const float xv = x[((long)n * HW + hw) * Cc + c];
+    const float4 d0 = *reinterpret_cast<const float4*>(df + (long)n * Cc * 8 + (long)c * 8);
+    const float4 d1 = *reinterpret_cast<const float4*>(df + (long)n * Cc * 8 + (long)c * 8 + 4);
+    acc[0] += xv * d0.x; acc[1] += xv * d0.y; acc[2] += xv * d0.z; acc[3] += xv * d0.w;
+    acc[4] += xv * d1.x; acc[5] += xv * d1.y; acc[6] += xv * d1.z; acc[7] += xv * d1.w;
+  }
+  float* o = partial + (((long)sp * HW + hw) * Cc + c) * 8;
+  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,
+            hipStream_t stream) {
+  hipLaunchKernelGGL(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit), dim3(256), 0, stream, x, df, partial, N,
+                     HW, Cc, nsplit);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// critic head (actor_critic_nets.py:65-73; shared Dense(1) over the ensemble, drq.py:201-207)
+// =============================================================================================
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float* w, const float* b, float* q,
+                                                    int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4 hv = *reinterpret_cast<const float4*>(h + (long)row * 256 + lane * 4);
+  const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
+  float s = hv.x * wv.x + hv.y * wv.y + hv.z * wv.z + hv.w * wv.w;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+  if (lane == 0) q[row] = s + b[0];
+}
+
+int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream) {
+  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, h, w, b, q, rows);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// dh[r][j] = dq[r]*w[j]
+__global__ void outer_kernel(const float* dq, const float* w, float* dh, int rows) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)rows * 256) return;
+  dh[e] = dq[e >> 8] * w[e & 255];
+}
+
+int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream) {
+  hipLaunchKernelGGL(outer_kernel, dim3(cdiv((long)rows * 256, 256)), dim3(256), 0, stream, dq, w, dh, rows);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// REDQ target + critic loss (sac.py:142-191).  Single workgroup: deterministic reductions.
+//   y[b] = r[b] + discount*mask[b]*min(Qt[i0][b], Qt[i1][b]);  dQ = 2(Q-y)/(E*Bg)
+//   scalars[0..2] = sum (Q-y)^2, sum Q, sum y   (local sums; the host / all-reduce normalises)
+//   dhead_b = sum dQ  (gradient of the shared head bias)
+// =============================================================================================
+__global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const float* q, const float* reward,
+                                                         const float* mask, int i0, int i1, int E, int B,
+                                                         float discount, float inv_norm, float* y_out,
+                                                         float* dq, float* scalars, float* dbias) {
+  __shared__ float red[4][256];
+  float s_d2 = 0.f, s_q = 0.f, s_y = 0.f, s_dq = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float y = reward[b] + discount * mask[b] * fminf(qt[(long)i0 * B + b], qt[(long)i1 * B + b]);
+    y_out[b] = y;
+    s_y += y;
+    for (int e = 0; e < E; ++e) {
+      const float qv = q[(long)e * B + b];
+      const float d = qv - y;
+      const float g = 2.f * d * inv_norm;
+      dq[(long)e * B + b] = g;
+      s_d2 += d * d;
+      s_q += qv;
+      s_dq += g;
+    }
+  }
+  red[0][threadIdx.x] = s_d2; red[1][threadIdx.x] = s_q; red[2][threadIdx.x] = s_y; red[3][threadIdx.x] = s_dq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    scalars[0] = red[0][0]; scalars[1] = red[1][0]; scalars[2] = red[2][0];
+    *dbias = red[3][0];
+  }
+}
+
+int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
+                int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
+                hipStream_t stream) {
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, stream, qt, q, reward, mask, i0, i1, E, B,
+                     discount, inv_norm, y_out, dq, scalars, dbias);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// tanh-Gaussian policy head (actor_critic_nets.py:179-272, distrax MultivariateNormalDiag + Tanh)
+//   std = clip(exp(log_std), std_min, std_max); u = mean + std*eps; a = tanh(u)
+//   logp = sum_j(-eps^2/2 - log std - log(2pi)/2) - sum_j 2(log2 - u - softplus(-2u))
+// pre: [2][B][A] (mean slab, log_std slab; biases already added)
+// =============================================================================================
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__global__ void policy_dist_fwd_kernel(const float* pre, const float* eps, int B, int A, float std_min,
+                                       float std_max, float* act, long ld_act, float* logp, float* std_out,
+                                       float* sum_logp /* nullable: scalar accumulated by one block */) {
+  __shared__ float red[256];
+  float local = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float mean = pre[(long)b * A + j], ls = pre[((long)B + b) * A + j], e = eps[(long)b * A + j];
+      const float sd = fminf(fmaxf(expf(ls), std_min), std_max);
+      const float u = mean + sd * e;
+      act[(long)b * ld_act + j] = tanhf(u);
+      std_out[(long)b * A + j] = sd;
+      lp += -0.5f * e * e - logf(sd) - 0.91893853320467274f;
+      lp -= 2.f * (0.69314718055994531f - u - softplusf(-2.f * u));
+    }
+    logp[b] = lp;
+    local += lp;
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sum_logp) *sum_logp = red[0];
+}
+
+int policy_dist_fwd(const float* pre, const float* eps, int B, int A, float std_min, float std_max, float* act,
+                    long ld_act, float* logp, float* std_out, float* sum_logp, hipStream_t stream) {
+  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(1), dim3(256), 0, stream, pre, eps, B, A, std_min, std_max,
+                     act, ld_act, logp, std_out, sum_logp);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// backward of the actor loss through the distribution:
+//   G_u = dL/da*(1-a^2) + c_lp*2a   (d logp/du = 2 tanh u);  dmean = G_u;
+//   dstd = G_u*eps - c_lp/std;  dlog_std = dstd*std if std_min < exp(ls) < std_max else 0
+// dpre: [2][B][A].  c_lp = dL/dlogp (device scalar *alpha times coef).
+__global__ void policy_dist_bwd_kernel(const float* da, long ld_da, const float* act, long ld_act,
+                                       const float* pre, const float* stdv, const float* eps,
+                                       const float* alpha, float coef, int B, int A, float std_min,
+                                       float std_max, float* dpre) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * A) return;
+  const int b = e / A, j = e - b * A;
+  const float c_lp = alpha[0] * coef;
+  const float a = act[(long)b * ld_act + j];
+  const float gu = da[(long)b * ld_da + j] * (1.f - a * a) + c_lp * 2.f * a;
+  const float sd = stdv[e];
+  const float raw = expf(pre[((long)B + b) * A + j]);
+  const float dstd = gu * eps[e] - c_lp / sd;
+  dpre[e] = gu;
+  dpre[(long)B * A + e] = (raw > std_min && raw < std_max) ? dstd * sd : 0.f;
+}
+
+int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
+                    const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
+                    float std_min, float std_max, float* dpre, hipStream_t stream) {
+  hipLaunchKernelGGL(policy_dist_bwd_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, stream, da, ld_da, act,
+                     ld_act, pre, stdv, eps, alpha, coef, B, A, std_min, std_max, dpre);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// small helpers ---------------------------------------------------------------------------------
+__global__ void copy_cols_kernel(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int r = e / cols, c = e - r * cols;
+  dst[(long)r * ld_dst + c] = src[(long)r * ld_src + c];
+}
+int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream) {
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, stream, src, ld_src, dst,
+                     ld_dst, rows, cols);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) p[e] = v;
+}
+int fill(float* p, float v, long n, hipStream_t stream) {
+  hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, v, n);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// alpha = softplus(lambda) (lagrange.py:49-50);  scalars[slot] = alpha
+__global__ void alpha_kernel(const float* lam, float* out) { out[0] = softplusf(lam[0]); }
+int temperature_alpha(const float* lam, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, lam, out);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// sum over rows of the ensemble-mean Q (actor loss info): scalars[out] = sum_b mean_e q[e][b]
+__global__ __launch_bounds__(256) void qmean_sum_kernel(const float* q, int E, int B, float* out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float m = 0.f;
+    for (int e = 0; e < E; ++e) m += q[(long)e * B + b];
+    s += m / (float)E;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(qmean_sum_kernel, dim3(1), dim3(256), 0, stream, q, E, B, out);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// 3x Adam over the full tree (restricted to each optimizer's non-zero support) + summed update +
+// target EMA.  common.py:124-168, optimizers.py:32-46, optax.adam(b1 .9, b2 .999, eps 1e-8).
+// A tx that is not in networks_to_update still steps with g = 0 (sac.py:276-277): its moments
+// decay and its momentum keeps moving the parameters.
+// =============================================================================================
+__global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.P) return;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  float p = a.theta[i];
+  float ua = 0.f, uc = 0.f, ut = 0.f;
+  if (i < a.Pc) {
+    const float g = a.critic_on ? a.g_critic[i] : 0.f;
+    const float m = b1 * a.m_c[i] + (1.f - b1) * g;
+    const float v = b2 * a.v_c[i] + (1.f - b2) * g * g;
+    a.m_c[i] = m; a.v_c[i] = v;
+    uc = -a.lr_c * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
+  }
+  if (i >= a.Pa0 && i < a.Pa1) {
+    const long k = i - a.Pa0;
+    const float g = a.actor_on ? a.g_actor[k] : 0.f;
+    const float m = b1 * a.m_a[k] + (1.f - b1) * g;
+    const float v = b2 * a.v_a[k] + (1.f - b2) * g * g;
+    a.m_a[k] = m; a.v_a[k] = v;
+    ua = -a.lr_a * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
+  }
+  if (i == a.P - 1) {  // temperature multiplier (lagrange.py): dL/dlambda = sigmoid(lambda)*(H - H_target)
+    float g = 0.f;
+    if (a.temp_on) {
+      const float H = -a.sum_logp_next[0] * a.inv_batch;
+      g = (1.f / (1.f + expf(-p))) * (H - a.target_entropy);
+      a.temp_grad_out[0] = g;
+    }
+    const float m = b1 * a.m_t[0] + (1.f - b1) * g;
+    const float v = b2 * a.v_t[0] + (1.f - b2) * g * g;
+    a.m_t[0] = m; a.v_t[0] = v;
+    ut = -a.lr_t * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
+  }
+  p = p + ((ua + uc) + ut);
+  a.theta[i] = p;
+  if (a.critic_on) a.theta_target[i] = p * a.tau + a.theta_target[i] * (1.f - a.tau);
+}
+
+int adam_ema(const AdamArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P, 256)), dim3(256), 0, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+__global__ void ema_kernel(const float* p, float* tp, float tau, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tp[i] = p[i] * tau + tp[i] * (1.f - tau);
+}
+int ema(const float* p, float* tp, float tau, long n, hipStream_t stream) {
+  hipLaunchKernelGGL(ema_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, tp, tau, n);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// =============================================================================================
+// device noise (production mode): counter-based hash -> N(0,1) and Bernoulli(keep) masks
+// =============================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void gen_normal_kernel(float* out, long n, uint64_t seed) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = mix64(seed ^ mix64((uint64_t)i));
+  const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);
+  const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  out[i] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+__global__ void gen_mask_kernel(uint8_t* out, long n, uint64_t seed, float keep) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = mix64(seed ^ mix64((uint64_t)i + 0x51ED270Bull));
+  out[i] = ((float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f)) < keep ? 1 : 0;
+}
+int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
+  hipLaunchKernelGGL(gen_normal_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, n, seed);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream) {
+  hipLaunchKernelGGL(gen_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, n, seed, keep);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+}  // namespace serl

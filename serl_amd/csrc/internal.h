@@ -1,0 +1,64 @@
+// Internal (non-ABI) interfaces between the translation units of libserl_mi355.so.
+#pragma once
+#include "common.h"
+
+namespace serl {
+
+// --------------------------------------------------------------------------------------------
+// Frozen ResNet-10 trunk (reference: serl_launcher/vision/resnet_v1.py:189-286, config :383-385)
+// --------------------------------------------------------------------------------------------
+constexpr int kTrunkStages = 4;
+constexpr int kStageFilters[kTrunkStages] = {64, 128, 256, 512};
+constexpr int kStageStride[kTrunkStages] = {1, 2, 2, 2};
+constexpr int kGnGroups = 4;
+
+struct TrunkWeights {  // device pointers into the agent's parameter arena (HWIO conv kernels)
+  const float* conv_init;  // [7][7][3][64]
+  const float *gn_init_s, *gn_init_b;
+  struct Block {
+    const float *conv0, *gn0_s, *gn0_b, *conv1, *gn1_s, *gn1_b, *proj, *gnp_s, *gnp_b;
+  } blk[kTrunkStages];
+};
+
+struct TrunkDims {
+  int H, W;            // input image
+  int h[6], w[6];      // [0]=conv_init out, [1]=pool out, [2..5]=block outputs
+};
+TrunkDims trunk_dims(int H, int W);
+
+struct TrunkWorkspace {
+  int max_images = 0;
+  TrunkDims d{};
+  float* raw_init = nullptr;  // [N][h0][w0][64]
+  float* pool = nullptr;      // [N][h1][w1][64]
+  struct B {
+    float *raw0, *raw1, *rawp, *out;
+  } blk[kTrunkStages]{};
+  double* stats = nullptr;  // 13 GN layers x [N][4][2]
+  float* coef = nullptr;    // 13 GN layers x 2 x [N][512]
+  void* base = nullptr;     // single allocation backing everything above
+  size_t bytes = 0;
+};
+size_t trunk_workspace_bytes(int max_images, int H, int W);
+// carve `ws` out of caller-provided device memory (at least trunk_workspace_bytes big)
+int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, int W);
+// frames: u8 [n][H][W][3] (device) -> feats: f32 [n][h5][w5][512] (device)
+int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n,
+                  float* feats_out, hipStream_t stream);
+
+// --------------------------------------------------------------------------------------------
+// small dense building blocks (heads.hip)
+// --------------------------------------------------------------------------------------------
+struct GemmDesc {
+  const float* A;
+  const float* B;
+  float* C;            // slab base; slab z at C + z*sCz
+  int M, N, K;
+  long sAm, sAk, sAb;  // element strides of A[m][k] and per-batch offset
+  long sBk, sBn, sBb;
+  long ldc, sCz;       // row stride of C and slab stride
+  int nbatch, splitk;  // grid.z = nbatch*splitk, z = batch*splitk + split
+};
+int gemm_f32(const GemmDesc& g, hipStream_t stream);
+
+}  // namespace serl

@@ -1,0 +1,595 @@
+// Frozen ResNet-10 trunk forward for MI355X (gfx950), fp32 in / fp32 accumulate on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32).  Reference semantics: serl_launcher/vision/resnet_v1.py:189-286
+// (normalise -> conv7x7/2 -> GN -> ReLU -> maxpool3x3/2 SAME -> 4 basic blocks, GroupNorm(4 groups,
+// eps 1e-5, fast variance), XLA SAME padding (lo 0, hi 1) for the stride-2 3x3 convs).
+//
+// Layout: activations NHWC fp32, conv kernels HWIO ( = row-major [K = kh*kw*Cin][Cout] GEMM B operand).
+// Every conv is an implicit GEMM  C[M = N*Ho*Wo][Cout] = im2col(A)[M][K] * W[K][Cout]:
+//   * 256-thread workgroups, 4 waves, each wave owns a 64x64 output tile = 2x2 MFMA 32x32 tiles;
+//   * BK = 32 K-chunks lie inside one (ky,kx) tap, so an A-tile row is one contiguous 128-byte
+//     channel segment of the NHWC input (or zeros outside the image) -> 16-byte coalesced loads;
+//   * register-staged double-buffered LDS (global loads of chunk c+1 are in flight under the
+//     MFMAs of chunk c), LDS row pitch 33 floats: conflict-free ds_read_b32 for the MFMA operands;
+//   * the previous layer's GroupNorm+ReLU is applied on load (per-sample scale/shift table), and
+//     this layer's GroupNorm statistics are reduced in the epilogue (fp64 atomics per (image,
+//     group)), so no activation is re-read just to be normalised.
+#include <algorithm>
+
+#include "internal.h"
+
+namespace serl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware bijective workgroup remap (8 XCDs, block b is dispatched to XCD b % 8): gives every
+// XCD a contiguous range of tile ids so tiles that share A rows / weights hit the same L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// GroupNorm statistics: 64-lane reduction of per-lane partial (sum, sumsq) in 16-lane channel
+// segments (+ the two row halves), then one fp64 atomic per 16-channel segment.
+__device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /* [G][2] of image */,
+                                            int chan, int gsize, bool valid) {
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  s += __shfl_xor(s, 32);
+  q += __shfl_xor(q, 32);
+  const int lane = threadIdx.x & 63;
+  if (valid && (lane & 15) == 0 && lane < 32) {
+    const int g = chan / gsize;
+    atomicAdd(&stats_ng[2 * g], (double)s);
+    atomicAdd(&stats_ng[2 * g + 1], (double)q);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_init: u8 image -> ImageNet normalise -> conv 7x7 stride 2 pad 3, 3 -> 64 (K = 147 -> 148)
+// One workgroup = 16x16 output pixels of one image x all 64 output channels.
+// ---------------------------------------------------------------------------------------------
+struct ConvInitArgs {
+  const uint8_t* img;  // [N][H][W][3]
+  const float* w;      // [147][64]
+  float* out;          // [N][Ho][Wo][64]
+  double* stats;       // [N][4][2]
+  int N, H, W, Ho, Wo, tiles_y, tiles_x;
+};
+
+constexpr int kCiPatch = 37;             // 2*16 + 5 input rows/cols per 16x16 output tile
+constexpr int kCiPW = kCiPatch * 3 + 2;  // LDS patch row pitch (floats)
+constexpr int kCiK = 148;                // 147 padded to a multiple of the MFMA K (2)
+constexpr int kCiBS = 64 + 4;            // weight row pitch in LDS
+
+__global__ __launch_bounds__(256) void conv_init_kernel(ConvInitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                      // [37][kCiPW]
+  float* wl = smem + kCiPatch * kCiPW + 3;  // [148][68]  (+3 keeps 16B alignment: 37*113=4181 -> 4184)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = b % a.tiles_x;
+  b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int oy0 = ty * 16, ox0 = tx * 16;
+  // weights -> LDS (row 147 zero)
+  for (int v = tid; v < kCiK * 16; v += 256) {
+    const int row = v >> 4, c4 = v & 15;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < 147) val = *reinterpret_cast<const float4*>(a.w + row * 64 + c4 * 4);
+    *reinterpret_cast<float4*>(wl + row * kCiBS + c4 * 4) = val;
+  }
+  // normalised input patch -> LDS (zero outside the image: the conv pads the NORMALISED tensor)
+  const uint8_t* img = a.img + (size_t)n * a.H * a.W * 3;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  for (int v = tid; v < kCiPatch * kCiPatch * 3; v += 256) {
+    const int yy = v / (kCiPatch * 3), rest = v - yy * (kCiPatch * 3);
+    const int xx = rest / 3, ch = rest - xx * 3;
+    const int iy = iy0 + yy, ix = ix0 + xx;
+    float val = 0.f;
+    if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+      const float mean = ch == 0 ? 0.485f : (ch == 1 ? 0.456f : 0.406f);
+      const float stdv = ch == 0 ? 0.229f : (ch == 1 ? 0.224f : 0.225f);
+      val = ((float)img[((size_t)iy * a.W + ix) * 3 + ch] / 255.0f - mean) / stdv;
+    }
+    patch[yy * kCiPW + rest] = val;
+  }
+  __syncthreads();
+  // wave `wave` owns output pixels [wave*64, wave*64+64) of the 16x16 tile (row-major), 64 channels
+  const int i = lane & 31, h = lane >> 5;
+  int abase[2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int p = wave * 64 + tm * 32 + i;
+    abase[tm] = (2 * (p >> 4)) * kCiPW + (p & 15) * 6;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+#pragma unroll 2
+  for (int ks = 0; ks < kCiK / 2; ++ks) {
+    const int k = 2 * ks + h;
+    const int kk = k < 147 ? k : 0;  // padded k reads a finite value; its weight row is zero
+    const int ky = kk / 21, rest = kk - ky * 21;
+    const int koff = ky * kCiPW + rest;
+    const float a0 = patch[abase[0] + koff], a1 = patch[abase[1] + koff];
+    const float b0 = wl[k * kCiBS + i], b1 = wl[k * kCiBS + 32 + i];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+  // epilogue: raw output + GroupNorm statistics
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      const bool ok = oy < a.Ho && ox < a.Wo;
+      float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const float v = ok ? acc[tm][tn][r] : 0.f;
+        if (ok) o[tn * 32 + i] = v;
+        s[tn] += v;
+        q[tn] += v * v;
+      }
+    }
+  double* st = a.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + i, 16, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm coefficients: stats (sum, sumsq) -> per (image, channel) scale/shift
+//   y = x*sc + sh,  sc = gamma*rsqrt(var+eps),  sh = beta - mean*sc,  var = max(0, E[x^2]-E[x]^2)
+// ---------------------------------------------------------------------------------------------
+__global__ void gn_coef_kernel(const double* stats, const float* gamma, const float* beta, float* sc,
+                               float* sh, int N, int Cc, double inv_count, float eps) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * Cc) return;
+  const int n = e / Cc, c = e - n * Cc;
+  const int g = c / (Cc / kGnGroups);
+  const double mean = stats[((size_t)n * kGnGroups + g) * 2] * inv_count;
+  const double m2 = stats[((size_t)n * kGnGroups + g) * 2 + 1] * inv_count;
+  const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float scv = gamma[c] * rstd;
+  sc[e] = scv;
+  sh[e] = beta[c] - (float)mean * scv;
+}
+
+// fallback GroupNorm statistics pass (used when the conv epilogue cannot attribute its rows to
+// images, i.e. Ho*Wo is neither a multiple of 64 nor 16/32): one workgroup per (image, group).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* stats, int P, int Cc) {
+  const int n = blockIdx.x / kGnGroups, g = blockIdx.x % kGnGroups;
+  const int gs = Cc / kGnGroups;
+  const float* xb = x + (size_t)n * P * Cc + g * gs;
+  double s = 0.0, q = 0.0;
+  for (int e = threadIdx.x; e < P * gs; e += 256) {
+    const int p = e / gs, c = e - p * gs;
+    const float v = xb[(size_t)p * Cc + c];
+    s += v;
+    q += (double)v * v;
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[((size_t)n * kGnGroups + g) * 2] = red[0][0];
+    stats[((size_t)n * kGnGroups + g) * 2 + 1] = red[1][0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GN-apply + ReLU + max_pool 3x3 stride 2 SAME (pad lo 0 / hi 1 with -inf)   (resnet_v1.py:257-259)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* x, const float* sc,
+                                                             const float* sh, float* out, int N, int Hi,
+                                                             int Wi, int Ho, int Wo, int Cc) {
+  const int c4n = Cc / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * Ho * Wo * c4n) return;
+  const int c4 = (int)(e % c4n);
+  long t = e / c4n;
+  const int ox = (int)(t % Wo);
+  t /= Wo;
+  const int oy = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  const float4 s = *reinterpret_cast<const float4*>(sc + (size_t)n * Cc + c4 * 4);
+  const float4 h = *reinterpret_cast<const float4*>(sh + (size_t)n * Cc + c4 * 4);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 + dy;
+    if (iy >= Hi) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 + dx;
+      if (ix >= Wi) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * Hi + iy) * Wi + ix) * Cc + c4 * 4);
+      m.x = fmaxf(m.x, fmaxf(v.x * s.x + h.x, 0.f));
+      m.y = fmaxf(m.y, fmaxf(v.y * s.y + h.y, 0.f));
+      m.z = fmaxf(m.z, fmaxf(v.z * s.z + h.z, 0.f));
+      m.w = fmaxf(m.w, fmaxf(v.w * s.w + h.w, 0.f));
+    }
+  }
+  *reinterpret_cast<float4*>(out + (((size_t)n * Ho + oy) * Wo + ox) * Cc + c4 * 4) = m;
+}
+
+// block output: out = relu( GN(raw_b) + residual ), residual = res (already activated) or GN(res_raw)
+__global__ __launch_bounds__(256) void block_out_kernel(const float* raw, const float* sc, const float* sh,
+                                                       const float* res, const float* rsc,
+                                                       const float* rsh, float* out, int N, int P, int Cc) {
+  const int c4n = Cc / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * P * c4n) return;
+  const int c4 = (int)(e % c4n);
+  const int n = (int)(e / ((long)P * c4n));
+  const float4 v = reinterpret_cast<const float4*>(raw)[e];
+  const float4 s = *reinterpret_cast<const float4*>(sc + (size_t)n * Cc + c4 * 4);
+  const float4 h = *reinterpret_cast<const float4*>(sh + (size_t)n * Cc + c4 * 4);
+  float4 r = reinterpret_cast<const float4*>(res)[e];
+  if (rsc) {
+    const float4 s2 = *reinterpret_cast<const float4*>(rsc + (size_t)n * Cc + c4 * 4);
+    const float4 h2 = *reinterpret_cast<const float4*>(rsh + (size_t)n * Cc + c4 * 4);
+    r.x = r.x * s2.x + h2.x; r.y = r.y * s2.y + h2.y; r.z = r.z * s2.z + h2.z; r.w = r.w * s2.w + h2.w;
+  }
+  float4 o;
+  o.x = fmaxf(r.x + (v.x * s.x + h.x), 0.f);
+  o.y = fmaxf(r.y + (v.y * s.y + h.y), 0.f);
+  o.z = fmaxf(r.z + (v.z * s.z + h.z), 0.f);
+  o.w = fmaxf(r.w + (v.w * s.w + h.w), 0.f);
+  reinterpret_cast<float4*>(out)[e] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic implicit-GEMM conv (3x3 / 1x1, Cin % 32 == 0, Cout % (64*WN) == 0)
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* in;     // [N][Hi][Wi][Cin]
+  const float* w;      // [KH*KW*Cin][Cout]
+  float* out;          // [N][Ho][Wo][Cout]
+  double* stats;       // [N][4][2] or nullptr
+  const float* in_sc;  // [N][Cin] GroupNorm-on-load (with ReLU) or nullptr
+  const float* in_sh;
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, padw;
+  int M, P, tiles_m, tiles_n;
+};
+
+// PMODE: how output rows map to images for the GN statistics
+//   0: P % 64 == 0 (a wave's 64 rows lie in one image)   1: P == 32   2: P == 16   3: no stats
+template <int WM, int WN, int PMODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = 64 * WM, BN = 64 * WN, AS = 33, BS = BN + 4;
+  constexpr int AI = BM / 32;  // float4 A loads per thread per chunk
+  constexpr int BI = BN / 32;  // float4 B loads per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                // [2][BM][AS]
+  float* Bs = smem + 2 * BM * AS;  // [2][32][BS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // ---- per-thread im2col row bookkeeping (rows are fixed across K chunks)
+  const int kq = tid & 7;
+  int rpix[AI], riy[AI], rix[AI], rn[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + (tid >> 3) + 32 * i;
+    if (m < a.M) {
+      const int n = m / a.P, rem = m - n * a.P;
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      rn[i] = n;
+      rpix[i] = n * a.Hi * a.Wi;
+      riy[i] = oy * a.stride - a.pad;
+      rix[i] = ox * a.stride - a.padw;
+    } else {
+      rn[i] = 0; rpix[i] = 0; riy[i] = -(1 << 20); rix[i] = -(1 << 20);
+    }
+  }
+  const int cpt = a.Cin >> 5;  // 32-channel chunks per tap
+  const int nchunks = a.KH * a.KW * cpt;
+  const int brow = BN == 64 ? (tid >> 4) : (tid >> 5);
+  const int bcol = BN == 64 ? (tid & 15) : (tid & 31);
+  constexpr int BROWSTEP = BN == 64 ? 16 : 8;
+
+  float4 ra[AI], rb[BI];
+  auto load_chunk = [&](int c) {
+    const int tap = c / cpt, ci0 = (c - tap * cpt) << 5;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int iy = riy[i] + ky, ix = rix[i] + kx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
+        v = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + iy * a.Wi + ix) * a.Cin + ci0 + 4 * kq);
+        if (a.in_sc) {
+          const float4 s = *reinterpret_cast<const float4*>(a.in_sc + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);
+          const float4 h = *reinterpret_cast<const float4*>(a.in_sh + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);
+          v.x = fmaxf(v.x * s.x + h.x, 0.f);
+          v.y = fmaxf(v.y * s.y + h.y, 0.f);
+          v.z = fmaxf(v.z * s.z + h.z, 0.f);
+          v.w = fmaxf(v.w * s.w + h.w, 0.f);
+        }
+      }
+      ra[i] = v;
+    }
+    const float* wp = a.w + (size_t)(c << 5) * a.Cout + n0 + 4 * bcol;
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      rb[i] = *reinterpret_cast<const float4*>(wp + (size_t)(brow + BROWSTEP * i) * a.Cout);
+  };
+  auto store_chunk = [&](int buf) {
+    float* Ab = As + buf * BM * AS;
+    float* Bb = Bs + buf * 32 * BS;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      float* p = Ab + ((tid >> 3) + 32 * i) * AS + 4 * kq;
+      p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      *reinterpret_cast<float4*>(Bb + (brow + BROWSTEP * i) * BS + 4 * bcol) = rb[i];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* Ab = As + buf * BM * AS + (wm * 64 + li) * AS + lh;
+    const float* Bb = Bs + buf * 32 * BS + lh * BS + wn * 64 + li;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float a0 = Ab[2 * ks], a1 = Ab[32 * AS + 2 * ks];
+      const float b0 = Bb[2 * ks * BS], b1 = Bb[2 * ks * BS + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: raw conv output (NHWC == row-major [M][Cout])
+  const int wrow0 = m0 + wm * 64;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) {
+        float* o = a.out + (size_t)m * a.Cout + n0 + wn * 64 + li;
+        o[0] = acc[tm][0][r];
+        o[32] = acc[tm][1][r];
+      }
+    }
+  // ---- epilogue: GroupNorm statistics (rows beyond M are exact zeros and contribute nothing)
+  if (PMODE != 3) {
+    const int gsize = a.Cout / kGnGroups;
+    constexpr int NSLOT = PMODE == 0 ? 1 : (PMODE == 1 ? 2 : 4);
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; ++slot) {
+      constexpr int ROWS = 64 / NSLOT;
+      const int mrow = wrow0 + slot * ROWS;
+      const bool valid = mrow < a.M;
+      const int n = valid ? mrow / a.P : 0;
+      double* st = a.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + 8 * (r >> 2);  // (+ (r&3) + 4*lh < 8): 8-row granules
+            if (row / ROWS == slot) {
+              const float v = acc[tm][tn][r];
+              s += v;
+              q += v * v;
+            }
+          }
+        stats_flush(s, q, st, n0 + wn * 64 + tn * 32 + li, gsize, valid);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int cd(int a, int b) { return (a + b - 1) / b; }
+
+TrunkDims trunk_dims(int H, int W) {
+  TrunkDims d{};
+  d.H = H; d.W = W;
+  d.h[0] = cd(H, 2); d.w[0] = cd(W, 2);
+  d.h[1] = cd(d.h[0], 2); d.w[1] = cd(d.w[0], 2);
+  for (int i = 0; i < kTrunkStages; ++i) {
+    d.h[2 + i] = cd(d.h[1 + i], kStageStride[i]);
+    d.w[2 + i] = cd(d.w[1 + i], kStageStride[i]);
+  }
+  return d;
+}
+
+constexpr int kGnLayers = 1 + 3 * kTrunkStages;
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int W) {
+  const TrunkDims d = trunk_dims(H, W);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    uint8_t* p = base ? base + off : nullptr;
+    off += al256(bytes);
+    return p;
+  };
+  float* raw_init = (float*)take((size_t)N * d.h[0] * d.w[0] * 64 * 4);
+  float* pool = (float*)take((size_t)N * d.h[1] * d.w[1] * 64 * 4);
+  TrunkWorkspace::B blk[kTrunkStages];
+  for (int i = 0; i < kTrunkStages; ++i) {
+    const size_t e = (size_t)N * d.h[2 + i] * d.w[2 + i] * kStageFilters[i] * 4;
+    blk[i].raw0 = (float*)take(e);
+    blk[i].raw1 = (float*)take(e);
+    blk[i].rawp = (float*)take(e);
+    blk[i].out = (float*)take(e);
+  }
+  double* stats = (double*)take((size_t)kGnLayers * N * kGnGroups * 2 * sizeof(double));
+  float* coef = (float*)take((size_t)kGnLayers * 2 * N * 512 * 4);
+  if (ws) {
+    ws->max_images = N; ws->d = d; ws->raw_init = raw_init; ws->pool = pool;
+    for (int i = 0; i < kTrunkStages; ++i) ws->blk[i] = blk[i];
+    ws->stats = stats; ws->coef = coef; ws->base = base; ws->bytes = off;
+  }
+  return off;
+}
+
+size_t trunk_workspace_bytes(int max_images, int H, int W) {
+  return trunk_layout(nullptr, nullptr, max_images, H, W);
+}
+
+int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, int W) {
+  SERL_REQUIRE(mem != nullptr, "trunk workspace memory is NULL");
+  SERL_REQUIRE(H >= 32 && W >= 32, "trunk needs images of at least 32x32 (got %dx%d)", H, W);
+  trunk_layout(&ws, (uint8_t*)mem, max_images, H, W);
+  return SERL_OK;
+}
+
+static int launch_conv(const float* in, const float* w, float* out, double* stats, const float* in_sc,
+                       const float* in_sh, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout,
+                       int ksz, int stride, hipStream_t stream) {
+  SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
+  ConvArgs a{};
+  a.in = in; a.w = w; a.out = out; a.stats = stats; a.in_sc = in_sc; a.in_sh = in_sh;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.KH = a.KW = ksz; a.stride = stride;
+  // XLA SAME padding: total = max((ceil(n/s)-1)*s + k - n, 0), lo = total/2
+  const int total = std::max((Ho - 1) * stride + ksz - Hi, 0);
+  a.pad = total / 2;
+  a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
+  a.M = N * Ho * Wo; a.P = Ho * Wo;
+  const bool wide = Cout >= 128;
+  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  a.tiles_m = cd(a.M, BM); a.tiles_n = Cout / BN;
+  const size_t lds = (size_t)(2 * BM * 33 + 2 * 32 * (BN + 4)) * 4;
+  const int pmode = (a.P % 64 == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
+  dim3 grid(a.tiles_m * a.tiles_n), block(256);
+#define SERL_LAUNCH_CONV(WM, WN, PM) \
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, PM>), grid, block, lds, stream, a)
+  if (wide) {
+    if (pmode == 0) SERL_LAUNCH_CONV(2, 2, 0);
+    else if (pmode == 1) SERL_LAUNCH_CONV(2, 2, 1);
+    else if (pmode == 2) SERL_LAUNCH_CONV(2, 2, 2);
+    else SERL_LAUNCH_CONV(2, 2, 3);
+  } else {
+    if (pmode == 0) SERL_LAUNCH_CONV(4, 1, 0);
+    else if (pmode == 1) SERL_LAUNCH_CONV(4, 1, 1);
+    else if (pmode == 2) SERL_LAUNCH_CONV(4, 1, 2);
+    else SERL_LAUNCH_CONV(4, 1, 3);
+  }
+#undef SERL_LAUNCH_CONV
+  SERL_HIP(hipGetLastError());
+  if (pmode == 3) {  // statistics in a separate pass
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
+    SERL_HIP(hipGetLastError());
+  }
+  return SERL_OK;
+}
+
+static int launch_coef(const double* stats, const float* gamma, const float* beta, float* sc, float* sh,
+                       int N, int Cc, int P, hipStream_t stream) {
+  const double inv = 1.0 / ((double)P * (Cc / kGnGroups));
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cd(N * Cc, 256)), dim3(256), 0, stream, stats, gamma, beta, sc, sh,
+                     N, Cc, inv, 1e-5f);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n, float* feats_out,
+                  hipStream_t stream) {
+  SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
+  const TrunkDims& d = ws.d;
+  const int N = n;
+  auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
+  auto sc_of = [&](int layer) { return ws.coef + (size_t)layer * 2 * ws.max_images * 512; };
+  auto sh_of = [&](int layer) { return sc_of(layer) + (size_t)ws.max_images * 512; };
+  SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kGnLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
+  int rc;
+  {  // conv_init
+    ConvInitArgs a{};
+    a.img = frames; a.w = w.conv_init; a.out = ws.raw_init; a.stats = stats_of(0);
+    a.N = N; a.H = d.H; a.W = d.W; a.Ho = d.h[0]; a.Wo = d.w[0];
+    a.tiles_y = cd(a.Ho, 16); a.tiles_x = cd(a.Wo, 16);
+    const size_t lds = (size_t)(kCiPatch * kCiPW + 3 + kCiK * kCiBS) * 4;
+    hipLaunchKernelGGL(conv_init_kernel, dim3(N * a.tiles_y * a.tiles_x), dim3(256), lds, stream, a);
+    SERL_HIP(hipGetLastError());
+  }
+  if ((rc = launch_coef(stats_of(0), w.gn_init_s, w.gn_init_b, sc_of(0), sh_of(0), N, 64, d.h[0] * d.w[0], stream))) return rc;
+  {
+    const long tot = (long)N * d.h[1] * d.w[1] * 16;
+    hipLaunchKernelGGL(gn_relu_maxpool_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.raw_init, sc_of(0),
+                       sh_of(0), ws.pool, N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
+    SERL_HIP(hipGetLastError());
+  }
+  const float* x = ws.pool;
+  int cin = 64;
+  for (int i = 0; i < kTrunkStages; ++i) {
+    const int f = kStageFilters[i], s = kStageStride[i];
+    const int Hi = d.h[1 + i], Wi = d.w[1 + i], Ho = d.h[2 + i], Wo = d.w[2 + i], P = Ho * Wo;
+    const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
+    const TrunkWeights::Block& bw = w.blk[i];
+    const bool has_proj = bw.proj != nullptr;
+    if ((rc = launch_conv(x, bw.conv0, ws.blk[i].raw0, stats_of(l0), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    if (has_proj)
+      if ((rc = launch_conv(x, bw.proj, ws.blk[i].rawp, stats_of(lp), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
+    if ((rc = launch_coef(stats_of(l0), bw.gn0_s, bw.gn0_b, sc_of(l0), sh_of(l0), N, f, P, stream))) return rc;
+    if ((rc = launch_conv(ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1), sc_of(l0), sh_of(l0), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
+    if ((rc = launch_coef(stats_of(l1), bw.gn1_s, bw.gn1_b, sc_of(l1), sh_of(l1), N, f, P, stream))) return rc;
+    if (has_proj)
+      if ((rc = launch_coef(stats_of(lp), bw.gnp_s, bw.gnp_b, sc_of(lp), sh_of(lp), N, f, P, stream))) return rc;
+    float* out = (i == kTrunkStages - 1) ? feats_out : ws.blk[i].out;
+    const long tot = (long)N * P * (f / 4);
+    hipLaunchKernelGGL(block_out_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1, sc_of(l1),
+                       sh_of(l1), has_proj ? ws.blk[i].rawp : x, has_proj ? sc_of(lp) : nullptr,
+                       has_proj ? sh_of(lp) : nullptr, out, N, P, f);
+    SERL_HIP(hipGetLastError());
+    x = out;
+    cin = f;
+  }
+  return SERL_OK;
+}
+
+}  // namespace serl

@@ -1,0 +1,174 @@
+"""GPU parity of the HIP SAC/DrQ update (through the C ABI) against the fp64 CPU oracle.
+Tolerance: 1e-4 (north-star: "within 1e-4 fp32"), measured as max-abs error relative to the
+tensor's max-abs (per leaf for gradients and parameters)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import drq_oracle as O
+import agent_helpers as AH
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("H,W,n", [(64, 64, 6), (128, 128, 5), (128, 64, 3)])
+def test_trunk_forward(gpu, H, W, n):
+    cfg = O.Config(image_keys=("a",), H=H, W=W, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=max(n, 4))
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    ref = O.trunk_forward(st.trunk, torch.tensor(img), torch.float64).numpy()
+    got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+    assert got.shape == ref.shape
+    assert AH.rel_err(got, ref) < TOL, AH.rel_err(got, ref)
+
+
+def _compare_state(cfg, st, core, tol=TOL):
+    worst = 0.0
+    for k in st.params:
+        for sec, tree in (("params", st.params), ("target_params", st.target)):
+            got = core.get(sec, AH.product_name(k, cfg.image_keys))
+            e = AH.rel_err(got, tree[k].numpy().reshape(-1))
+            worst = max(worst, e)
+            assert e < tol, (sec, k, e)
+    return worst
+
+
+def _check_grads(cfg, core, grads, tap, sl_lo, tol=TOL):
+    sl, _ = AH.leaf_slices(cfg)
+    n = {"g_critic": sl["enc/proprio/ln/bias"][1], "g_actor": sl["actor/logstd/bias"][1] - sl_lo}[tap]
+    g = core.debug(tap, n)
+    for k, gv in grads.items():
+        lo, hi = sl[k]
+        e = AH.rel_err(g[lo - sl_lo:hi - sl_lo], gv.numpy().reshape(-1))
+        assert e < tol, (tap, k, e)
+
+
+@pytest.mark.parametrize("B", [16, 40])
+def test_update_critics_matches_oracle(gpu, B):
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    st, core = AH.make_pair(cfg, B)
+    b = AH.synth_batch(cfg, B, seed=3)
+    noise = O.make_noise(cfg, B, seed=7)
+    info, aux = O.update_critics(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64))
+    db = AH.batch_to_device(cfg, b)
+    core.update_critics(db, AH.noise_to_device(cfg, noise))
+    got = core.read_info()
+    for k in ("critic_loss", "predicted_qs", "target_qs"):
+        assert abs(got[k] - info[k]) < TOL * max(1.0, abs(info[k])), (k, got[k], info[k])
+    q = core.debug("q", cfg.ensemble * B).reshape(cfg.ensemble, B)
+    assert AH.rel_err(q, aux["q"].numpy()) < TOL
+    assert AH.rel_err(core.debug("target_q", B), aux["target_q"].numpy()) < TOL
+    _check_grads(cfg, core, aux["grads"], "g_critic", 0)
+    _compare_state(cfg, st, core)
+    assert core.step == st.step == 1
+
+
+@pytest.mark.parametrize("utd", [1, 2])
+def test_update_high_utd_matches_oracle(gpu, utd):
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    B = 16
+    st, core = AH.make_pair(cfg, B)
+    b = AH.synth_batch(cfg, B, seed=4)
+    noise = O.make_noise(cfg, B, seed=8, utd_ratio=utd)
+    info, aux = O.update_high_utd(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64), utd)
+    db = AH.batch_to_device(cfg, b)
+    core.update_high_utd(db, utd, AH.noise_to_device(cfg, noise))
+    got = core.read_info()
+    for k in ("critic_loss", "predicted_qs", "target_qs", "actor_loss", "temperature", "entropy", "temperature_loss"):
+        assert abs(got[k] - info[k]) < TOL * max(1.0, abs(info[k])), (k, got[k], info[k])
+    sl, _ = AH.leaf_slices(cfg)
+    _check_grads(cfg, core, aux["g_actor"], "g_actor", sl["enc/proprio/dense/kernel"][0])
+    _compare_state(cfg, st, core)
+    assert core.step == st.step == utd + 1
+
+
+def test_multi_step_sequence(gpu):
+    """CAR=4 style sequence (3x update_critics + 1x update_high_utd), twice: exercises the
+    zero-gradient Adam momentum steps, the EMA and step/bias-correction bookkeeping."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    B = 8
+    st, core = AH.make_pair(cfg, B)
+    for it in range(8):
+        b = AH.synth_batch(cfg, B, seed=100 + it)
+        noise = O.make_noise(cfg, B, seed=200 + it)
+        tb, tn = AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64)
+        db, dn = AH.batch_to_device(cfg, b), AH.noise_to_device(cfg, noise)
+        if it % 4 == 3:
+            O.update_high_utd(st, tb, tn, 1)
+            core.update_high_utd(db, 1, dn)
+        else:
+            O.update_critics(st, tb, tn)
+            core.update_critics(db, dn)
+    worst = _compare_state(cfg, st, core, tol=5e-4)
+    assert core.step == st.step == 10
+    print("worst rel err after 10 steps:", worst)
+
+
+def test_dp_split_equals_full_batch(gpu):
+    """Batch-sharded data parallelism (common.py:213-214 pmean): gradients of two half batches
+    (normalised by the global count) sum to the full-batch gradient."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    B = 16
+    _, core = AH.make_pair(cfg, B)
+    b = AH.synth_batch(cfg, B, seed=5)
+    noise = AH.noise_to_device(cfg, O.make_noise(cfg, B, seed=9))
+    db = AH.batch_to_device(cfg, b)
+    sl, _ = AH.leaf_slices(cfg)
+    n = sl["enc/proprio/ln/bias"][1]
+    core.begin_update()
+    core.encode(db)
+    core.critic_grads(0, B, B, noise)
+    full = core.debug("g_critic", n).astype(np.float64)
+    sc_full = core.debug("scalars", 3).astype(np.float64)
+    parts, scs = [], []
+    for r in range(2):
+        core.critic_grads(r * 8, 8, B, noise)
+        parts.append(core.debug("g_critic", n).astype(np.float64))
+        scs.append(core.debug("scalars", 3).astype(np.float64))
+    assert AH.rel_err(parts[0] + parts[1], full) < 1e-5
+    assert AH.rel_err(scs[0] + scs[1], sc_full) < 1e-5
+
+
+def test_sample_actions(gpu):
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    st, core = AH.make_pair(cfg, 8)
+    b = AH.synth_batch(cfg, 4, seed=6)
+    frames = torch.tensor(np.stack([b["obs"][k] for k in cfg.image_keys]), device="cuda")
+    state = torch.tensor(b["state"], device="cuda")
+    feats = O.features(st, {k: torch.tensor(v) for k, v in b["obs"].items()})
+    enc = O.encode(st.params, cfg, feats, torch.tensor(b["state"], dtype=torch.float64))
+    mean, std = O.policy_head(st.params, cfg, enc)
+    mode = core.sample_actions(frames, state, None).cpu().numpy()
+    assert AH.rel_err(mode, torch.tanh(mean).numpy()) < TOL
+    eps = np.random.default_rng(0).standard_normal((4, cfg.A)).astype(np.float32)
+    a, _ = O.sample_and_log_prob(mean, std, torch.tensor(eps, dtype=torch.float64))
+    got = core.sample_actions(frames, state, torch.tensor(eps, device="cuda")).cpu().numpy()
+    assert AH.rel_err(got, a.numpy()) < TOL
+
+
+def test_error_behaviour(gpu):
+    from serl_amd._lib import SerlError
+    cfg = O.Config(image_keys=("front",), H=64, W=64, S=5, A=3)
+    _, core = AH.make_pair(cfg, 6)
+    db = AH.batch_to_device(cfg, AH.synth_batch(cfg, 6))
+    with pytest.raises(SerlError, match="divisible by UTD"):
+        core.update_high_utd(db, 4)  # sac.py:561-563
+    with pytest.raises(SerlError):
+        core.set("params", "no/such/leaf", np.zeros(3))
+    with pytest.raises(SerlError):
+        core.set("opt/critic/mu", "actor/w1", np.ones(core.leaves["actor/w1"]))  # outside the support
+
+
+def test_production_noise_runs(gpu):
+    """noise=None: device RNG path (no parity claim, just finite results and moving params)."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    _, core = AH.make_pair(cfg, 8)
+    db = AH.batch_to_device(cfg, AH.synth_batch(cfg, 8))
+    before = core.get("params", "actor/w1").copy()
+    core.update_critics(db)
+    core.update_high_utd(db, 1)
+    info = core.read_info()
+    assert all(np.isfinite(v) for v in info.values()), info
+    assert not np.array_equal(before, core.get("params", "actor/w1"))
