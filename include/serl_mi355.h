@@ -208,6 +208,8 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
 /* Debug / test taps (device->host copies of internal activations). */
 int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream);
 int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64_t count);
+/* inject gradients / scalars ("g_critic", "g_actor", "scalars") before serl_agent_apply: optimizer tests */
+int serl_agent_debug_set(serl_agent* a, const char* what, const float* host, int64_t count);
 
 #ifdef __cplusplus
 }

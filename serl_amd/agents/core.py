@@ -161,6 +161,11 @@ class AgentCore:
         return out
 
 
+    def debug_set(self, what: str, value):
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(-1))
+        _lib.check(self.L.serl_agent_debug_set(self._h, what.encode(), v.ctypes.data, v.size))
+
+
 class _DevPtr:
     """Minimal __cuda_array_interface__ carrier so torch can alias library-owned HBM."""
 

@@ -937,4 +937,22 @@ int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64
   return SERL_OK;
 }
 
+int serl_agent_debug_set(serl_agent* a, const char* what, const float* host, int64_t count) {
+  SERL_REQUIRE(a && what && host, "NULL argument");
+  SERL_HIP(hipSetDevice(a->cfg.device));
+  const Offs& o = a->o;
+  const std::string w(what);
+  float* p = nullptr;
+  long n = 0;
+  if (w == "g_critic") { p = a->Gc; n = o.Pc; }
+  else if (w == "g_actor") { p = a->Ga; n = o.Pa1 - o.Pa0; }
+  else if (w == "scalars") { p = a->SC; n = kScalars; }
+  else { set_error("unknown debug tap '%s'", what); return SERL_ERR_INVALID; }
+  SERL_REQUIRE(count <= n && count > 0, "tap '%s' holds %ld floats, got %lld", what, n, (long long)count);
+  SERL_HIP(hipDeviceSynchronize());
+  SERL_HIP(hipMemcpy(p, host, sizeof(float) * count, hipMemcpyHostToDevice));
+  if (a->last_global <= 0) a->last_global = 1;
+  return SERL_OK;
+}
+
 }  // extern "C"

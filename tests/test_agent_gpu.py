@@ -24,15 +24,66 @@ def test_trunk_forward(gpu, H, W, n):
     assert AH.rel_err(got, ref) < TOL, AH.rel_err(got, ref)
 
 
-def _compare_state(cfg, st, core, tol=TOL):
+def _compare_state(cfg, st, core, tol=TOL, steps=1):
+    """End-to-end parameter parity.  Adam's update -lr*m/(sqrt(v)+1e-8) is sign-like, hence
+    ill-conditioned wherever |g| ~ 1e-8 (fp32 vs fp64 gradient noise flips it by up to 2*lr): the
+    bulk (99.9th percentile) must match within `tol`, every element within the Adam bound, and
+    the optimizer itself is checked exactly with injected gradients in test_adam_ema_injected."""
     worst = 0.0
     for k in st.params:
         for sec, tree in (("params", st.params), ("target_params", st.target)):
-            got = core.get(sec, AH.product_name(k, cfg.image_keys))
-            e = AH.rel_err(got, tree[k].numpy().reshape(-1))
-            worst = max(worst, e)
-            assert e < tol, (sec, k, e)
+            got = core.get(sec, AH.product_name(k, cfg.image_keys)).astype(np.float64)
+            ref = tree[k].numpy().reshape(-1)
+            err = np.abs(got - ref)
+            scale = max(np.max(np.abs(ref)), 1e-30)
+            bulk = float(np.quantile(err, 0.999)) / scale
+            worst = max(worst, bulk)
+            assert bulk < tol, (sec, k, bulk)
+            bound = 2.1 * cfg.lr * steps * (cfg.tau * steps if sec == "target_params" else 1.0) + tol * scale
+            assert err.max() <= bound, (sec, k, err.max(), bound)
     return worst
+
+
+def test_adam_ema_injected(gpu):
+    """3x Adam (zero-gradient momentum steps included) + summed update + target EMA, elementwise
+    against the oracle with the SAME injected gradients (common.py:124-168)."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3, warmup=3)
+    st, core = AH.make_pair(cfg, 4, dtype=torch.float64)
+    sl, P = AH.leaf_slices(cfg)
+    pc, pa0, pa1 = sl["enc/proprio/ln/bias"][1], sl["enc/proprio/dense/kernel"][0], sl["actor/logstd/bias"][1]
+    rng = np.random.default_rng(0)
+    H_target = cfg.target_entropy
+    for it in range(6):
+        crit = it % 3 != 2
+        if crit:
+            g = (rng.standard_normal(pc) * 10.0 ** rng.uniform(-9, -2, pc)).astype(np.float32)
+            grads = {"critic": {k: torch.tensor(g[lo:hi].astype(np.float64)).reshape(st.params[k].shape)
+                                for k, (lo, hi) in sl.items() if hi <= pc}}
+            core.debug_set("g_critic", g)
+            O.apply_gradients(st, grads)
+            O.target_update(st)
+            core.apply(1)
+        else:
+            g = (rng.standard_normal(pa1 - pa0) * 10.0 ** rng.uniform(-9, -2, pa1 - pa0)).astype(np.float32)
+            sum_logp_next = np.float32(rng.standard_normal() * 3)
+            lam = st.params["temp/lagrange"]
+            H = -float(sum_logp_next) / 1.0
+            gt = torch.sigmoid(lam) * (H - H_target)
+            grads = {"actor": {k: torch.tensor(g[lo - pa0:hi - pa0].astype(np.float64)).reshape(st.params[k].shape)
+                               for k, (lo, hi) in sl.items() if lo >= pa0 and hi <= pa1},
+                     "temperature": {"temp/lagrange": gt}}
+            sc = np.zeros(32, np.float32)
+            sc[5] = sum_logp_next
+            core.debug_set("g_actor", g)
+            core.debug_set("scalars", sc)
+            O.apply_gradients(st, grads)
+            core.apply(2)
+        for k in st.params:
+            for sec, tree in (("params", st.params), ("target_params", st.target)):
+                got = core.get(sec, AH.product_name(k, cfg.image_keys))
+                ref = tree[k].numpy().reshape(-1)
+                assert np.allclose(got, ref, rtol=2e-5, atol=2e-7), (it, sec, k, np.abs(got - ref).max())
+    assert core.step == st.step == 6
 
 
 def _check_grads(cfg, core, grads, tap, sl_lo, tol=TOL):
@@ -80,7 +131,7 @@ def test_update_high_utd_matches_oracle(gpu, utd):
         assert abs(got[k] - info[k]) < TOL * max(1.0, abs(info[k])), (k, got[k], info[k])
     sl, _ = AH.leaf_slices(cfg)
     _check_grads(cfg, core, aux["g_actor"], "g_actor", sl["enc/proprio/dense/kernel"][0])
-    _compare_state(cfg, st, core)
+    _compare_state(cfg, st, core, steps=utd + 1)
     assert core.step == st.step == utd + 1
 
 
@@ -101,7 +152,7 @@ def test_multi_step_sequence(gpu):
         else:
             O.update_critics(st, tb, tn)
             core.update_critics(db, dn)
-    worst = _compare_state(cfg, st, core, tol=5e-4)
+    worst = _compare_state(cfg, st, core, tol=5e-4, steps=10)
     assert core.step == st.step == 10
     print("worst rel err after 10 steps:", worst)
 
