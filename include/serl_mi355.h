@@ -38,6 +38,13 @@ int serl_version(void);
 /* number of visible HIP devices (0 if none); does not fail without a GPU */
 int serl_device_count(void);
 
+/* Per-launch HIP-event timing of the hot kernels (off by default).  serl_profile_read returns, per
+ * instrumented kernel tag, the summed duration and launch count since the last reset:
+ * names is char[max_entries][64]. Used by bench.py for the live roofline numbers. */
+int serl_profile_enable(int on);
+int serl_profile_reset(void);
+int serl_profile_read(int max_entries, char* names, double* total_ms, int64_t* counts, int* n_out);
+
 /* ------------------------------------------------------------------------------------------
  * Replay buffer  (data/memory_efficient_replay_buffer.py, data/replay_buffer.py, data/dataset.py)
  * Frames live in HBM: one u8[H*W*C] frame per slot per camera (the *next* frame of the

@@ -49,6 +49,9 @@ def _declare(lib):
         "serl_rb_gather_packed": [vp, vp, i32, P(vp), vp, vp, vp, vp, vp, vp, vp],
         "serl_rb_gather_crop": [P(vp), i32, P(vp), P(i32), vp, vp, P(SerlBatch), vp],
         "serl_crop_packed": [i32, P(vp), i32, i32, i32, i32, i32, vp, vp, vp, vp],
+        "serl_profile_enable": [i32],
+        "serl_profile_reset": [],
+        "serl_profile_read": [i32, vp, vp, vp, P(i32)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -87,6 +90,21 @@ def check(status: int):
     if status != 0:
         msg = lib().serl_last_error()
         raise SerlError(f"libserl_mi355 status {status}: {msg.decode() if msg else '?'}")
+
+
+def profile_read(max_entries=64):
+    """-> {tag: (total_ms, count)} of the instrumented kernels since the last reset."""
+    import numpy as np
+    names = C.create_string_buffer(max_entries * 64)
+    ms = np.zeros(max_entries, np.float64)
+    cnt = np.zeros(max_entries, np.int64)
+    n = C.c_int()
+    check(lib().serl_profile_read(max_entries, C.cast(names, C.c_void_p), ms.ctypes.data, cnt.ctypes.data, C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        tag = names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode()
+        out[tag] = (float(ms[i]), int(cnt[i]))
+    return out
 
 
 def exported_symbols():

@@ -1,0 +1,278 @@
+"""DrQAgent / SACAgent with the reference's Python API, backed by libserl_mi355.so.
+
+Mirrors (same names, argument meaning, error behaviour):
+  serl_launcher/agents/continuous/drq.py:24-328   DrQAgent.create_drq / update_high_utd / update_critics
+  serl_launcher/agents/continuous/sac.py:243-320  SACAgent.update / sample_actions
+  serl_launcher/common/common.py:81-114           JaxRLTrainState fields (step, params, target_params,
+                                                   opt_states, rng) exposed through `agent.state`
+The reference is functional (returns a new agent); this agent mutates its device state and
+returns `self`, which is what the learner loop (`agent, info = agent.update_critics(batch)`) needs.
+All numerics run in HIP kernels; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict, FrozenSet, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..data.data_store import LazyBatch, gather_crop
+from ..utils import init as pinit
+from .. import _lib
+from .batch import DeviceBatch
+from .core import APPLY_ACTOR_TEMP, APPLY_CRITIC, TX_NAMES, AgentCore
+from .flax_tree import export_tree
+
+
+class PendingInfo:
+    """Info dict of the LAST update call; reading it synchronises the stream (the reference's jitted
+    update returns device arrays that are also only materialised when logged)."""
+
+    def __init__(self, agent, kind, serial):
+        self._agent, self._kind, self._serial, self._val = agent, kind, serial, None
+
+    def resolve(self) -> dict:
+        if self._val is None:
+            if self._agent._update_serial != self._serial:
+                raise RuntimeError("info of an older update was overwritten; read it before the next update")
+            r = self._agent.core.read_info()
+            lr = {f"{n}_lr": r[f"{n}_lr"] for n in TX_NAMES}
+            out = {"critic": {k: r[k] for k in ("critic_loss", "predicted_qs", "target_qs")}}
+            if self._kind == "high_utd":
+                out["actor"] = {k: r[k] for k in ("actor_loss", "temperature", "entropy")}
+                out["temperature"] = {"temperature_loss": r["temperature_loss"]}
+            out.update(lr)
+            self._val = out
+        return self._val
+
+    def __getitem__(self, k):
+        return self.resolve()[k]
+
+    def items(self):
+        return self.resolve().items()
+
+    def keys(self):
+        return self.resolve().keys()
+
+    def __repr__(self):
+        return repr(self.resolve())
+
+
+class TrainStateView:
+    """agent.state: JaxRLTrainState-shaped, materialised from HBM on access (common.py:81-114)."""
+
+    def __init__(self, agent):
+        self._a = agent
+
+    @property
+    def step(self):
+        return self._a.core.step
+
+    @property
+    def params(self):
+        return export_tree(self._a.core, "params", self._a.image_keys)
+
+    @property
+    def target_params(self):
+        return export_tree(self._a.core, "target_params", self._a.image_keys)
+
+    @property
+    def opt_states(self):
+        out = {}
+        for tx in TX_NAMES:
+            out[tx] = {"count": self._a.core.step,
+                       "hyperparams": {"learning_rate": self._a.lr_at(self._a.core.step), "weight_decay": None},
+                       "mu": export_tree(self._a.core, f"opt/{tx}/mu", self._a.image_keys),
+                       "nu": export_tree(self._a.core, f"opt/{tx}/nu", self._a.image_keys)}
+        return out
+
+    @property
+    def rng(self):
+        return self._a._rng_key.copy()
+
+
+class DrQAgent:
+    def __init__(self, core: AgentCore, image_keys, config: dict, seed: int):
+        self.core = core
+        self.image_keys = tuple(image_keys)
+        self.config = config
+        self._np_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 0xD1CE])))
+        self._rng_key = np.array([0, seed], np.uint32)
+        self._batch: Optional[DeviceBatch] = None
+        self._update_serial = 0
+        self.state = TrainStateView(self)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def create_drq(cls, rng, observations, actions, encoder_type: str = "small", shared_encoder: bool = True,
+                   use_proprio: bool = False, critic_network_kwargs: dict = None,
+                   policy_network_kwargs: dict = None, policy_kwargs: dict = None,
+                   critic_ensemble_size: int = 2, critic_subsample_size: Optional[int] = None,
+                   temperature_init: float = 1.0, image_keys: Iterable[str] = ("image",),
+                   discount: float = 0.95, soft_target_update_rate: float = 0.005,
+                   target_entropy: Optional[float] = None, backup_entropy: bool = False,
+                   batch_size: int = 256, device: int = 0, learning_rate: float = 3e-4, **kwargs):
+        """drq.py:104-242.  Only the configuration the reference's examples run is built natively:
+        encoder_type="resnet-pretrained", use_proprio=True, REDQ subsample 2, tanh-squashed
+        exp-parameterised policy, LayerNorm+tanh 256x256 MLPs (utils/launcher.py:79-116)."""
+        if encoder_type != "resnet-pretrained":
+            raise NotImplementedError(f"Unknown encoder type: {encoder_type} (only 'resnet-pretrained' is built)")
+        if not use_proprio or backup_entropy or critic_subsample_size != 2:
+            raise NotImplementedError("only use_proprio=True, backup_entropy=False, critic_subsample_size=2")
+        pk = policy_kwargs or {}
+        if pk.get("std_parameterization", "exp") != "exp" or not pk.get("tanh_squash_distribution", True):
+            raise NotImplementedError("policy must be tanh-squashed with std_parameterization='exp'")
+        for nk in (critic_network_kwargs or {}, policy_network_kwargs or {}):
+            if list(nk.get("hidden_dims", [256, 256])) != [256, 256] or not nk.get("use_layer_norm", True):
+                raise NotImplementedError("MLPs must be [256,256] with LayerNorm")
+        seed = int(np.asarray(rng).reshape(-1)[-1]) if not isinstance(rng, int) else rng
+        image_keys = tuple(image_keys)
+        img = np.asarray(observations[image_keys[0]])
+        H, W = img.shape[-3], img.shape[-2]
+        S = int(np.asarray(observations["state"]).shape[-1])
+        A = int(np.asarray(actions).shape[-1])
+        if target_entropy is None:
+            target_entropy = -A / 2  # drq.py:88-89
+        core = AgentCore(device=device, n_cam=len(image_keys), H=H, W=W, state_dim=S, act_dim=A,
+                         batch=batch_size, ensemble=critic_ensemble_size, discount=discount,
+                         tau=soft_target_update_rate, lr=learning_rate, std_min=pk.get("std_min", 1e-5),
+                         std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed)
+        theta = pinit.init_theta(len(image_keys), H, W, S, A, seed=seed, temperature_init=temperature_init,
+                                 ensemble=critic_ensemble_size)
+        trunk = pinit.init_trunk(seed=seed)
+        for sec in ("params", "target_params"):  # JaxRLTrainState.create(target_params=params)
+            core.load_flat(sec, theta)
+            core.load_flat(sec, trunk)
+        config = dict(critic_ensemble_size=critic_ensemble_size, critic_subsample_size=critic_subsample_size,
+                      discount=discount, soft_target_update_rate=soft_target_update_rate,
+                      target_entropy=target_entropy, backup_entropy=backup_entropy, image_keys=image_keys)
+        agent = cls(core, image_keys, config, seed)
+        agent._lr, agent._warmup = learning_rate, 0
+        return agent
+
+    def lr_at(self, count):
+        return self._lr * count / self._warmup if count < self._warmup else self._lr
+
+    def load_trunk_params(self, pretrained: Dict[str, dict]):
+        """utils/train_utils.py:69-130: patch the frozen ResNet-10 trunk from the pretrained pickle's
+        tree {conv_init: {kernel}, norm_init: {scale,bias}, ResNetBlock_i: {...}} (params and target)."""
+        from .flax_tree import trunk_from_flax
+        flat = trunk_from_flax(pretrained)
+        for sec in ("params", "target_params"):
+            self.core.load_flat(sec, flat)
+        return self
+
+    def replace(self, **kw):  # agent.replace(state=...) in the reference; state is device-resident here
+        if kw and set(kw) - {"state"}:
+            raise NotImplementedError(list(kw))
+        return self
+
+    # ------------------------------------------------------------------ batches
+    def _device_batch(self, B):
+        c = self.core.cfg
+        if self._batch is None or self._batch.batch != B:
+            self._batch = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
+        return self._batch
+
+    def _draw_crops(self, B):
+        # data_augmentation_fn (drq.py:244-253): one (dy,dx) in [0,8] per frame, the SAME for every camera;
+        # obs and next_obs use independent draws (drq.py:279-281).  Host stream, not jax threefry.
+        co = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
+        cn = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
+        return co, cn
+
+    def prepare(self, batch, crops=None) -> DeviceBatch:
+        """sample-gather [+ concat_batches] + _unpack + random-shift crop -> DeviceBatch."""
+        if isinstance(batch, DeviceBatch):
+            return batch
+        if isinstance(batch, LazyBatch):
+            B = batch.batch_size
+            out = self._device_batch(B)
+            co, cn = crops if crops is not None else self._draw_crops(B)
+            gather_crop(batch.parts, co, cn, out)
+            return out
+        # reference-format dict of device tensors (packed or unpacked frames)
+        import ctypes as C
+        obs, nobs = batch["observations"], batch["next_observations"]
+        B = int(batch["rewards"].shape[0])
+        out = self._device_batch(B)
+        co, cn = crops if crops is not None else self._draw_crops(B)
+        keep, ptrs = [], (C.c_void_p * len(self.image_keys))()
+        for i, k in enumerate(self.image_keys):
+            if k in nobs:  # unpacked: re-pack [B,2,H,W,C] (train_utils._unpack inverse)
+                p = torch.cat([obs[k], nobs[k]], dim=1).contiguous()
+            else:
+                p = obs[k].contiguous()
+            assert p.shape[1] == 2, "only num_stack == 1 (T=1) is supported"
+            keep.append(p)
+            ptrs[i] = p.data_ptr()
+        c = self.core.cfg
+        s = torch.cuda.current_stream(self.core.device).cuda_stream
+        _lib.check(_lib.lib().serl_crop_packed(c.device, ptrs, c.n_cam, B, c.H, c.W, 3, co.ctypes.data,
+                                               cn.ctypes.data, out.frames.data_ptr(), C.c_void_p(s)))
+        out.state[0].copy_(obs["state"].reshape(B, -1))
+        out.state[1].copy_(nobs["state"].reshape(B, -1))
+        out.action.copy_(batch["actions"])
+        out.reward.copy_(batch["rewards"])
+        out.mask.copy_(batch["masks"])
+        out._keep = keep
+        return out
+
+    # ------------------------------------------------------------------ updates
+    def update_critics(self, batch, *, pmap_axis: Optional[str] = None, noise=None, crops=None):
+        """drq.py:296-328."""
+        db = self.prepare(batch, crops)
+        self.core.update_critics(db, noise)
+        self._update_serial += 1
+        return self, PendingInfo(self, "critics", self._update_serial)
+
+    def update_high_utd(self, batch, *, utd_ratio: int, pmap_axis: Optional[str] = None, noise=None, crops=None):
+        """drq.py:255-294 -> sac.py:544-596."""
+        db = self.prepare(batch, crops)
+        assert db.batch % utd_ratio == 0, \
+            f"Batch size {db.batch} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
+        self.core.update_high_utd(db, utd_ratio, noise)
+        self._update_serial += 1
+        return self, PendingInfo(self, "high_utd", self._update_serial)
+
+    def update(self, batch, *, pmap_axis: str = None,
+               networks_to_update: FrozenSet[str] = frozenset({"actor", "critic", "temperature"}), noise=None):
+        """sac.py:243-299 on an already augmented batch.  Supported subsets: {"critic"} and
+        {"actor","temperature"} (the two the reference's learners use)."""
+        loss_keys = {"actor", "critic", "temperature"}
+        assert set(networks_to_update).issubset(loss_keys), f"Invalid gradient steps: {networks_to_update}"
+        db = self.prepare(batch, crops=(np.full((batch.batch, 2), 4, np.int32),) * 2) if isinstance(batch, LazyBatch) else batch
+        self.core.begin_update()
+        self.core.encode(db)
+        if set(networks_to_update) == {"critic"}:
+            self.core.critic_grads(0, db.batch, db.batch, noise)
+            self.core.apply(APPLY_CRITIC)
+            kind = "critics"
+        elif set(networks_to_update) == {"actor", "temperature"}:
+            self.core.actor_grads(db.batch, noise)
+            self.core.apply(APPLY_ACTOR_TEMP)
+            kind = "high_utd"
+        else:
+            raise NotImplementedError(f"networks_to_update={set(networks_to_update)}")
+        self._update_serial += 1
+        return self, PendingInfo(self, kind, self._update_serial)
+
+    # ------------------------------------------------------------------ acting
+    def sample_actions(self, observations, *, seed=None, argmax: bool = False, **kwargs):
+        """sac.py:301-320: policy forward with train=False; sample (external seed) or mode."""
+        if argmax:
+            assert seed is None, "Cannot specify seed when sampling deterministically"
+        c = self.core.cfg
+        st = np.asarray(observations["state"], np.float32)
+        batched = st.ndim == 3
+        n = st.shape[0] if batched else 1
+        frames = np.stack([np.asarray(observations[k], np.uint8).reshape(n, c.H, c.W, 3) for k in self.image_keys])
+        f = torch.from_numpy(frames).to(self.core.device)
+        s = torch.from_numpy(st.reshape(n, -1)).to(self.core.device)
+        eps = None
+        if not argmax:
+            assert seed is not None, "Must specify rng when sampling"
+            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(np.asarray(seed).reshape(-1).tolist())))
+            eps = torch.from_numpy(g.standard_normal((n, c.act_dim)).astype(np.float32)).to(self.core.device)
+        a = self.core.sample_actions(f, s, eps).cpu().numpy()
+        return a if batched else a[0]

@@ -3,6 +3,7 @@
 // SpatialLearnedEmbeddings, tanh-Gaussian policy head, REDQ target, losses, 3x Adam + target EMA).
 // Reference semantics are cited per kernel (paths relative to serl_launcher/serl_launcher/).
 #include "heads.h"
+#include "prof.h"
 
 namespace serl {
 
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
 }
 
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
+  ProfScope prof("adam_ema", stream);
   hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P, 256)), dim3(256), 0, stream, a);
   SERL_HIP(hipGetLastError());
   return SERL_OK;

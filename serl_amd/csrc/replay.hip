@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "prof.h"
 
 namespace serl {
 
@@ -572,6 +573,7 @@ static int launch_gather_crop(GatherArgs& a, hipStream_t stream) {
   a.n_frame_blocks = 2 * a.n_cam * a.batch * chunks;
   const int rec_blocks = a.from_packed ? 0 : cdiv((long)a.batch * a.rec_len, 256);
   const size_t lds = (size_t)kRowsPerBlock * ((size_t)a.W * a.C + 16);
+  ProfScope prof("gather_crop", stream);
   hipLaunchKernelGGL(gather_crop_kernel, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
   SERL_HIP(hipGetLastError());
   return SERL_OK;

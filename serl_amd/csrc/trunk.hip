@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "prof.h"
 
 namespace serl {
 
@@ -488,9 +489,9 @@ int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, i
   return SERL_OK;
 }
 
-static int launch_conv(const float* in, const float* w, float* out, double* stats, const float* in_sc,
-                       const float* in_sh, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout,
-                       int ksz, int stride, hipStream_t stream) {
+static int launch_conv(const char* tag, const float* in, const float* w, float* out, double* stats,
+                       const float* in_sc, const float* in_sh, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
+                       int Cout, int ksz, int stride, hipStream_t stream) {
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgs a{};
   a.in = in; a.w = w; a.out = out; a.stats = stats; a.in_sc = in_sc; a.in_sh = in_sh;
@@ -507,6 +508,8 @@ static int launch_conv(const float* in, const float* w, float* out, double* stat
   const size_t lds = (size_t)(2 * BM * 33 + 2 * 32 * (BN + 4)) * 4;
   const int pmode = (a.P % 64 == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  {
+  ProfScope prof(tag, stream);
 #define SERL_LAUNCH_CONV(WM, WN, PM) \
   hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, PM>), grid, block, lds, stream, a)
   if (wide) {
@@ -521,6 +524,7 @@ static int launch_conv(const float* in, const float* w, float* out, double* stat
     else SERL_LAUNCH_CONV(4, 1, 3);
   }
 #undef SERL_LAUNCH_CONV
+  }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {  // statistics in a separate pass
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
@@ -554,12 +558,14 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
     a.N = N; a.H = d.H; a.W = d.W; a.Ho = d.h[0]; a.Wo = d.w[0];
     a.tiles_y = cd(a.Ho, 16); a.tiles_x = cd(a.Wo, 16);
     const size_t lds = (size_t)(kCiPatch * kCiPW + 3 + kCiK * kCiBS) * 4;
+    ProfScope prof("conv_init", stream);
     hipLaunchKernelGGL(conv_init_kernel, dim3(N * a.tiles_y * a.tiles_x), dim3(256), lds, stream, a);
     SERL_HIP(hipGetLastError());
   }
   if ((rc = launch_coef(stats_of(0), w.gn_init_s, w.gn_init_b, sc_of(0), sh_of(0), N, 64, d.h[0] * d.w[0], stream))) return rc;
   {
     const long tot = (long)N * d.h[1] * d.w[1] * 16;
+    ProfScope prof("gn_relu_maxpool", stream);
     hipLaunchKernelGGL(gn_relu_maxpool_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.raw_init, sc_of(0),
                        sh_of(0), ws.pool, N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
     SERL_HIP(hipGetLastError());
@@ -572,16 +578,21 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
-    if ((rc = launch_conv(x, bw.conv0, ws.blk[i].raw0, stats_of(l0), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    static const char* kTags[kTrunkStages][3] = {{"conv_igemm/b0_conv0", "conv_igemm/b0_conv1", "conv_igemm/b0_proj"},
+                                                  {"conv_igemm/b1_conv0", "conv_igemm/b1_conv1", "conv_igemm/b1_proj"},
+                                                  {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
+                                                  {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
+    if ((rc = launch_conv(kTags[i][0], x, bw.conv0, ws.blk[i].raw0, stats_of(l0), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
     if (has_proj)
-      if ((rc = launch_conv(x, bw.proj, ws.blk[i].rawp, stats_of(lp), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
+      if ((rc = launch_conv(kTags[i][2], x, bw.proj, ws.blk[i].rawp, stats_of(lp), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
     if ((rc = launch_coef(stats_of(l0), bw.gn0_s, bw.gn0_b, sc_of(l0), sh_of(l0), N, f, P, stream))) return rc;
-    if ((rc = launch_conv(ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1), sc_of(l0), sh_of(l0), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
+    if ((rc = launch_conv(kTags[i][1], ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1), sc_of(l0), sh_of(l0), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
     if ((rc = launch_coef(stats_of(l1), bw.gn1_s, bw.gn1_b, sc_of(l1), sh_of(l1), N, f, P, stream))) return rc;
     if (has_proj)
       if ((rc = launch_coef(stats_of(lp), bw.gnp_s, bw.gnp_b, sc_of(lp), sh_of(lp), N, f, P, stream))) return rc;
     float* out = (i == kTrunkStages - 1) ? feats_out : ws.blk[i].out;
     const long tot = (long)N * P * (f / 4);
+    ProfScope prof("block_out", stream);
     hipLaunchKernelGGL(block_out_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1, sc_of(l1),
                        sh_of(l1), has_proj ? ws.blk[i].rawp : x, has_proj ? sc_of(lp) : nullptr,
                        has_proj ? sh_of(lp) : nullptr, out, N, P, f);
