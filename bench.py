@@ -104,42 +104,18 @@ def main():
     agent = make_drq_agent(42, sample_obs, np.zeros((A,), np.float32), image_keys=KEYS,
                            encoder_type="resnet-pretrained", batch_size=Bl, device=local_rank)
     core = agent.core
-    if world > 1:  # decorrelate the per-rank device noise; REDQ indices stay shared (host stream)
-        pass
     db = DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank)
-    crop_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(7)))
-    redq_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(8)))
-    gv_c = core.grad_view(APPLY_CRITIC) if world > 1 else None
-    gv_a = core.grad_view(APPLY_ACTOR_TEMP) if world > 1 else None
-    lo, hi = rank * Bl, (rank + 1) * Bl
 
-    def fetch():
-        idx = rb.sample_indices(B)                       # identical stream on every rank
-        co = crop_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
-        cn = crop_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
-        gather_crop([(rb, idx[lo:hi])], co[lo:hi], cn[lo:hi], db)
+    def gather(parts, co, cn):                           # fused K2+K3+K4 into the local device batch
+        gather_crop(parts, co, cn, db)
+        return db
 
-    def critic_step():
-        fetch()
-        noise = {"redq_idx": redq_rng.integers(0, 10, size=(1, 2)).astype(np.int32)}
-        core.begin_update()
-        core.encode(db)
-        core.critic_grads(0, Bl, B, noise)
-        if world > 1:
-            dist.all_reduce(gv_c)
-        core.apply(APPLY_CRITIC)
-
-    def full_step():
-        critic_step()                                    # update_high_utd(utd_ratio=1): critic ...
-        core.actor_grads(B, None)                        # ... then actor + temperature on the same batch
-        if world > 1:
-            dist.all_reduce(gv_a)
-        core.apply(APPLY_ACTOR_TEMP)
+    from serl_amd.parallel import DataParallelLearner
+    learner = DataParallelLearner(core, gather, [rb], [B], rank, world,
+                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else None, seed=7)
 
     def iteration():
-        for _ in range(args.car - 1):
-            critic_step()
-        full_step()
+        learner.iteration(args.car)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,97 @@
+"""Batch-sharded data parallelism for the learner: one process per GPU, gradients all-reduced over
+RCCL/xGMI (torch.distributed backend "nccl").  This makes the reference's dormant
+`jax.lax.pmean(grads_and_aux, pmap_axis)` (serl_launcher/common/common.py:213-214) real.
+
+Sharding contract (DESIGN.md "multi-GPU"):
+  * every rank holds a full replica of the replay buffer(s) with the same contents and the same
+    seed, so all ranks draw the IDENTICAL global index stream (bit-exact with 1 GPU);
+  * rank r owns samples [r*B/P, (r+1)*B/P) of the (concatenated online+demo) global batch;
+  * losses are normalised by the GLOBAL batch, so all-reduce(SUM) of [gradients | loss scalars]
+    equals the single-device gradient; every rank then applies the identical Adam/EMA update
+    (no parameter broadcast needed).
+The class only touches its collaborators through small duck-typed interfaces, so the sharding and
+collective plumbing is testable on CPU with the gloo backend (tests/test_parallel_cpu.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 2
+
+
+def shard_parts(parts: Sequence[Tuple[object, np.ndarray]], rank: int, world: int):
+    """parts: [(buffer, idx[n_i])] in concat order (global batch = sum n_i).  Returns this rank's
+    slice as parts plus the (lo, hi) global sample range."""
+    total = sum(len(ix) for _, ix in parts)
+    assert total % world == 0, f"global batch {total} not divisible by world size {world}"
+    per = total // world
+    lo, hi = rank * per, (rank + 1) * per
+    out, start = [], 0
+    for buf, ix in parts:
+        a, b = max(lo, start), min(hi, start + len(ix))
+        if a < b:
+            out.append((buf, ix[a - start:b - start]))
+        start += len(ix)
+    return out, (lo, hi)
+
+
+class DataParallelLearner:
+    """core: object with begin_update/encode/critic_grads/actor_grads/apply/grad_view (AgentCore);
+    gather: callable(parts, crop_obs, crop_next) -> device batch for `core.encode`."""
+
+    def __init__(self, core, gather, buffers: List[object], batch_sizes: List[int], rank: int = 0,
+                 world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10):
+        self.core, self.gather, self.buffers, self.batch_sizes = core, gather, buffers, batch_sizes
+        self.rank, self.world = rank, world
+        self.B = sum(batch_sizes)
+        assert self.B % world == 0
+        self.Bl = self.B // world
+        self.all_reduce = all_reduce
+        self.ensemble = ensemble
+        # host noise shared by all ranks (same seed): crop offsets and REDQ subsample indices
+        self._crop_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 1])))
+        self._redq_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 2])))
+        self._gv = {}
+
+    def _view(self, which):
+        if which not in self._gv:
+            self._gv[which] = self.core.grad_view(which)
+        return self._gv[which]
+
+    def _reduce(self, which):
+        if self.world > 1:
+            self.all_reduce(self._view(which))
+
+    def fetch(self):
+        """One global batch: identical index/crop streams on all ranks, local slice materialised."""
+        parts = [(b, b.sample_indices(n)) for b, n in zip(self.buffers, self.batch_sizes)]
+        co = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
+        cn = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
+        local, (lo, hi) = shard_parts(parts, self.rank, self.world)
+        return self.gather(local, co[lo:hi], cn[lo:hi])
+
+    def update_critics(self, batch=None):
+        """DrQAgent.update_critics over the global batch (one grad-step)."""
+        db = self.fetch() if batch is None else batch
+        noise = {"redq_idx": self._redq_rng.integers(0, self.ensemble, size=(1, 2)).astype(np.int32)}
+        self.core.begin_update()
+        self.core.encode(db)
+        self.core.critic_grads(0, self.Bl, self.B, noise)
+        self._reduce(APPLY_CRITIC)
+        self.core.apply(APPLY_CRITIC)
+        return db
+
+    def update_high_utd(self, batch=None):
+        """DrQAgent.update_high_utd(utd_ratio=1): critic step, then actor+temperature on the same batch."""
+        self.update_critics(batch)
+        self.core.actor_grads(self.B, None)
+        self._reduce(APPLY_ACTOR_TEMP)
+        self.core.apply(APPLY_ACTOR_TEMP)
+
+    def iteration(self, critic_actor_ratio: int = 1):
+        """One learner-loop iteration (examples/async_drq_sim/async_drq_sim.py:266-292)."""
+        for _ in range(critic_actor_ratio - 1):
+            self.update_critics()
+        self.update_high_utd()

@@ -42,3 +42,16 @@ def run():
         assert (fr[0, c] == random_shift(ob["observations"][k][:, 0], co)).all()
         assert (fr[1, c] == random_shift(ob["observations"][k][:, 1], cn)).all()
     print("smoke: replay gather+crop parity OK")
+    # one tiny critic + actor update of the HIP agent against the fp64 oracle
+    import agent_helpers as AH
+    from oracle import drq_oracle as O
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    st, core = AH.make_pair(cfg, 8)
+    b = AH.synth_batch(cfg, 8, seed=1)
+    noise = O.make_noise(cfg, 8, seed=2)
+    info, _ = O.update_high_utd(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64), 1)
+    core.update_high_utd(AH.batch_to_device(cfg, b), 1, AH.noise_to_device(cfg, noise))
+    got = core.read_info()
+    for k in ("critic_loss", "predicted_qs", "target_qs", "actor_loss", "entropy", "temperature_loss"):
+        assert abs(got[k] - info[k]) < 1e-4 * max(1.0, abs(info[k])), (k, got[k], info[k])
+    print("smoke: update_high_utd parity OK", {k: round(v, 5) for k, v in got.items()})

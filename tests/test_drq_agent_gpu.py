@@ -1,0 +1,114 @@
+"""GPU: the reference-named Python surface (make_drq_agent, DrQAgent.update_*, sample_actions,
+agent.state, get_iterator / concat_batches learner loop) on top of the C ABI."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_spaces
+
+pytestmark = pytest.mark.gpu
+KEYS, H, W, S, A = ("front", "wrist"), 64, 64, 7, 4
+
+
+class _Env:
+    def __init__(self):
+        self.observation_space, self.action_space = make_spaces(KEYS, H, W, 3, 1, S, A)
+
+
+def _setup(B=16, demo=False):
+    from serl_amd.utils.launcher import make_drq_agent, make_replay_buffer
+    from serl_amd.utils.synthetic import transition_stream
+    env = _Env()
+    rb = make_replay_buffer(env, capacity=300, type="memory_efficient_replay_buffer", image_keys=KEYS)
+    rb.seed(0)
+    for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 20, 5), 150):
+        rb.insert(tr)
+    obs = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8),
+           "state": np.zeros((1, S), np.float32)}
+    agent = make_drq_agent(3, obs, np.zeros((A,), np.float32), image_keys=KEYS,
+                           encoder_type="resnet-pretrained", batch_size=B)
+    return env, rb, agent
+
+
+def test_learner_loop_shape(gpu):
+    """examples/async_drq_sim/async_drq_sim.py:238-292 with critic_actor_ratio=2 and a demo buffer."""
+    from serl_amd.utils.launcher import make_replay_buffer
+    from serl_amd.utils.synthetic import transition_stream
+    from serl_amd.utils.train_utils import concat_batches
+    env, rb, agent = _setup(B=16)
+    demo = make_replay_buffer(env, capacity=100, type="memory_efficient_replay_buffer", image_keys=KEYS)
+    demo.seed(1)
+    for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 10, 9), 40):
+        demo.insert(tr)
+    args = {"batch_size": 8, "pack_obs_and_next_obs": True, "lazy": True}
+    it, dit = rb.get_iterator(sample_args=args), demo.get_iterator(sample_args=args)
+    w0 = agent.core.get("params", "critic/w1").copy()
+    for step in range(3):
+        batch = concat_batches(next(it), next(dit), axis=0)
+        agent, cinfo = agent.update_critics(batch)
+        assert set(cinfo.keys()) == {"critic", "actor_lr", "critic_lr", "temperature_lr"}
+        batch = concat_batches(next(it), next(dit), axis=0)
+        agent, info = agent.update_high_utd(batch, utd_ratio=1)
+        d = info.resolve()
+        assert set(d["critic"]) == {"critic_loss", "predicted_qs", "target_qs"}
+        assert set(d["actor"]) == {"actor_loss", "temperature", "entropy"}
+        assert set(d["temperature"]) == {"temperature_loss"}
+        assert all(np.isfinite(v) for v in d["critic"].values())
+    assert agent.state.step == 9            # 3 x (1 critic + (1 critic + 1 actor/temp)) update() calls
+    assert not np.array_equal(w0, agent.core.get("params", "critic/w1"))
+    _, stale = agent.update_critics(concat_batches(next(it), next(dit), axis=0))
+    agent.update_critics(concat_batches(next(it), next(dit), axis=0))
+    with pytest.raises(RuntimeError):
+        stale.resolve()                      # never read, and overwritten by the later update
+
+
+def test_dict_batch_equals_lazy_batch(gpu):
+    """eager reference-format batch (packed frames) and the fused lazy path feed identical bytes."""
+    env, rb, agent = _setup(B=8)
+    idx = rb.sample_indices(8)
+    from serl_amd.data.data_store import LazyBatch
+    crops = (np.random.default_rng(0).integers(0, 9, (8, 2)).astype(np.int32),
+             np.random.default_rng(1).integers(0, 9, (8, 2)).astype(np.int32))
+    a = agent.prepare(LazyBatch([(rb, idx)]), crops)
+    fa, sa, aa = a.frames.clone(), a.state.clone(), a.action.clone()
+    b = agent.prepare(rb.gather(idx), crops)
+    torch.cuda.synchronize()
+    assert torch.equal(fa, b.frames) and torch.equal(sa, b.state) and torch.equal(aa, b.action)
+
+
+def test_state_export_and_sample_actions(gpu):
+    env, rb, agent = _setup(B=8)
+    p = agent.state.params
+    enc = p["modules_actor"]["encoder"]
+    assert enc["encoder_front"]["pretrained_encoder"]["conv_init"]["kernel"].shape == (7, 7, 3, 64)
+    assert enc["encoder_wrist"]["SpatialLearnedEmbeddings_0"]["kernel"].shape == (2, 2, 512, 8)
+    assert enc["Dense_0"]["kernel"].shape == (S, 64)
+    assert p["modules_critic"]["critic_ensemble"]["Dense_0"]["kernel"].shape == (10, 2 * 256 + 64 + A, 256)
+    assert p["modules_actor"]["Dense_1"]["bias"].shape == (A,)
+    assert p["modules_temperature"]["lagrange"].shape == ()
+    tp = agent.state.target_params
+    assert np.array_equal(tp["modules_actor"]["network"]["Dense_0"]["kernel"], p["modules_actor"]["network"]["Dense_0"]["kernel"])
+    os_ = agent.state.opt_states
+    assert set(os_) == {"actor", "critic", "temperature"} and os_["critic"]["count"] == 0
+    obs = {"front": np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8),
+           "wrist": np.random.default_rng(1).integers(0, 256, (1, H, W, 3), dtype=np.uint8),
+           "state": np.zeros((1, S), np.float32)}
+    a = agent.sample_actions(obs, argmax=True)
+    assert a.shape == (A,) and np.all(np.abs(a) <= 1)
+    a2 = agent.sample_actions(obs, seed=np.array([0, 5], np.uint32))
+    assert a2.shape == (A,) and not np.allclose(a, a2)
+    with pytest.raises(AssertionError):
+        agent.sample_actions(obs, seed=np.array([0, 5], np.uint32), argmax=True)   # sac.py:316-317
+
+
+def test_reference_error_behaviour(gpu):
+    env, rb, agent = _setup(B=6)
+    batch = rb.sample(6, pack_obs_and_next_obs=True, lazy=True)
+    with pytest.raises(AssertionError, match="divisible by UTD"):
+        agent.update_high_utd(batch, utd_ratio=4)
+    from serl_amd.agents.drq import DrQAgent
+    with pytest.raises(NotImplementedError, match="Unknown encoder type"):
+        DrQAgent.create_drq(0, {"front": np.zeros((1, H, W, 3)), "state": np.zeros((1, S))}, np.zeros(A),
+                            encoder_type="bogus", image_keys=("front",))

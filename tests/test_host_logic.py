@@ -1,0 +1,55 @@
+"""CPU: host-side logic that needs no GPU (lazy batches, flax tree naming, initialisers, shims)."""
+import numpy as np
+import pytest
+
+from serl_amd.data.data_store import LazyBatch, concat_batches
+from serl_amd.utils import init as pinit
+
+
+def test_lazy_concat_order():
+    a, b = object(), object()
+    la, lb = LazyBatch([(a, np.arange(3))]), LazyBatch([(b, np.arange(5))])
+    c = concat_batches(la, lb, axis=0)  # async_drq_sim.py:277: online first, then demo
+    assert c.batch_size == 8 and c.parts[0][0] is a and c.parts[1][0] is b
+    with pytest.raises(AssertionError):
+        concat_batches(la, lb, axis=1)
+
+
+def test_param_counts_match_survey():
+    th = pinit.theta_shapes(2, 128, 128, 24, 6)
+    n = sum(int(np.prod(s)) if len(s) else 1 for s in th.values())
+    assert n == 4_609_998
+    t = sum(int(np.prod(s)) for s in pinit.trunk_shapes().values())
+    assert t == 4_905_792
+    names = list(th)
+    # arena order: camera heads | critic | proprio | actor | temperature (optimizer supports contiguous)
+    assert names.index("critic/w1") < names.index("enc/proprio/dense/kernel") < names.index("actor/w1")
+    assert names[-1] == "temp/lagrange"
+
+
+def test_flax_tree_paths():
+    from serl_amd.agents.flax_tree import theta_paths, _trunk_paths
+    tp = theta_paths(("front", "wrist"))
+    assert tp["enc/1/sle"] == [("modules_actor", "encoder", "encoder_wrist", "SpatialLearnedEmbeddings_0", "kernel")]
+    assert tp["critic/head/kernel"] == [("modules_critic", "Dense_0", "kernel")]
+    assert tp["temp/lagrange"] == [("modules_temperature", "lagrange")]
+    assert set(tp) == set(pinit.theta_shapes(2, 128, 128, 24, 6))
+    assert set(_trunk_paths()) == set(pinit.trunk_shapes())
+
+
+def test_initialisers_are_seeded_and_sane():
+    a = pinit.init_theta(2, 64, 64, 5, 3, seed=1)
+    b = pinit.init_theta(2, 64, 64, 5, 3, seed=1)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert abs(float(np.log1p(np.exp(a["temp/lagrange"]))) - 1e-2) < 1e-6   # softplus(lambda0) = temperature_init
+    assert a["critic/w1"].shape == (10, 2 * 256 + 64 + 3, 256)
+    t = pinit.init_trunk(seed=1)
+    assert t["trunk/block1/proj"].shape == (1, 1, 64, 128) and "trunk/block0/proj" not in t
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from serl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.SerlError, match="no CPU fallback"):
+        _lib.lib()

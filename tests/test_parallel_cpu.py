@@ -1,0 +1,127 @@
+"""CPU (gloo, world_size 2): the data-parallel plumbing of serl_amd/parallel.py -- identical index
+streams on all ranks, sample sharding over a concatenated (online+demo) batch, all-reduce of the
+[gradients | scalars] view and identical parameter updates -- with a NumPy stand-in for the HIP core."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from serl_amd.parallel import APPLY_ACTOR_TEMP, APPLY_CRITIC, DataParallelLearner, shard_parts
+
+
+class FakeBuffer:
+    def __init__(self, n, seed):
+        self.n = n
+        self.rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+    def sample_indices(self, b):
+        return self.rng.integers(self.n, size=b)
+
+
+class FakeCore:
+    """grad = sum over LOCAL samples of phi(sample id) / global_count; params -= grad on apply."""
+
+    def __init__(self, dim=7):
+        self.g = {APPLY_CRITIC: torch.zeros(dim + 3, dtype=torch.float64),
+                  APPLY_ACTOR_TEMP: torch.zeros(3 + dim, dtype=torch.float64)}
+        self.params = torch.zeros(dim, dtype=torch.float64)
+        self.dim, self.batch, self.log = dim, None, []
+
+    @staticmethod
+    def phi(ids, dim):
+        return np.stack([np.sin(ids * (k + 1) * 0.37) for k in range(dim)], axis=1)
+
+    def begin_update(self):
+        pass
+
+    def encode(self, batch):
+        self.batch = batch
+
+    def critic_grads(self, off, cnt, global_count, noise, redq_row=0):
+        ids = self.batch["ids"][off:off + cnt].astype(np.float64)
+        self.g[APPLY_CRITIC][:self.dim] = torch.tensor(self.phi(ids, self.dim).sum(0) / global_count)
+        self.g[APPLY_CRITIC][self.dim:] = torch.tensor([ids.sum(), len(ids), float(noise["redq_idx"].sum()) * len(ids) / global_count])
+
+    def actor_grads(self, global_count, noise):
+        ids = self.batch["ids"].astype(np.float64)
+        self.g[APPLY_ACTOR_TEMP][3:] = torch.tensor(self.phi(ids + 0.5, self.dim).sum(0) / global_count)
+        self.g[APPLY_ACTOR_TEMP][:3] = torch.tensor([ids.sum(), len(ids), 0.0])
+
+    def apply(self, which, w=1.0):
+        g = self.g[which][:self.dim] if which == APPLY_CRITIC else self.g[which][3:]
+        self.params -= g
+        self.log.append(self.g[which].clone())
+
+    def grad_view(self, which):
+        return self.g[which]
+
+
+def _gather(parts, co, cn):
+    ids = np.concatenate([ix + 1000 * k for k, (b, ix) in enumerate(parts)]) if parts else np.zeros(0)
+    assert len(co) == len(ids) == len(cn)
+    return {"ids": ids, "co": co, "cn": cn}
+
+
+def _tagged_gather(bufs):
+    def g(parts, co, cn):
+        ids = np.concatenate([ix + 1000 * bufs.index(b) for b, ix in parts])
+        return {"ids": ids, "co": co, "cn": cn}
+    return g
+
+
+def _run(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bufs = [FakeBuffer(500, 0), FakeBuffer(60, 1)]
+    core = FakeCore()
+    lr = DataParallelLearner(core, _tagged_gather(bufs), bufs, [12, 12], rank, world,
+                             all_reduce=lambda t: dist.all_reduce(t), seed=3)
+    for _ in range(3):
+        lr.iteration(critic_actor_ratio=2)
+    out[rank] = (core.params.numpy().copy(), [x.numpy().copy() for x in core.log])
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_parts_covers_batch_exactly():
+    a, b = object(), object()
+    parts = [(a, np.arange(10)), (b, np.arange(100, 106))]
+    seen = []
+    for r in range(4):
+        loc, (lo, hi) = shard_parts(parts, r, 4)
+        assert hi - lo == 4 and sum(len(ix) for _, ix in loc) == 4
+        seen += [int(v) for _, ix in loc for v in ix]
+    assert seen == list(range(10)) + list(range(100, 106))
+    with pytest.raises(AssertionError):
+        shard_parts(parts, 0, 3)
+
+
+def test_two_rank_dp_matches_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run, args=(world, port, out), nprocs=world, join=True)
+    # single-process reference
+    bufs = [FakeBuffer(500, 0), FakeBuffer(60, 1)]
+    core = FakeCore()
+    lr = DataParallelLearner(core, _tagged_gather(bufs), bufs, [12, 12], 0, 1, seed=3)
+    for _ in range(3):
+        lr.iteration(critic_actor_ratio=2)
+    p0, log0 = out[0]
+    p1, log1 = out[1]
+    assert np.array_equal(p0, p1), "ranks must apply identical updates"
+    assert np.allclose(p0, core.params.numpy(), rtol=0, atol=1e-12)
+    for x, y, z in zip(log0, log1, core.log):
+        assert np.array_equal(x, y)
+        assert np.allclose(x, z.numpy(), rtol=0, atol=1e-9)  # all-reduced sums == full-batch values
