@@ -278,11 +278,13 @@ struct ConvArgs {
 };
 
 // PMODE: how output rows map to images for the GN statistics
-//   0: P % 64 == 0 (a wave's 64 rows lie in one image)   1: P == 32   2: P == 16   3: no stats
-template <int WM, int WN, int PMODE>
+//   0: P % (32*TM) == 0 (a wave's rows lie in one image)   1: P == 32   2: P == 16   3: no stats
+// TM: 32-row MFMA tiles per wave along M (wave tile = 32*TM x 64).  Workgroup tile = (32*TM*WM) x (64*WN).
+template <int WM, int WN, int TM, int PMODE, bool ONE_IMG>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
-  constexpr int BM = 64 * WM, BN = 64 * WN, AS = 33, BS = BN + 4;
+  constexpr int WROWS = 32 * TM;
+  constexpr int BM = WROWS * WM, BN = 64 * WN, AS = 33, BS = BN + 4;
   constexpr int AI = BM / 32;  // float4 A loads per thread per chunk
   constexpr int BI = BN / 32;  // float4 B loads per thread per chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -311,85 +313,106 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       rn[i] = 0; rpix[i] = 0; riy[i] = -(1 << 20); rix[i] = -(1 << 20);
     }
   }
+  // ONE_IMG: one image per workgroup tile (P % BM == 0) -> one scale/shift vector per chunk serves all
+  // rows of this thread.  (Compile-time: a runtime select over the arrays would put them in scratch.)
   const int cpt = a.Cin >> 5;  // 32-channel chunks per tap
   const int nchunks = a.KH * a.KW * cpt;
   const int brow = BN == 64 ? (tid >> 4) : (tid >> 5);
   const int bcol = BN == 64 ? (tid & 15) : (tid & 31);
   constexpr int BROWSTEP = BN == 64 ? 16 : 8;
 
-  float4 ra[AI], rb[BI];
-  auto load_chunk = [&](int c) {
-    const int tap = c / cpt, ci0 = (c - tap * cpt) << 5;
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int iy = riy[i] + ky, ix = rix[i] + kx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) {
-        v = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + iy * a.Wi + ix) * a.Cin + ci0 + 4 * kq);
-        if (a.in_sc) {
-          const float4 s = *reinterpret_cast<const float4*>(a.in_sc + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);
-          const float4 h = *reinterpret_cast<const float4*>(a.in_sh + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);
-          v.x = fmaxf(v.x * s.x + h.x, 0.f);
-          v.y = fmaxf(v.y * s.y + h.y, 0.f);
-          v.z = fmaxf(v.z * s.z + h.z, 0.f);
-          v.w = fmaxf(v.w * s.w + h.w, 0.f);
-        }
-      }
-      ra[i] = v;
-    }
-    const float* wp = a.w + (size_t)(c << 5) * a.Cout + n0 + 4 * bcol;
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      rb[i] = *reinterpret_cast<const float4*>(wp + (size_t)(brow + BROWSTEP * i) * a.Cout);
-  };
-  auto store_chunk = [&](int buf) {
-    float* Ab = As + buf * BM * AS;
-    float* Bb = Bs + buf * 32 * BS;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      float* p = Ab + ((tid >> 3) + 32 * i) * AS + 4 * kq;
-      p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      *reinterpret_cast<float4*>(Bb + (brow + BROWSTEP * i) * BS + 4 * bcol) = rb[i];
-  };
+  constexpr int NS = ONE_IMG ? 1 : AI;
+  float4 ra[AI], rb[BI], rs[NS], rh[NS];
+  unsigned okmask = 0;
+  // Loads are unconditional (coordinates clamped into the image): nothing consumes a loaded value
+  // before the MFMA phase of the current chunk is over, so all of them stay in flight together.
+  // (Macros, not lambdas: by-reference captures kept the staging arrays in scratch memory.)
+#define SERL_LOAD_CHUNK(CIDX)                                                                                  \
+  {                                                                                                            \
+    const int c_ = (CIDX);                                                                                     \
+    const int tap = c_ / cpt, ci0 = (c_ - tap * cpt) << 5;                                                     \
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;                                                           \
+    okmask = 0;                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
+      const int iy = riy[i] + ky, ix = rix[i] + kx;                                                            \
+      const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;                          \
+      okmask |= (ok ? 1u : 0u) << i;                                                                           \
+      const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);                                \
+      ra[i] = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + cy * a.Wi + cx) * a.Cin + ci0 + 4 * kq); \
+    }                                                                                                          \
+    if (a.in_sc) {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                                         \
+        rs[i] = *reinterpret_cast<const float4*>(a.in_sc + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);              \
+        rh[i] = *reinterpret_cast<const float4*>(a.in_sh + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);              \
+      }                                                                                                        \
+    }                                                                                                          \
+    const float* wp = a.w + (size_t)(c_ << 5) * a.Cout + n0 + 4 * bcol;                                        \
+    _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                             \
+        rb[i] = *reinterpret_cast<const float4*>(wp + (size_t)(brow + BROWSTEP * i) * a.Cout);                 \
+  }
+  // GroupNorm+ReLU of the producing layer and the zero padding are applied here, on the way to LDS
+#define SERL_STORE_CHUNK(BUF)                                                                                  \
+  {                                                                                                            \
+    float* Ab_ = As + (BUF) * BM * AS;                                                                         \
+    float* Bb_ = Bs + (BUF) * 32 * BS;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
+      float4 v = ra[i];                                                                                        \
+      if (a.in_sc) {                                                                                           \
+        const float4 s_ = rs[ONE_IMG ? 0 : i];                                                                 \
+        const float4 h_ = rh[ONE_IMG ? 0 : i];                                                                 \
+        v.x = fmaxf(v.x * s_.x + h_.x, 0.f);                                                                   \
+        v.y = fmaxf(v.y * s_.y + h_.y, 0.f);                                                                   \
+        v.z = fmaxf(v.z * s_.z + h_.z, 0.f);                                                                   \
+        v.w = fmaxf(v.w * s_.w + h_.w, 0.f);                                                                   \
+      }                                                                                                        \
+      if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
+      float* p_ = Ab_ + ((tid >> 3) + 32 * i) * AS + 4 * kq;                                                   \
+      p_[0] = v.x; p_[1] = v.y; p_[2] = v.z; p_[3] = v.w;                                                      \
+    }                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < BI; ++i)                                                             \
+        *reinterpret_cast<float4*>(Bb_ + (brow + BROWSTEP * i) * BS + 4 * bcol) = rb[i];                       \
+  }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
-  load_chunk(0);
-  store_chunk(0);
+  SERL_LOAD_CHUNK(0);
+  SERL_STORE_CHUNK(0);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
-    const float* Ab = As + buf * BM * AS + (wm * 64 + li) * AS + lh;
+    // unconditional prefetch/store (the last iteration re-loads its own chunk into the idle buffer):
+    // keeps the staging registers in SSA form -- a conditional here makes hipcc spill them to scratch
+    // and wait for every load right after issuing it.
+    SERL_LOAD_CHUNK(min(c + 1, nchunks - 1));
+    const float* Ab = As + buf * BM * AS + (wm * WROWS + li) * AS + lh;
     const float* Bb = Bs + buf * 32 * BS + lh * BS + wn * 64 + li;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const float a0 = Ab[2 * ks], a1 = Ab[32 * AS + 2 * ks];
       const float b0 = Bb[2 * ks * BS], b1 = Bb[2 * ks * BS + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const float av = Ab[tm * 32 * AS + 2 * ks];
+        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[tm][1], 0, 0, 0);
+      }
     }
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    SERL_STORE_CHUNK(buf ^ 1);
     __syncthreads();
   }
+#undef SERL_LOAD_CHUNK
+#undef SERL_STORE_CHUNK
 
   // ---- epilogue: raw conv output (NHWC == row-major [M][Cout])
-  const int wrow0 = m0 + wm * 64;
+  const int wrow0 = m0 + wm * WROWS;
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -402,10 +425,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // ---- epilogue: GroupNorm statistics (rows beyond M are exact zeros and contribute nothing)
   if (PMODE != 3) {
     const int gsize = a.Cout / kGnGroups;
-    constexpr int NSLOT = PMODE == 0 ? 1 : (PMODE == 1 ? 2 : 4);
+    constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);  // rows per image slot
+    constexpr int NSLOT = WROWS / ROWS;
 #pragma unroll
     for (int slot = 0; slot < NSLOT; ++slot) {
-      constexpr int ROWS = 64 / NSLOT;
       const int mrow = wrow0 + slot * ROWS;
       const bool valid = mrow < a.M;
       const int n = valid ? mrow / a.P : 0;
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int tn = 0; tn < 2; ++tn) {
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = tm * 32 + 8 * (r >> 2);  // (+ (r&3) + 4*lh < 8): 8-row granules
@@ -503,30 +526,34 @@ static int launch_conv(const char* tag, const float* in, const float* w, float* 
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
   const bool wide = Cout >= 128;
-  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  const int BM = 128, BN = wide ? 128 : 64;   // wide: 2x2 waves of 64x64; narrow: 4x1 waves of 32x64
   a.tiles_m = cd(a.M, BM); a.tiles_n = Cout / BN;
   const size_t lds = (size_t)(2 * BM * 33 + 2 * 32 * (BN + 4)) * 4;
-  const int pmode = (a.P % 64 == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
+  const int wrows = wide ? 64 : 32;
+  const int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
   {
   ProfScope prof(tag, stream);
-#define SERL_LAUNCH_CONV(WM, WN, PM) \
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, PM>), grid, block, lds, stream, a)
+  const bool one_img = (a.P % BM) == 0;
+#define SERL_LAUNCH_CONV(WM, WN, TM, PM)                                                                 \
+  do {                                                                                                   \
+    if (one_img) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, PM, true>), grid, block, lds, stream, a);  \
+    else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, PM, false>), grid, block, lds, stream, a);         \
+  } while (0)
   if (wide) {
-    if (pmode == 0) SERL_LAUNCH_CONV(2, 2, 0);
-    else if (pmode == 1) SERL_LAUNCH_CONV(2, 2, 1);
-    else if (pmode == 2) SERL_LAUNCH_CONV(2, 2, 2);
-    else SERL_LAUNCH_CONV(2, 2, 3);
+    if (pmode == 0) SERL_LAUNCH_CONV(2, 2, 2, 0);
+    else if (pmode == 1) SERL_LAUNCH_CONV(2, 2, 2, 1);
+    else if (pmode == 2) SERL_LAUNCH_CONV(2, 2, 2, 2);
+    else SERL_LAUNCH_CONV(2, 2, 2, 3);
   } else {
-    if (pmode == 0) SERL_LAUNCH_CONV(4, 1, 0);
-    else if (pmode == 1) SERL_LAUNCH_CONV(4, 1, 1);
-    else if (pmode == 2) SERL_LAUNCH_CONV(4, 1, 2);
-    else SERL_LAUNCH_CONV(4, 1, 3);
+    if (pmode == 0) SERL_LAUNCH_CONV(4, 1, 1, 0);
+    else if (pmode == 2) SERL_LAUNCH_CONV(4, 1, 1, 2);
+    else SERL_LAUNCH_CONV(4, 1, 1, 3);
   }
 #undef SERL_LAUNCH_CONV
   }
   SERL_HIP(hipGetLastError());
-  if (pmode == 3) {  // statistics in a separate pass
+  if (pmode == 3 || (!wide && pmode == 1)) {  // statistics in a separate pass
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
     SERL_HIP(hipGetLastError());
   }
