@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--fill", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,6 +84,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert B % world == 0
     Bl = B // world
+    emu = args.emulate_world
+    if emu:
+        assert world == 1
+        Bl = B // emu
 
     from serl_amd import _lib
     from serl_amd.agents.batch import DeviceBatch
@@ -111,8 +117,8 @@ def main():
         return db
 
     from serl_amd.parallel import DataParallelLearner
-    learner = DataParallelLearner(core, gather, [rb], [B], rank, world,
-                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else None, seed=7)
+    learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world,
+                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else (lambda t: None), seed=7)
 
     def iteration():
         learner.iteration(args.car)
@@ -183,7 +189,7 @@ def main():
         "config": {"workload": "async_drq_sim (DrQ, ResNet-10 frozen trunk, REDQ-10 critic)", "global_batch": B,
                    "per_gpu_batch": Bl, "cameras": len(KEYS), "image": [H, W, 3], "state_dim": S, "act_dim": A,
                    "critic_actor_ratio": args.car, "utd_ratio": 1, "replay_capacity": args.capacity,
-                   "replay_fill": args.fill, "parallelism": f"dp{world}", "grad_steps_per_step": args.car,
+                   "replay_fill": args.fill, "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": args.car,
                    "trunk_passes_per_grad_step": 2},
         "roofline": roofline,
         "last_info": {k: round(float(v), 6) for k, v in info.items()},

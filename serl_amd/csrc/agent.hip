@@ -417,9 +417,7 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
   l.dx = dpre; l.dg = dg;
   RC(ln_tanh_bwd(l, D, st));
   if (G) {
-    RC(colsum(dg, xhat, groups, rows_per_group, D, G + g_off, pg_gstride, false, st));
-    RC(colsum(dg, nullptr, groups, rows_per_group, D, G + be_off, pg_gstride, false, st));
-    RC(colsum(dpre, nullptr, groups, rows_per_group, D, G + b_off, pg_gstride, false, st));
+    RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, st));
   }
   return SERL_OK;
 }

@@ -33,6 +33,8 @@ int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream);
 
 int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
            long out_gstride, bool accumulate, hipStream_t stream);
+int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
+            float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
 int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
             int Cc, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,

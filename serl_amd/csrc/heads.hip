@@ -239,6 +239,46 @@ int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D
   return SERL_OK;
 }
 
+// fused parameter gradients of one Dense->LN->tanh layer (one pass over dg, xhat, dpre):
+//   dgamma[g][j] = sum_r dg*xhat,  dbeta[g][j] = sum_r dg,  dbias[g][j] = sum_r dpre
+__global__ __launch_bounds__(512) void colsum3_kernel(const float* dg, const float* xhat, const float* dpre,
+                                                     int rows_per_group, int D, float* o_gamma, float* o_beta,
+                                                     float* o_bias, long gstride) {
+  __shared__ float red[3][8][64];
+  const int grp = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (col < D) {
+    const long base = (long)grp * rows_per_group;
+    for (int r = part; r < rows_per_group; r += 8) {
+      const long e = (base + r) * D + col;
+      const float g = dg[e];
+      s0 += g * xhat[e];
+      s1 += g;
+      s2 += dpre[e];
+    }
+  }
+  red[0][part][threadIdx.x & 63] = s0;
+  red[1][part][threadIdx.x & 63] = s1;
+  red[2][part][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (part < 3 && col < D) {
+    const int c = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[part][k][c];
+    float* o = (part == 0 ? o_gamma : (part == 1 ? o_beta : o_bias)) + (long)grp * gstride + col;
+    *o = t;
+  }
+}
+
+int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
+            float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum3_kernel, dim3(cdiv(D, 64), groups), dim3(512), 0, stream, dg, xhat, dpre,
+                     rows_per_group, D, o_gamma, o_beta, o_bias, gstride);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
 // =============================================================================================
 // SpatialLearnedEmbeddings (resnet_v1.py:94-111): f[n][c*F+j] = sum_hw x[n][hw][c]*K[hw][c][j]
 // (+ Dropout(0.1) keep-mask, resnet_v1.py:351).  F == 8.

@@ -35,7 +35,6 @@ struct TrunkWorkspace {
     float *raw0, *raw1, *rawp, *out;
   } blk[kTrunkStages]{};
   double* stats = nullptr;  // 13 GN layers x [N][4][2]
-  float* coef = nullptr;    // 13 GN layers x 2 x [N][512]
   void* base = nullptr;     // single allocation backing everything above
   size_t bytes = 0;
 };

@@ -153,22 +153,29 @@ __global__ __launch_bounds__(256) void conv_init_kernel(ConvInitArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm coefficients: stats (sum, sumsq) -> per (image, channel) scale/shift
+// GroupNorm applied by the CONSUMER: every kernel that reads a raw conv output derives the per
+// (image, channel) scale/shift on the fly from the producer's (sum, sumsq) statistics:
 //   y = x*sc + sh,  sc = gamma*rsqrt(var+eps),  sh = beta - mean*sc,  var = max(0, E[x^2]-E[x]^2)
+// (flax nn.GroupNorm fast variance, eps 1e-5; resnet_v1.py:119-126,237).  No coefficient table, no
+// extra launch between a conv and its consumer.
 // ---------------------------------------------------------------------------------------------
-__global__ void gn_coef_kernel(const double* stats, const float* gamma, const float* beta, float* sc,
-                               float* sh, int N, int Cc, double inv_count, float eps) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N * Cc) return;
-  const int n = e / Cc, c = e - n * Cc;
-  const int g = c / (Cc / kGnGroups);
-  const double mean = stats[((size_t)n * kGnGroups + g) * 2] * inv_count;
-  const double m2 = stats[((size_t)n * kGnGroups + g) * 2 + 1] * inv_count;
+struct GnRef {
+  const double* stats;  // [N][4][2] (sum, sumsq) of the producing conv; nullptr = identity
+  const float* gamma;   // [C]
+  const float* beta;    // [C]
+  double inv_count;     // 1 / (P * C/4)
+  int gsize;            // channels per group
+};
+
+__device__ __forceinline__ void gn_coef4(const GnRef& g, int n, int c, float4& sc, float4& sh) {
+  const double* st = g.stats + ((size_t)n * kGnGroups + c / g.gsize) * 2;
+  const double mean = st[0] * g.inv_count, m2 = st[1] * g.inv_count;
   const float var = fmaxf((float)(m2 - mean * mean), 0.f);
-  const float rstd = rsqrtf(var + eps);
-  const float scv = gamma[c] * rstd;
-  sc[e] = scv;
-  sh[e] = beta[c] - (float)mean * scv;
+  const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
+  const float4 ga = *reinterpret_cast<const float4*>(g.gamma + c);
+  const float4 be = *reinterpret_cast<const float4*>(g.beta + c);
+  sc = make_float4(ga.x * rstd, ga.y * rstd, ga.z * rstd, ga.w * rstd);
+  sh = make_float4(be.x - mf * sc.x, be.y - mf * sc.y, be.z - mf * sc.z, be.w - mf * sc.w);
 }
 
 // fallback GroupNorm statistics pass (used when the conv epilogue cannot attribute its rows to
@@ -204,9 +211,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* s
 // ---------------------------------------------------------------------------------------------
 // GN-apply + ReLU + max_pool 3x3 stride 2 SAME (pad lo 0 / hi 1 with -inf)   (resnet_v1.py:257-259)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* x, const float* sc,
-                                                             const float* sh, float* out, int N, int Hi,
-                                                             int Wi, int Ho, int Wo, int Cc) {
+__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* x, GnRef gn, float* out, int N,
+                                                             int Hi, int Wi, int Ho, int Wo, int Cc) {
   const int c4n = Cc / 4;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)N * Ho * Wo * c4n) return;
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* x, co
   t /= Wo;
   const int oy = (int)(t % Ho);
   const int n = (int)(t / Ho);
-  const float4 s = *reinterpret_cast<const float4*>(sc + (size_t)n * Cc + c4 * 4);
-  const float4 h = *reinterpret_cast<const float4*>(sh + (size_t)n * Cc + c4 * 4);
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
@@ -238,21 +244,20 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* x, co
 }
 
 // block output: out = relu( GN(raw_b) + residual ), residual = res (already activated) or GN(res_raw)
-__global__ __launch_bounds__(256) void block_out_kernel(const float* raw, const float* sc, const float* sh,
-                                                       const float* res, const float* rsc,
-                                                       const float* rsh, float* out, int N, int P, int Cc) {
+__global__ __launch_bounds__(256) void block_out_kernel(const float* raw, GnRef gn, const float* res, GnRef rgn,
+                                                       float* out, int N, int P, int Cc) {
   const int c4n = Cc / 4;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)N * P * c4n) return;
   const int c4 = (int)(e % c4n);
   const int n = (int)(e / ((long)P * c4n));
   const float4 v = reinterpret_cast<const float4*>(raw)[e];
-  const float4 s = *reinterpret_cast<const float4*>(sc + (size_t)n * Cc + c4 * 4);
-  const float4 h = *reinterpret_cast<const float4*>(sh + (size_t)n * Cc + c4 * 4);
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
   float4 r = reinterpret_cast<const float4*>(res)[e];
-  if (rsc) {
-    const float4 s2 = *reinterpret_cast<const float4*>(rsc + (size_t)n * Cc + c4 * 4);
-    const float4 h2 = *reinterpret_cast<const float4*>(rsh + (size_t)n * Cc + c4 * 4);
+  if (rgn.stats) {
+    float4 s2, h2;
+    gn_coef4(rgn, n, c4 * 4, s2, h2);
     r.x = r.x * s2.x + h2.x; r.y = r.y * s2.y + h2.y; r.z = r.z * s2.z + h2.z; r.w = r.w * s2.w + h2.w;
   }
   float4 o;
@@ -271,30 +276,43 @@ struct ConvArgs {
   const float* w;      // [KH*KW*Cin][Cout]
   float* out;          // [N][Ho][Wo][Cout]
   double* stats;       // [N][4][2] or nullptr
-  const float* in_sc;  // [N][Cin] GroupNorm-on-load (with ReLU) or nullptr
-  const float* in_sh;
+  GnRef in_gn;         // GroupNorm+ReLU of the producing layer applied on load (stats == nullptr: none)
   int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, padw;
   int M, P, tiles_m, tiles_n;
 };
 
 // PMODE: how output rows map to images for the GN statistics
 //   0: P % (32*TM) == 0 (a wave's rows lie in one image)   1: P == 32   2: P == 16   3: no stats
-// TM: 32-row MFMA tiles per wave along M (wave tile = 32*TM x 64).  Workgroup tile = (32*TM*WM) x (64*WN).
-template <int WM, int WN, int TM, int PMODE, bool ONE_IMG>
+// TM/TN: 32x32 MFMA tiles per wave along M/N.  Workgroup tile = (32*TM*WM) x (32*TN*WN).
+template <int WM, int WN, int TM, int TN, int PMODE, bool ONE_IMG>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int WROWS = 32 * TM;
-  constexpr int BM = WROWS * WM, BN = 64 * WN, AS = 33, BS = BN + 4;
+  constexpr int WCOLS = 32 * TN;
+  constexpr int BM = WROWS * WM, BN = WCOLS * WN, AS = 33, BS = BN + 4;
   constexpr int AI = BM / 32;  // float4 A loads per thread per chunk
   constexpr int BI = BN / 32;  // float4 B loads per thread per chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                // [2][BM][AS]
   float* Bs = smem + 2 * BM * AS;  // [2][32][BS]
+  float* gnm = Bs + 2 * 32 * BS;   // [(BM+1)*4] mean  of (image in tile, group) of the producing layer
+  float* gnr = gnm + (BM + 1) * 4; // [(BM+1)*4] rstd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
+  const int n_first = m0 / a.P;
+  if (a.in_gn.stats) {  // GroupNorm statistics of the producer -> (mean, rstd) table for this tile's images
+    const int n_last = min(a.N - 1, (m0 + BM - 1) / a.P);
+    for (int t = tid; t < (n_last - n_first + 1) * kGnGroups; t += 256) {
+      const double* st = a.in_gn.stats + ((size_t)n_first * kGnGroups + t) * 2;
+      const double mean = st[0] * a.in_gn.inv_count, m2 = st[1] * a.in_gn.inv_count;
+      gnm[t] = (float)mean;
+      gnr[t] = rsqrtf(fmaxf((float)(m2 - mean * mean), 0.f) + 1e-5f);
+    }
+    __syncthreads();
+  }
 
   // ---- per-thread im2col row bookkeeping (rows are fixed across K chunks)
   const int kq = tid & 7;
@@ -317,9 +335,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // rows of this thread.  (Compile-time: a runtime select over the arrays would put them in scratch.)
   const int cpt = a.Cin >> 5;  // 32-channel chunks per tap
   const int nchunks = a.KH * a.KW * cpt;
-  const int brow = BN == 64 ? (tid >> 4) : (tid >> 5);
-  const int bcol = BN == 64 ? (tid & 15) : (tid & 31);
-  constexpr int BROWSTEP = BN == 64 ? 16 : 8;
+  constexpr int BQ = BN / 4;            // float4 per weight-tile row
+  constexpr int BROWSTEP = 256 / BQ;    // rows covered per pass of the 256 threads
+  const int brow = tid / BQ, bcol = tid % BQ;
 
   constexpr int NS = ONE_IMG ? 1 : AI;
   float4 ra[AI], rb[BI], rs[NS], rh[NS];
@@ -340,10 +358,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);                                \
       ra[i] = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + cy * a.Wi + cx) * a.Cin + ci0 + 4 * kq); \
     }                                                                                                          \
-    if (a.in_sc) {                                                                                             \
+    if (a.in_gn.stats) {                                                                                       \
+      const int c4_ = ci0 + 4 * kq, grp_ = c4_ / a.in_gn.gsize;                                                \
+      const float4 ga_ = *reinterpret_cast<const float4*>(a.in_gn.gamma + c4_);                                \
+      const float4 be_ = *reinterpret_cast<const float4*>(a.in_gn.beta + c4_);                                 \
       _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                                         \
-        rs[i] = *reinterpret_cast<const float4*>(a.in_sc + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);              \
-        rh[i] = *reinterpret_cast<const float4*>(a.in_sh + (size_t)rn[i] * a.Cin + ci0 + 4 * kq);              \
+        const int t_ = max(rn[i] - n_first, 0) * kGnGroups + grp_;                                             \
+        const float mean_ = gnm[t_], rstd_ = gnr[t_];                                                          \
+        rs[i] = make_float4(ga_.x * rstd_, ga_.y * rstd_, ga_.z * rstd_, ga_.w * rstd_);                       \
+        rh[i] = make_float4(be_.x - mean_ * rs[i].x, be_.y - mean_ * rs[i].y, be_.z - mean_ * rs[i].z,         \
+                            be_.w - mean_ * rs[i].w);                                                          \
       }                                                                                                        \
     }                                                                                                          \
     const float* wp = a.w + (size_t)(c_ << 5) * a.Cout + n0 + 4 * bcol;                                        \
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     float* Bb_ = Bs + (BUF) * 32 * BS;                                                                         \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       float4 v = ra[i];                                                                                        \
-      if (a.in_sc) {                                                                                           \
+      if (a.in_gn.stats) {                                                                                     \
         const float4 s_ = rs[ONE_IMG ? 0 : i];                                                                 \
         const float4 h_ = rh[ONE_IMG ? 0 : i];                                                                 \
         v.x = fmaxf(v.x * s_.x + h_.x, 0.f);                                                                   \
@@ -373,11 +397,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         *reinterpret_cast<float4*>(Bb_ + (brow + BROWSTEP * i) * BS + 4 * bcol) = rb[i];                       \
   }
 
-  f32x16 acc[TM][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
@@ -392,15 +416,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // and wait for every load right after issuing it.
     SERL_LOAD_CHUNK(min(c + 1, nchunks - 1));
     const float* Ab = As + buf * BM * AS + (wm * WROWS + li) * AS + lh;
-    const float* Bb = Bs + buf * 32 * BS + lh * BS + wn * 64 + li;
+    const float* Bb = Bs + buf * 32 * BS + lh * BS + wn * WCOLS + li;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const float b0 = Bb[2 * ks * BS], b1 = Bb[2 * ks * BS + 32];
+      float bv[TN];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) bv[tn] = Bb[2 * ks * BS + 32 * tn];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const float av = Ab[tm * 32 * AS + 2 * ks];
-        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[tm][0], 0, 0, 0);
-        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[tm][1], 0, 0, 0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[tn], acc[tm][tn], 0, 0, 0);
       }
     }
     SERL_STORE_CHUNK(buf ^ 1);
@@ -417,9 +444,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m < a.M) {
-        float* o = a.out + (size_t)m * a.Cout + n0 + wn * 64 + li;
-        o[0] = acc[tm][0][r];
-        o[32] = acc[tm][1][r];
+        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
       }
     }
   // ---- epilogue: GroupNorm statistics (rows beyond M are exact zeros and contribute nothing)
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int n = valid ? mrow / a.P : 0;
       double* st = a.stats + (size_t)n * kGnGroups * 2;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
+      for (int tn = 0; tn < TN; ++tn) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
               q += v * v;
             }
           }
-        stats_flush(s, q, st, n0 + wn * 64 + tn * 32 + li, gsize, valid);
+        stats_flush(s, q, st, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
       }
     }
   }
@@ -492,11 +519,10 @@ static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int 
     blk[i].out = (float*)take(e);
   }
   double* stats = (double*)take((size_t)kGnLayers * N * kGnGroups * 2 * sizeof(double));
-  float* coef = (float*)take((size_t)kGnLayers * 2 * N * 512 * 4);
   if (ws) {
     ws->max_images = N; ws->d = d; ws->raw_init = raw_init; ws->pool = pool;
     for (int i = 0; i < kTrunkStages; ++i) ws->blk[i] = blk[i];
-    ws->stats = stats; ws->coef = coef; ws->base = base; ws->bytes = off;
+    ws->stats = stats; ws->base = base; ws->bytes = off;
   }
   return off;
 }
@@ -512,60 +538,64 @@ int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, i
   return SERL_OK;
 }
 
-static int launch_conv(const char* tag, const float* in, const float* w, float* out, double* stats,
-                       const float* in_sc, const float* in_sh, int N, int Hi, int Wi, int Cin, int Ho, int Wo,
-                       int Cout, int ksz, int stride, hipStream_t stream) {
+static GnRef gn_ref(const double* stats, const float* gamma, const float* beta, int P, int Cc) {
+  GnRef g{};
+  g.stats = stats; g.gamma = gamma; g.beta = beta;
+  g.inv_count = 1.0 / ((double)P * (Cc / kGnGroups));
+  g.gsize = Cc / kGnGroups;
+  return g;
+}
+
+static int launch_conv(const char* tag, const float* in, const float* w, float* out, double* stats, GnRef in_gn,
+                       int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
+                       hipStream_t stream) {
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgs a{};
-  a.in = in; a.w = w; a.out = out; a.stats = stats; a.in_sc = in_sc; a.in_sh = in_sh;
+  a.in = in; a.w = w; a.out = out; a.stats = stats; a.in_gn = in_gn;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.KH = a.KW = ksz; a.stride = stride;
   // XLA SAME padding: total = max((ceil(n/s)-1)*s + k - n, 0), lo = total/2
-  const int total = std::max((Ho - 1) * stride + ksz - Hi, 0);
-  a.pad = total / 2;
+  a.pad = std::max((Ho - 1) * stride + ksz - Hi, 0) / 2;
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
-  const bool wide = Cout >= 128;
-  const int BM = 128, BN = wide ? 128 : 64;   // wide: 2x2 waves of 64x64; narrow: 4x1 waves of 32x64
+  // tile choice: 128x128 (2x2 waves of 64x64) for wide layers, 128x64 (4x1 waves of 32x64) for Cout == 64,
+  // 64x64 (2x2 waves of 32x32) when the big tile would leave most of the 256 CUs idle (small batches,
+  // i.e. one rank's share of a data-parallel job).
+  int cfg = Cout >= 128 ? 0 : 1;
+  if (cfg == 0 && (long)cd(a.M, 128) * (Cout / 128) < 512) cfg = 2;
+  const int BM = cfg == 2 ? 64 : 128, BN = cfg == 0 ? 128 : 64;
+  const int wrows = cfg == 0 ? 64 : 32;
   a.tiles_m = cd(a.M, BM); a.tiles_n = Cout / BN;
-  const size_t lds = (size_t)(2 * BM * 33 + 2 * 32 * (BN + 4)) * 4;
-  const int wrows = wide ? 64 : 32;
-  const int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
+  const size_t lds = (size_t)(2 * BM * 33 + 2 * 32 * (BN + 4) + 2 * (BM + 1) * 4) * 4;
+  int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
+  if (cfg != 0 && pmode == 1) pmode = 3;
+  const bool one_img = (a.P % BM) == 0;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
   {
-  ProfScope prof(tag, stream);
-  const bool one_img = (a.P % BM) == 0;
-#define SERL_LAUNCH_CONV(WM, WN, TM, PM)                                                                 \
-  do {                                                                                                   \
-    if (one_img) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, PM, true>), grid, block, lds, stream, a);  \
-    else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, PM, false>), grid, block, lds, stream, a);         \
+    ProfScope prof(tag, stream);
+#define SERL_LAUNCH_CONV2(WM, WN, TM, TN, PM)                                                                      \
+  do {                                                                                                             \
+    if (one_img) hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, PM, true>), grid, block, lds, stream, a);   \
+    else hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, TM, TN, PM, false>), grid, block, lds, stream, a);          \
   } while (0)
-  if (wide) {
-    if (pmode == 0) SERL_LAUNCH_CONV(2, 2, 2, 0);
-    else if (pmode == 1) SERL_LAUNCH_CONV(2, 2, 2, 1);
-    else if (pmode == 2) SERL_LAUNCH_CONV(2, 2, 2, 2);
-    else SERL_LAUNCH_CONV(2, 2, 2, 3);
-  } else {
-    if (pmode == 0) SERL_LAUNCH_CONV(4, 1, 1, 0);
-    else if (pmode == 2) SERL_LAUNCH_CONV(4, 1, 1, 2);
-    else SERL_LAUNCH_CONV(4, 1, 1, 3);
-  }
+#define SERL_LAUNCH_CONV(WM, WN, TM, TN)                       \
+  do {                                                         \
+    if (pmode == 0) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 0);      \
+    else if (pmode == 1) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 1); \
+    else if (pmode == 2) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 2); \
+    else SERL_LAUNCH_CONV2(WM, WN, TM, TN, 3);                 \
+  } while (0)
+    if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
+    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 1, 2);
+    else SERL_LAUNCH_CONV(2, 2, 1, 1);
 #undef SERL_LAUNCH_CONV
+#undef SERL_LAUNCH_CONV2
   }
   SERL_HIP(hipGetLastError());
-  if (pmode == 3 || (!wide && pmode == 1)) {  // statistics in a separate pass
+  if (pmode == 3) {  // statistics in a separate pass
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
     SERL_HIP(hipGetLastError());
   }
-  return SERL_OK;
-}
-
-static int launch_coef(const double* stats, const float* gamma, const float* beta, float* sc, float* sh,
-                       int N, int Cc, int P, hipStream_t stream) {
-  const double inv = 1.0 / ((double)P * (Cc / kGnGroups));
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(cd(N * Cc, 256)), dim3(256), 0, stream, stats, gamma, beta, sc, sh,
-                     N, Cc, inv, 1e-5f);
-  SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
 
@@ -575,8 +605,6 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
   const TrunkDims& d = ws.d;
   const int N = n;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
-  auto sc_of = [&](int layer) { return ws.coef + (size_t)layer * 2 * ws.max_images * 512; };
-  auto sh_of = [&](int layer) { return sc_of(layer) + (size_t)ws.max_images * 512; };
   SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kGnLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
   int rc;
   {  // conv_init
@@ -589,16 +617,17 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
     hipLaunchKernelGGL(conv_init_kernel, dim3(N * a.tiles_y * a.tiles_x), dim3(256), lds, stream, a);
     SERL_HIP(hipGetLastError());
   }
-  if ((rc = launch_coef(stats_of(0), w.gn_init_s, w.gn_init_b, sc_of(0), sh_of(0), N, 64, d.h[0] * d.w[0], stream))) return rc;
   {
     const long tot = (long)N * d.h[1] * d.w[1] * 16;
     ProfScope prof("gn_relu_maxpool", stream);
-    hipLaunchKernelGGL(gn_relu_maxpool_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.raw_init, sc_of(0),
-                       sh_of(0), ws.pool, N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
+    hipLaunchKernelGGL(gn_relu_maxpool_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.raw_init,
+                       gn_ref(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64), ws.pool, N, d.h[0],
+                       d.w[0], d.h[1], d.w[1], 64);
     SERL_HIP(hipGetLastError());
   }
   const float* x = ws.pool;
   int cin = 64;
+  const GnRef none{};
   for (int i = 0; i < kTrunkStages; ++i) {
     const int f = kStageFilters[i], s = kStageStride[i];
     const int Hi = d.h[1 + i], Wi = d.w[1 + i], Ho = d.h[2 + i], Wo = d.w[2 + i], P = Ho * Wo;
@@ -609,20 +638,17 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
                                                   {"conv_igemm/b1_conv0", "conv_igemm/b1_conv1", "conv_igemm/b1_proj"},
                                                   {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
                                                   {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
-    if ((rc = launch_conv(kTags[i][0], x, bw.conv0, ws.blk[i].raw0, stats_of(l0), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    if ((rc = launch_conv(kTags[i][0], x, bw.conv0, ws.blk[i].raw0, stats_of(l0), none, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
     if (has_proj)
-      if ((rc = launch_conv(kTags[i][2], x, bw.proj, ws.blk[i].rawp, stats_of(lp), nullptr, nullptr, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
-    if ((rc = launch_coef(stats_of(l0), bw.gn0_s, bw.gn0_b, sc_of(l0), sh_of(l0), N, f, P, stream))) return rc;
-    if ((rc = launch_conv(kTags[i][1], ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1), sc_of(l0), sh_of(l0), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
-    if ((rc = launch_coef(stats_of(l1), bw.gn1_s, bw.gn1_b, sc_of(l1), sh_of(l1), N, f, P, stream))) return rc;
-    if (has_proj)
-      if ((rc = launch_coef(stats_of(lp), bw.gnp_s, bw.gnp_b, sc_of(lp), sh_of(lp), N, f, P, stream))) return rc;
+      if ((rc = launch_conv(kTags[i][2], x, bw.proj, ws.blk[i].rawp, stats_of(lp), none, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
+    if ((rc = launch_conv(kTags[i][1], ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1),
+                          gn_ref(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
     float* out = (i == kTrunkStages - 1) ? feats_out : ws.blk[i].out;
     const long tot = (long)N * P * (f / 4);
     ProfScope prof("block_out", stream);
-    hipLaunchKernelGGL(block_out_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1, sc_of(l1),
-                       sh_of(l1), has_proj ? ws.blk[i].rawp : x, has_proj ? sc_of(lp) : nullptr,
-                       has_proj ? sh_of(lp) : nullptr, out, N, P, f);
+    hipLaunchKernelGGL(block_out_kernel, dim3(cd(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,
+                       gn_ref(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f), has_proj ? ws.blk[i].rawp : x,
+                       has_proj ? gn_ref(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f) : none, out, N, P, f);
     SERL_HIP(hipGetLastError());
     x = out;
     cin = f;
