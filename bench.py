@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--fill", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
@@ -110,15 +112,17 @@ def main():
     agent = make_drq_agent(42, sample_obs, np.zeros((A,), np.float32), image_keys=KEYS,
                            encoder_type="resnet-pretrained", batch_size=Bl, device=local_rank)
     core = agent.core
-    db = DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank)
+    dbs = [DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank) for _ in range(2)]
 
-    def gather(parts, co, cn):                           # fused K2+K3+K4 into the local device batch
-        gather_crop(parts, co, cn, db)
-        return db
+    def gather(parts, co, cn, slot):                     # fused K2+K3+K4 into the slot's device batch
+        gather_crop(parts, co, cn, dbs[slot])
+        return dbs[slot]
 
-    from serl_amd.parallel import DataParallelLearner
+    from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
+    sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank))
     learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world,
-                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else (lambda t: None), seed=7)
+                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else (lambda t: None),
+                                  seed=7, schedule=sched)
 
     def iteration():
         learner.iteration(args.car)
@@ -190,7 +194,8 @@ def main():
                    "per_gpu_batch": Bl, "cameras": len(KEYS), "image": [H, W, 3], "state_dim": S, "act_dim": A,
                    "critic_actor_ratio": args.car, "utd_ratio": 1, "replay_capacity": args.capacity,
                    "replay_fill": args.fill, "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": args.car,
-                   "trunk_passes_per_grad_step": 2},
+                   "trunk_passes_per_grad_step": 2,
+                   "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
         "roofline": roofline,
         "last_info": {k: round(float(v), 6) for k, v in info.items()},
         "setup": {"replay_fill_s": round(fill_s, 2)},

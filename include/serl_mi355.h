@@ -196,6 +196,12 @@ int serl_agent_read_info(serl_agent* a, serl_info* host_out, void* stream);
  * [r*B/P,(r+1)*B/P) of the global batch; the caller all-reduces (SUM) the gradient view between
  * *_grads and apply.  global_count = samples of this (mini)batch over all ranks (loss normaliser). */
 int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream); /* frozen trunk, both passes */
+/* Software pipelining: the frozen trunk does not depend on the trainable parameters, so the trunk
+ * pass of batch i+1 (slot (i+1)&1, on a second stream) may overlap the update of batch i.  The
+ * caller orders the streams with events; serl_agent_select_slot picks the batch the following
+ * *_grads calls consume.  serl_agent_encode == encode_slot(0) + select_slot(0). */
+int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, void* stream);
+int serl_agent_select_slot(serl_agent* a, int slot);
 int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
                             const serl_noise* noise, int redq_row, void* stream);
 int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* noise, void* stream);

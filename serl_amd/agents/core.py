@@ -117,6 +117,12 @@ class AgentCore:
     def encode(self, batch):
         _lib.check(self.L.serl_agent_encode(self._h, C.byref(batch.cstruct), self._stream()))
 
+    def encode_slot(self, batch, slot):
+        _lib.check(self.L.serl_agent_encode_slot(self._h, C.byref(batch.cstruct), slot, self._stream()))
+
+    def select_slot(self, slot):
+        _lib.check(self.L.serl_agent_select_slot(self._h, slot))
+
     def critic_grads(self, offset, count, global_count, noise=None, redq_row=0):
         _lib.check(self.L.serl_agent_critic_grads(self._h, offset, count, global_count, self._noise(noise),
                                                   redq_row, self._stream()))

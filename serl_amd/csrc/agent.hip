@@ -83,7 +83,10 @@ struct serl_agent {
   float* aux = nullptr;       // [X_N]
   TrunkWeights tw{};
   TrunkWorkspace tws{};
-  float* feats = nullptr;  // [2][n_cam][B][HW][512]
+  float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
+  float* feats_slot[3] = {nullptr, nullptr, nullptr};  // 0/1: pipelined update batches, 2: sample_actions
+  serl_batch cur_slot[2]{};
+  bool slot_valid[2] = {false, false};
   EncBuf encP{}, encT{}, encO{};
   CritBuf critT{}, crit{};
   PolBuf pol{};
@@ -248,7 +251,8 @@ size_t carve(serl_agent* a, void* base) {
   a->info_acc = b.take<float>(I_N);
   a->aux = b.take<float>(X_N);
   const size_t persistent = b.off;  // zero-initialised region ends here
-  a->feats = b.take<float>(2L * c.n_cam * B * a->HW * 512);
+  for (int k = 0; k < 3; ++k) a->feats_slot[k] = b.take<float>((k < 2 ? 2L : 1L) * c.n_cam * B * a->HW * 512);
+  a->feats = a->feats_slot[0];
   auto enc = [&](EncBuf& e) {
     e.f = b.take<float>((long)c.n_cam * B * a->D);
     e.xhat = b.take<float>((long)c.n_cam * B * c.bottleneck);
@@ -681,25 +685,41 @@ static int check_batch(serl_agent* a, const serl_batch* b) {
   return SERL_OK;
 }
 
-int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream) {
+int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, void* stream) {
   SERL_REQUIRE(a, "NULL agent");
+  SERL_REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
   int rc = check_batch(a, batch);
   if (rc) return rc;
   SERL_HIP(hipSetDevice(a->cfg.device));
   hipStream_t st = (hipStream_t)stream;
-  a->cur = *batch;
-  a->has_batch = true;
+  a->cur_slot[slot] = *batch;
+  a->slot_valid[slot] = true;
+  float* feats = a->feats_slot[slot];
   const serl_agent_cfg& c = a->cfg;
   const int B = batch->batch;
   const size_t fbytes = (size_t)c.H * c.W * 3;
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
-    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, a->feats, st);
+    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st);
   }
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < c.n_cam; ++k)
       RC(trunk_forward(a->tw, a->tws, batch->frames + ((size_t)(w * c.n_cam + k) * B) * fbytes, B,
-                       a->feats + (((long)w * c.n_cam + k) * c.batch) * a->HW * 512, st));
+                       feats + (((long)w * c.n_cam + k) * c.batch) * a->HW * 512, st));
   return SERL_OK;
+}
+
+int serl_agent_select_slot(serl_agent* a, int slot) {
+  SERL_REQUIRE(a, "NULL agent");
+  SERL_REQUIRE((slot == 0 || slot == 1) && a->slot_valid[slot], "slot %d holds no encoded batch", slot);
+  a->feats = a->feats_slot[slot];
+  a->cur = a->cur_slot[slot];
+  a->has_batch = true;
+  return SERL_OK;
+}
+
+int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream) {
+  RC(serl_agent_encode_slot(a, batch, 0, stream));
+  return serl_agent_select_slot(a, 0);
 }
 
 int serl_agent_begin_update(serl_agent* a, void* stream) {
@@ -892,9 +912,11 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   // trunk on [n_cam][n] images -> feats slot 0; state goes through a temporary serl_batch view
   const size_t fbytes = (size_t)c.H * c.W * 3;
   for (int k = 0; k < c.n_cam; ++k)
-    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats + ((long)k * c.batch) * a->HW * 512, st));
+    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[2] + ((long)k * c.batch) * a->HW * 512, st));
   serl_batch saved = a->cur;
   const bool had = a->has_batch;
+  float* saved_feats = a->feats;
+  a->feats = a->feats_slot[2];
   a->cur = serl_batch{};
   a->cur.batch = n;
   a->cur.state = const_cast<float*>(dev_state);
@@ -906,6 +928,7 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, n, dev_eps, dev_out_actions, c.act_dim, nullptr, st));
   a->cur = saved;
   a->has_batch = had;
+  a->feats = saved_feats;
   return SERL_OK;
 }
 

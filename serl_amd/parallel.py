@@ -1,6 +1,6 @@
-"""Batch-sharded data parallelism for the learner: one process per GPU, gradients all-reduced over
-RCCL/xGMI (torch.distributed backend "nccl").  This makes the reference's dormant
-`jax.lax.pmean(grads_and_aux, pmap_axis)` (serl_launcher/common/common.py:213-214) real.
+"""Batch-sharded data parallelism + software pipelining for the learner: one process per GPU,
+gradients all-reduced over RCCL/xGMI (torch.distributed backend "nccl").  This makes the reference's
+dormant `jax.lax.pmean(grads_and_aux, pmap_axis)` (serl_launcher/common/common.py:213-214) real.
 
 Sharding contract (DESIGN.md "multi-GPU"):
   * every rank holds a full replica of the replay buffer(s) with the same contents and the same
@@ -9,12 +9,18 @@ Sharding contract (DESIGN.md "multi-GPU"):
   * losses are normalised by the GLOBAL batch, so all-reduce(SUM) of [gradients | loss scalars]
     equals the single-device gradient; every rank then applies the identical Adam/EMA update
     (no parameter broadcast needed).
+
+Pipelining: the frozen trunk depends only on the batch's pixels, never on the trainable parameters,
+so batch i+1 is sampled, gathered, augmented and pushed through the trunk on a second stream while
+the heads / backward / optimizer of batch i run on the main stream (the reference's iterator also
+samples two batches ahead, data/replay_buffer.py:77-90).  Results are identical to the serial order.
+
 The class only touches its collaborators through small duck-typed interfaces, so the sharding and
 collective plumbing is testable on CPU with the gloo backend (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 
@@ -37,12 +43,64 @@ def shard_parts(parts: Sequence[Tuple[object, np.ndarray]], rank: int, world: in
     return out, (lo, hi)
 
 
+class SerialSchedule:
+    """No overlap: everything on the caller's stream."""
+    slots = 1
+
+    def side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def produced(self, slot):
+        pass
+
+    def wait_produced(self, slot):
+        pass
+
+    def consumed(self, slot):
+        pass
+
+    def wait_consumed(self, slot):
+        pass
+
+
+class TorchPipelineSchedule:
+    """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream."""
+    slots = 2
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = device
+        self.side_stream = torch.cuda.Stream(device=device)
+        self.ev_prod = [torch.cuda.Event() for _ in range(2)]
+        self.ev_cons = [None, None]
+
+    def side(self):
+        return self.torch.cuda.stream(self.side_stream)
+
+    def produced(self, slot):
+        self.ev_prod[slot].record(self.side_stream)
+
+    def wait_produced(self, slot):
+        self.torch.cuda.current_stream(self.device).wait_event(self.ev_prod[slot])
+
+    def consumed(self, slot):
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        self.ev_cons[slot] = ev
+
+    def wait_consumed(self, slot):
+        if self.ev_cons[slot] is not None:
+            self.side_stream.wait_event(self.ev_cons[slot])
+
+
 class DataParallelLearner:
-    """core: object with begin_update/encode/critic_grads/actor_grads/apply/grad_view (AgentCore);
-    gather: callable(parts, crop_obs, crop_next) -> device batch for `core.encode`."""
+    """core: object with begin_update/encode_slot/select_slot/critic_grads/actor_grads/apply/grad_view
+    (AgentCore); gather: callable(parts, crop_obs, crop_next, slot) -> device batch for that slot."""
 
     def __init__(self, core, gather, buffers: List[object], batch_sizes: List[int], rank: int = 0,
-                 world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10):
+                 world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10, schedule=None):
         self.core, self.gather, self.buffers, self.batch_sizes = core, gather, buffers, batch_sizes
         self.rank, self.world = rank, world
         self.B = sum(batch_sizes)
@@ -50,10 +108,13 @@ class DataParallelLearner:
         self.Bl = self.B // world
         self.all_reduce = all_reduce
         self.ensemble = ensemble
+        self.sched = schedule or SerialSchedule()
         # host noise shared by all ranks (same seed): crop offsets and REDQ subsample indices
         self._crop_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 1])))
         self._redq_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 2])))
         self._gv = {}
+        self._pending = None   # slot of the prefetched (sampled + gathered + encoded) batch
+        self._next_slot = 0
 
     def _view(self, which):
         if which not in self._gv:
@@ -64,31 +125,52 @@ class DataParallelLearner:
         if self.world > 1:
             self.all_reduce(self._view(which))
 
-    def fetch(self):
-        """One global batch: identical index/crop streams on all ranks, local slice materialised."""
+    def _produce(self):
+        """Sample one global batch (identical index/crop streams on all ranks), materialise this rank's
+        slice and run the frozen trunk on it -- on the side stream when pipelining."""
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self.sched.slots
         parts = [(b, b.sample_indices(n)) for b, n in zip(self.buffers, self.batch_sizes)]
         co = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
         cn = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
         local, (lo, hi) = shard_parts(parts, self.rank, self.world)
-        return self.gather(local, co[lo:hi], cn[lo:hi])
+        self.sched.wait_consumed(slot)
+        with self.sched.side():
+            db = self.gather(local, co[lo:hi], cn[lo:hi], slot)
+            self.core.encode_slot(db, slot)
+        self.sched.produced(slot)
+        return slot
 
-    def update_critics(self, batch=None):
-        """DrQAgent.update_critics over the global batch (one grad-step)."""
-        db = self.fetch() if batch is None else batch
+    def _acquire(self):
+        slot = self._pending if self._pending is not None else self._produce()
+        self._pending = None
+        if self.sched.slots > 1:
+            self._pending = self._produce()      # batch i+1 overlaps the update of batch i
+        self.sched.wait_produced(slot)
+        self.core.select_slot(slot)
+        return slot
+
+    def _critic(self):
         noise = {"redq_idx": self._redq_rng.integers(0, self.ensemble, size=(1, 2)).astype(np.int32)}
         self.core.begin_update()
-        self.core.encode(db)
         self.core.critic_grads(0, self.Bl, self.B, noise)
         self._reduce(APPLY_CRITIC)
         self.core.apply(APPLY_CRITIC)
-        return db
 
-    def update_high_utd(self, batch=None):
+    def update_critics(self):
+        """DrQAgent.update_critics over the global batch (one grad-step)."""
+        slot = self._acquire()
+        self._critic()
+        self.sched.consumed(slot)
+
+    def update_high_utd(self):
         """DrQAgent.update_high_utd(utd_ratio=1): critic step, then actor+temperature on the same batch."""
-        self.update_critics(batch)
+        slot = self._acquire()
+        self._critic()
         self.core.actor_grads(self.B, None)
         self._reduce(APPLY_ACTOR_TEMP)
         self.core.apply(APPLY_ACTOR_TEMP)
+        self.sched.consumed(slot)
 
     def iteration(self, critic_actor_ratio: int = 1):
         """One learner-loop iteration (examples/async_drq_sim/async_drq_sim.py:266-292)."""

@@ -29,7 +29,7 @@ class FakeCore:
         self.g = {APPLY_CRITIC: torch.zeros(dim + 3, dtype=torch.float64),
                   APPLY_ACTOR_TEMP: torch.zeros(3 + dim, dtype=torch.float64)}
         self.params = torch.zeros(dim, dtype=torch.float64)
-        self.dim, self.batch, self.log = dim, None, []
+        self.dim, self.batch, self.log, self.slots = dim, None, [], {}
 
     @staticmethod
     def phi(ids, dim):
@@ -38,8 +38,11 @@ class FakeCore:
     def begin_update(self):
         pass
 
-    def encode(self, batch):
-        self.batch = batch
+    def encode_slot(self, batch, slot):
+        self.slots[slot] = batch
+
+    def select_slot(self, slot):
+        self.batch = self.slots[slot]
 
     def critic_grads(self, off, cnt, global_count, noise, redq_row=0):
         ids = self.batch["ids"][off:off + cnt].astype(np.float64)
@@ -60,14 +63,14 @@ class FakeCore:
         return self.g[which]
 
 
-def _gather(parts, co, cn):
+def _gather(parts, co, cn, slot=0):
     ids = np.concatenate([ix + 1000 * k for k, (b, ix) in enumerate(parts)]) if parts else np.zeros(0)
     assert len(co) == len(ids) == len(cn)
     return {"ids": ids, "co": co, "cn": cn}
 
 
 def _tagged_gather(bufs):
-    def g(parts, co, cn):
+    def g(parts, co, cn, slot=0):
         ids = np.concatenate([ix + 1000 * bufs.index(b) for b, ix in parts])
         return {"ids": ids, "co": co, "cn": cn}
     return g
