@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--fill", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--trunk", choices=["f16x3", "f32"], default="f16x3",
+                    help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -112,6 +114,7 @@ def main():
     agent = make_drq_agent(42, sample_obs, np.zeros((A,), np.float32), image_keys=KEYS,
                            encoder_type="resnet-pretrained", batch_size=Bl, device=local_rank)
     core = agent.core
+    core.set_trunk_mode(args.trunk)
     dbs = [DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank) for _ in range(2)]
 
     def gather(parts, co, cn, slot):                     # fused K2+K3+K4 into the slot's device batch

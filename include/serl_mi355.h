@@ -159,6 +159,10 @@ int serl_agent_leaf_info(serl_agent* a, int i, char* name_out, int name_cap, int
 int serl_agent_set(serl_agent* a, const char* section, const char* leaf, const float* host, int64_t count);
 int serl_agent_get(serl_agent* a, const char* section, const char* leaf, float* host_out, int64_t count);
 int serl_agent_set_step(serl_agent* a, int64_t step); /* JaxRLTrainState.step and the Adam counts */
+/* Arithmetic of the frozen trunk's 3x3/1x1 convs: 0 = exact fp32 MFMA, 1 (default) = split-fp16
+ * ("f16x3": x = hi + 2^-11 lo', three fp16 MFMA products per fp32 product, fp32 accumulate; error per
+ * product <= ~3*2^-22, i.e. fp32-roundoff class -- DESIGN.md section 4; parity tests run both modes). */
+int serl_agent_set_trunk_mode(serl_agent* a, int mode);
 int64_t serl_agent_get_step(serl_agent* a);
 
 /* Explicit randomness (parity mode).  All pointers are DEVICE addresses; NULL members (or a NULL

@@ -58,6 +58,10 @@ class AgentCore:
         _lib.check(self.L.serl_agent_get(self._h, section.encode(), leaf.encode(), out.ctypes.data, out.size))
         return out
 
+    def set_trunk_mode(self, mode: str):
+        """'f32' = exact fp32 MFMA convs, 'f16x3' = split-fp16 convs (default)."""
+        _lib.check(self.L.serl_agent_set_trunk_mode(self._h, {"f32": 0, "f16x3": 1}[mode]))
+
     def load_flat(self, section: str, tree: Dict[str, np.ndarray]):
         for k, v in tree.items():
             self.set(section, k, v)

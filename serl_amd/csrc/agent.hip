@@ -83,6 +83,8 @@ struct serl_agent {
   float* aux = nullptr;       // [X_N]
   TrunkWeights tw{};
   TrunkWorkspace tws{};
+  TrunkPacked tpk{};
+  int trunk_mode = 1;  // 0: exact fp32 MFMA convs, 1: split-fp16 (f16x3) convs for the blocks
   float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
   float* feats_slot[3] = {nullptr, nullptr, nullptr};  // 0/1: pipelined update batches, 2: sample_actions
   serl_batch cur_slot[2]{};
@@ -299,6 +301,8 @@ size_t carve(serl_agent* a, void* base) {
   const int nimg = 2 * c.n_cam * c.batch;
   void* tmem = b.take<uint8_t>(trunk_workspace_bytes(nimg, c.H, c.W));
   if (base) trunk_workspace_bind(a->tws, tmem, nimg, c.H, c.W);
+  void* pmem = b.take<uint8_t>(trunk_packed_bytes());
+  if (base) trunk_packed_bind(a->tpk, pmem);
   (void)persistent;
   return b.off;
 }
@@ -647,6 +651,7 @@ int serl_agent_set(serl_agent* a, const char* section, const char* leaf, const f
     return SERL_OK;
   }
   SERL_HIP(hipMemcpy(p, host, sizeof(float) * n, hipMemcpyHostToDevice));
+  if (std::strncmp(leaf, "trunk/", 6) == 0) a->tpk.dirty = true;
   return SERL_OK;
 }
 
@@ -663,6 +668,12 @@ int serl_agent_get(serl_agent* a, const char* section, const char* leaf, float* 
   return SERL_OK;
 }
 
+int serl_agent_set_trunk_mode(serl_agent* a, int mode) {
+  SERL_REQUIRE(a && (mode == 0 || mode == 1), "trunk mode must be 0 (fp32) or 1 (f16x3)");
+  a->trunk_mode = mode;
+  return SERL_OK;
+}
+
 int serl_agent_set_step(serl_agent* a, int64_t step) {
   SERL_REQUIRE(a && step >= 0, "bad argument");
   a->step = step;
@@ -673,7 +684,7 @@ int64_t serl_agent_get_step(serl_agent* a) { return a ? a->step : -1; }
 int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream) {
   SERL_REQUIRE(a && dev_frames && dev_feats_out, "NULL argument");
   SERL_HIP(hipSetDevice(a->cfg.device));
-  return trunk_forward(a->tw, a->tws, dev_frames, n, dev_feats_out, (hipStream_t)stream);
+  return trunk_forward(a->tw, a->tws, dev_frames, n, dev_feats_out, (hipStream_t)stream, a->trunk_mode ? &a->tpk : nullptr);
 }
 
 static int check_batch(serl_agent* a, const serl_batch* b) {
@@ -699,12 +710,12 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
   const int B = batch->batch;
   const size_t fbytes = (size_t)c.H * c.W * 3;
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
-    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st);
+    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr);
   }
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < c.n_cam; ++k)
       RC(trunk_forward(a->tw, a->tws, batch->frames + ((size_t)(w * c.n_cam + k) * B) * fbytes, B,
-                       feats + (((long)w * c.n_cam + k) * c.batch) * a->HW * 512, st));
+                       feats + (((long)w * c.n_cam + k) * c.batch) * a->HW * 512, st, a->trunk_mode ? &a->tpk : nullptr));
   return SERL_OK;
 }
 
@@ -912,7 +923,7 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   // trunk on [n_cam][n] images -> feats slot 0; state goes through a temporary serl_batch view
   const size_t fbytes = (size_t)c.H * c.W * 3;
   for (int k = 0; k < c.n_cam; ++k)
-    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[2] + ((long)k * c.batch) * a->HW * 512, st));
+    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[2] + ((long)k * c.batch) * a->HW * 512, st, a->trunk_mode ? &a->tpk : nullptr));
   serl_batch saved = a->cur;
   const bool had = a->has_batch;
   float* saved_feats = a->feats;

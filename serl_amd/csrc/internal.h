@@ -41,9 +41,17 @@ struct TrunkWorkspace {
 size_t trunk_workspace_bytes(int max_images, int H, int W);
 // carve `ws` out of caller-provided device memory (at least trunk_workspace_bytes big)
 int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, int W);
-// frames: u8 [n][H][W][3] (device) -> feats: f32 [n][h5][w5][512] (device)
+// split-fp16 copies of the 3x3 / 1x1 conv kernels (trunk_f16x3.hip): fp16 [Cout][K] hi and scaled-lo planes
+struct TrunkPacked {
+  struct W { uint16_t *hi, *lo; } blk[kTrunkStages][3]{};  // [stage][conv0, conv1, proj]
+  bool dirty = true;
+};
+size_t trunk_packed_bytes();
+int trunk_packed_bind(TrunkPacked& p, void* mem);
+// frames: u8 [n][H][W][3] (device) -> feats: f32 [n][h5][w5][512] (device).
+// packed == nullptr: exact fp32 MFMA convs; otherwise the split-fp16 (f16x3) convs for the blocks.
 int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n,
-                  float* feats_out, hipStream_t stream);
+                  float* feats_out, hipStream_t stream, TrunkPacked* packed = nullptr);
 
 // --------------------------------------------------------------------------------------------
 // small dense building blocks (heads.hip)

@@ -17,38 +17,9 @@
 
 #include "internal.h"
 #include "prof.h"
+#include "trunk_common.h"
 
 namespace serl {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// ---------------------------------------------------------------------------------------------
-// XCD-aware bijective workgroup remap (8 XCDs, block b is dispatched to XCD b % 8): gives every
-// XCD a contiguous range of tile ids so tiles that share A rows / weights hit the same L2.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
-// GroupNorm statistics: 64-lane reduction of per-lane partial (sum, sumsq) in 16-lane channel
-// segments (+ the two row halves), then one fp64 atomic per 16-channel segment.
-__device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /* [G][2] of image */,
-                                            int chan, int gsize, bool valid) {
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) {
-    s += __shfl_xor(s, off);
-    q += __shfl_xor(q, off);
-  }
-  s += __shfl_xor(s, 32);
-  q += __shfl_xor(q, 32);
-  const int lane = threadIdx.x & 63;
-  if (valid && (lane & 15) == 0 && lane < 32) {
-    const int g = chan / gsize;
-    atomicAdd(&stats_ng[2 * g], (double)s);
-    atomicAdd(&stats_ng[2 * g + 1], (double)q);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // conv_init: u8 image -> ImageNet normalise -> conv 7x7 stride 2 pad 3, 3 -> 64 (K = 147 -> 148)
@@ -152,32 +123,6 @@ __global__ __launch_bounds__(256) void conv_init_kernel(ConvInitArgs a) {
   for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + i, 16, true);
 }
 
-// ---------------------------------------------------------------------------------------------
-// GroupNorm applied by the CONSUMER: every kernel that reads a raw conv output derives the per
-// (image, channel) scale/shift on the fly from the producer's (sum, sumsq) statistics:
-//   y = x*sc + sh,  sc = gamma*rsqrt(var+eps),  sh = beta - mean*sc,  var = max(0, E[x^2]-E[x]^2)
-// (flax nn.GroupNorm fast variance, eps 1e-5; resnet_v1.py:119-126,237).  No coefficient table, no
-// extra launch between a conv and its consumer.
-// ---------------------------------------------------------------------------------------------
-struct GnRef {
-  const double* stats;  // [N][4][2] (sum, sumsq) of the producing conv; nullptr = identity
-  const float* gamma;   // [C]
-  const float* beta;    // [C]
-  double inv_count;     // 1 / (P * C/4)
-  int gsize;            // channels per group
-};
-
-__device__ __forceinline__ void gn_coef4(const GnRef& g, int n, int c, float4& sc, float4& sh) {
-  const double* st = g.stats + ((size_t)n * kGnGroups + c / g.gsize) * 2;
-  const double mean = st[0] * g.inv_count, m2 = st[1] * g.inv_count;
-  const float var = fmaxf((float)(m2 - mean * mean), 0.f);
-  const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
-  const float4 ga = *reinterpret_cast<const float4*>(g.gamma + c);
-  const float4 be = *reinterpret_cast<const float4*>(g.beta + c);
-  sc = make_float4(ga.x * rstd, ga.y * rstd, ga.z * rstd, ga.w * rstd);
-  sh = make_float4(be.x - mf * sc.x, be.y - mf * sc.y, be.z - mf * sc.z, be.w - mf * sc.w);
-}
-
 // fallback GroupNorm statistics pass (used when the conv epilogue cannot attribute its rows to
 // images, i.e. Ho*Wo is neither a multiple of 64 nor 16/32): one workgroup per (image, group).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, double* stats, int P, int Cc) {
@@ -271,15 +216,6 @@ __global__ __launch_bounds__(256) void block_out_kernel(const float* raw, GnRef 
 // ---------------------------------------------------------------------------------------------
 // generic implicit-GEMM conv (3x3 / 1x1, Cin % 32 == 0, Cout % (64*WN) == 0)
 // ---------------------------------------------------------------------------------------------
-struct ConvArgs {
-  const float* in;     // [N][Hi][Wi][Cin]
-  const float* w;      // [KH*KW*Cin][Cout]
-  float* out;          // [N][Ho][Wo][Cout]
-  double* stats;       // [N][4][2] or nullptr
-  GnRef in_gn;         // GroupNorm+ReLU of the producing layer applied on load (stats == nullptr: none)
-  int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, padw;
-  int M, P, tiles_m, tiles_n;
-};
 
 // PMODE: how output rows map to images for the GN statistics
 //   0: P % (32*TM) == 0 (a wave's rows lie in one image)   1: P == 32   2: P == 16   3: no stats
@@ -599,8 +535,60 @@ static int launch_conv(const char* tag, const float* in, const float* w, float* 
   return SERL_OK;
 }
 
+static void conv_dims(int i, int which, int& K, int& Cout) {
+  const int cin = i == 0 ? 64 : kStageFilters[i - 1], f = kStageFilters[i];
+  Cout = f;
+  K = which == 0 ? 9 * cin : (which == 1 ? 9 * f : cin);
+}
+
+size_t trunk_packed_bytes() {
+  size_t off = 0;
+  for (int i = 0; i < kTrunkStages; ++i)
+    for (int k = 0; k < 3; ++k) {
+      if (k == 2 && i == 0) continue;
+      int K, Cout;
+      conv_dims(i, k, K, Cout);
+      off += 2 * al256((size_t)K * Cout * 2);
+    }
+  return off;
+}
+
+int trunk_packed_bind(TrunkPacked& p, void* mem) {
+  SERL_REQUIRE(mem != nullptr, "packed-weight memory is NULL");
+  uint8_t* b = (uint8_t*)mem;
+  size_t off = 0;
+  for (int i = 0; i < kTrunkStages; ++i)
+    for (int k = 0; k < 3; ++k) {
+      if (k == 2 && i == 0) continue;
+      int K, Cout;
+      conv_dims(i, k, K, Cout);
+      p.blk[i][k].hi = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
+      p.blk[i][k].lo = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
+    }
+  p.dirty = true;
+  return SERL_OK;
+}
+
+static int trunk_pack(const TrunkWeights& w, TrunkPacked& p, hipStream_t stream) {
+  for (int i = 0; i < kTrunkStages; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const float* src = k == 0 ? w.blk[i].conv0 : (k == 1 ? w.blk[i].conv1 : w.blk[i].proj);
+      if (!src) continue;
+      int K, Cout;
+      conv_dims(i, k, K, Cout);
+      int rc = pack_conv_weights_f16x3(src, p.blk[i][k].hi, p.blk[i][k].lo, K, Cout, stream);
+      if (rc) return rc;
+    }
+  p.dirty = false;
+  return SERL_OK;
+}
+
 int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n, float* feats_out,
-                  hipStream_t stream) {
+                  hipStream_t stream, TrunkPacked* packed) {
+  if (packed && packed->dirty) {
+    int prc = trunk_pack(w, *packed, stream);
+    if (prc) return prc;
+  }
   SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
   const TrunkDims& d = ws.d;
   const int N = n;
@@ -638,11 +626,19 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
                                                   {"conv_igemm/b1_conv0", "conv_igemm/b1_conv1", "conv_igemm/b1_proj"},
                                                   {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
                                                   {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
-    if ((rc = launch_conv(kTags[i][0], x, bw.conv0, ws.blk[i].raw0, stats_of(l0), none, N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    auto conv = [&](int which, const float* in, const float* wf, float* out, double* st, GnRef g, int hi, int wi,
+                    int ci, int ksz, int strd) -> int {
+      if (packed) {
+        PackedConvWeights pw{packed->blk[i][which].hi, packed->blk[i][which].lo};
+        return launch_conv_f16x3(kTags[i][which], in, pw, out, st, g, N, hi, wi, ci, Ho, Wo, f, ksz, strd, stream);
+      }
+      return launch_conv(kTags[i][which], in, wf, out, st, g, N, hi, wi, ci, Ho, Wo, f, ksz, strd, stream);
+    };
+    if ((rc = conv(0, x, bw.conv0, ws.blk[i].raw0, stats_of(l0), none, Hi, Wi, cin, 3, s))) return rc;
     if (has_proj)
-      if ((rc = launch_conv(kTags[i][2], x, bw.proj, ws.blk[i].rawp, stats_of(lp), none, N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
-    if ((rc = launch_conv(kTags[i][1], ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1),
-                          gn_ref(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
+      if ((rc = conv(2, x, bw.proj, ws.blk[i].rawp, stats_of(lp), none, Hi, Wi, cin, 1, s))) return rc;
+    if ((rc = conv(1, ws.blk[i].raw0, bw.conv1, ws.blk[i].raw1, stats_of(l1),
+                   gn_ref(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), Ho, Wo, f, 3, 1))) return rc;
     float* out = (i == kTrunkStages - 1) ? feats_out : ws.blk[i].out;
     const long tot = (long)N * P * (f / 4);
     ProfScope prof("block_out", stream);

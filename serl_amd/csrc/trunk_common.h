@@ -1,0 +1,85 @@
+// Device helpers shared by the trunk kernels (trunk.hip: exact fp32 MFMA; trunk_f16x3.hip: split-fp16 MFMA).
+#pragma once
+#include "internal.h"
+
+namespace serl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware bijective workgroup remap (8 XCDs, block b is dispatched to XCD b % 8): gives every
+// XCD a contiguous range of tile ids so tiles that share A rows / weights hit the same L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// GroupNorm statistics: 64-lane reduction of per-lane partial (sum, sumsq) in 16-lane channel
+// segments (+ the two row halves), then one fp64 atomic per 16-channel segment.
+__device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /* [G][2] of image */,
+                                            int chan, int gsize, bool valid) {
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  s += __shfl_xor(s, 32);
+  q += __shfl_xor(q, 32);
+  const int lane = threadIdx.x & 63;
+  if (valid && (lane & 15) == 0 && lane < 32) {
+    const int g = chan / gsize;
+    atomicAdd(&stats_ng[2 * g], (double)s);
+    atomicAdd(&stats_ng[2 * g + 1], (double)q);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm applied by the CONSUMER: every kernel that reads a raw conv output derives the per
+// (image, channel) scale/shift on the fly from the producer's (sum, sumsq) statistics:
+//   y = x*sc + sh,  sc = gamma*rsqrt(var+eps),  sh = beta - mean*sc,  var = max(0, E[x^2]-E[x]^2)
+// (flax nn.GroupNorm fast variance, eps 1e-5; resnet_v1.py:119-126,237).  No coefficient table, no
+// extra launch between a conv and its consumer.
+// ---------------------------------------------------------------------------------------------
+struct GnRef {
+  const double* stats;  // [N][4][2] (sum, sumsq) of the producing conv; nullptr = identity
+  const float* gamma;   // [C]
+  const float* beta;    // [C]
+  double inv_count;     // 1 / (P * C/4)
+  int gsize;            // channels per group
+};
+
+__device__ __forceinline__ void gn_coef4(const GnRef& g, int n, int c, float4& sc, float4& sh) {
+  const double* st = g.stats + ((size_t)n * kGnGroups + c / g.gsize) * 2;
+  const double mean = st[0] * g.inv_count, m2 = st[1] * g.inv_count;
+  const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+  const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
+  const float4 ga = *reinterpret_cast<const float4*>(g.gamma + c);
+  const float4 be = *reinterpret_cast<const float4*>(g.beta + c);
+  sc = make_float4(ga.x * rstd, ga.y * rstd, ga.z * rstd, ga.w * rstd);
+  sh = make_float4(be.x - mf * sc.x, be.y - mf * sc.y, be.z - mf * sc.z, be.w - mf * sc.w);
+}
+
+struct ConvArgs {
+  const float* in;     // [N][Hi][Wi][Cin]
+  const float* w;      // [KH*KW*Cin][Cout]
+  float* out;          // [N][Ho][Wo][Cout]
+  double* stats;       // [N][4][2] or nullptr
+  GnRef in_gn;         // GroupNorm+ReLU of the producing layer applied on load (stats == nullptr: none)
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, padw;
+  int M, P, tiles_m, tiles_n;
+};
+
+// host-side launch of the split-fp16 implicit-GEMM conv (trunk_f16x3.hip); same contract as the fp32 one
+struct PackedConvWeights {
+  const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous)
+  const uint16_t* lo;  // fp16 [Cout][K]  (w - float(hi)) * 2^11
+};
+int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, float* out, double* stats, GnRef in_gn,
+                       int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
+                       hipStream_t stream);
+// w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K]
+int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream);
+
+}  // namespace serl

@@ -1,0 +1,356 @@
+// Split-fp16 ("f16x3") implicit-GEMM conv for the frozen ResNet-10 trunk on MI355X (gfx950).
+//
+// fp32 operands are split on the fly into  x = hi + 2^-11 * lo'  with hi = fp16(x) and
+// lo' = fp16((x - hi) * 2^11)  (the residual is exact in fp32 and the 2^11 scale keeps it in fp16's
+// normal range), and every fp32 product is replaced by three fp16 MFMA products accumulated in fp32:
+//     a*b ~= a_hi*b_hi + 2^-11 * (a_hi*b_lo' + a_lo'*b_hi)       (the 2^-22 a_lo'*b_lo' term is dropped)
+// on v_mfma_f32_32x32x16_f16, whose dense rate is 16x the f32-input MFMA: 3 instructions of 32 cycles
+// per 32x32x16 block instead of 8 of 64.  The hi*hi products and the cross products go to separate
+// fp32 accumulators that are combined once in the epilogue.  Per-product relative error <= ~3*2^-22
+// (7e-7), i.e. fp32-roundoff class; measured error of the whole trunk vs fp64 in tests/test_agent_gpu.py
+// next to the exact-fp32 kernel's (every parity test runs in both modes).
+//
+// Same structure as conv_igemm_kernel (trunk.hip): NHWC activations stay fp32 in HBM, BK = 32 chunks
+// inside one (ky,kx) tap, GroupNorm+ReLU of the producer applied on load, GN statistics in the
+// epilogue.  Differences: weights are pre-split and pre-transposed once to fp16 [Cout][K] (hi, lo');
+// LDS holds fp16 hi/lo' planes with K contiguous (64-byte rows, 16-byte slots XOR-swizzled by
+// (row>>2)&3 -> conflict-free ds_read_b128 MFMA fragments).
+#include <algorithm>
+
+#include "prof.h"
+#include "trunk_common.h"
+
+namespace serl {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
+
+struct ConvArgsB {
+  ConvArgs c;           // .w unused
+  const uint16_t* whi;  // [Cout][K]
+  const uint16_t* wlo;
+  int K;
+};
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
+
+// float4 -> 4 fp16 hi (packed in uint2) and 4 fp16 lo' = fp16((x - hi) * 2^11)   (round-to-nearest-even)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  const _Float16 hx = (_Float16)clamp_h(v.x), hy = (_Float16)clamp_h(v.y);
+  const _Float16 hz = (_Float16)clamp_h(v.z), hw = (_Float16)clamp_h(v.w);
+  const _Float16 lx = (_Float16)((v.x - (float)hx) * kLoScale), ly = (_Float16)((v.y - (float)hy) * kLoScale);
+  const _Float16 lz = (_Float16)((v.z - (float)hz) * kLoScale), lw = (_Float16)((v.w - (float)hw) * kLoScale);
+  hi = make_uint2(pack_h2(hx, hy), pack_h2(hz, hw));
+  lo = make_uint2(pack_h2(lx, ly), pack_h2(lz, lw));
+}
+
+// byte offset of 16-byte slot `slot` (0..3) of row `row` in a [rows][32] bf16 plane (64-byte rows)
+__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int WM, int WN, int TM, int TN, int PMODE, bool ONE_IMG>
+__global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  const ConvArgs& a = ab.c;
+  constexpr int WROWS = 32 * TM, WCOLS = 32 * TN;
+  constexpr int BM = WROWS * WM, BN = WCOLS * WN;
+  constexpr int AI = BM / 32;   // float4 A loads per thread per chunk
+  constexpr int BI = BN / 32;   // 16-byte B loads per thread per chunk (hi and lo planes together: BN*4 slots*2 / 256)
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  float* gnm = reinterpret_cast<float*>(smemb + 2 * STAGE);
+  float* gnr = gnm + (BM + 1) * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int n_first = m0 / a.P;
+  if (a.in_gn.stats) {
+    const int n_last = min(a.N - 1, (m0 + BM - 1) / a.P);
+    for (int t = tid; t < (n_last - n_first + 1) * kGnGroups; t += 256) {
+      const double* st = a.in_gn.stats + ((size_t)n_first * kGnGroups + t) * 2;
+      const double mean = st[0] * a.in_gn.inv_count, m2 = st[1] * a.in_gn.inv_count;
+      gnm[t] = (float)mean;
+      gnr[t] = rsqrtf(fmaxf((float)(m2 - mean * mean), 0.f) + 1e-5f);
+    }
+    __syncthreads();
+  }
+  const int kq = tid & 7;
+  int rpix[AI], riy[AI], rix[AI], rn[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + (tid >> 3) + 32 * i;
+    if (m < a.M) {
+      const int n = m / a.P, rem = m - n * a.P;
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      rn[i] = n;
+      rpix[i] = n * a.Hi * a.Wi;
+      riy[i] = oy * a.stride - a.pad;
+      rix[i] = ox * a.stride - a.padw;
+    } else {
+      rn[i] = 0; rpix[i] = 0; riy[i] = -(1 << 20); rix[i] = -(1 << 20);
+    }
+  }
+  const int cpt = a.Cin >> 5;
+  const int nchunks = a.KH * a.KW * cpt;
+  // B loader: item j = tid + 256*i over [plane(hi,lo)][BN rows][4 slots]
+  constexpr int NS = ONE_IMG ? 1 : AI;
+  float4 ra[AI], rs[NS], rh[NS];
+  uint4 rb[BI];
+  unsigned okmask = 0;
+
+#define SERL_LOAD_CHUNK(CIDX)                                                                                  \
+  {                                                                                                            \
+    const int c_ = (CIDX);                                                                                     \
+    const int tap = c_ / cpt, ci0 = (c_ - tap * cpt) << 5;                                                     \
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;                                                           \
+    okmask = 0;                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
+      const int iy = riy[i] + ky, ix = rix[i] + kx;                                                            \
+      const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;                          \
+      okmask |= (ok ? 1u : 0u) << i;                                                                           \
+      const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);                                \
+      ra[i] = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + cy * a.Wi + cx) * a.Cin + ci0 + 4 * kq); \
+    }                                                                                                          \
+    if (a.in_gn.stats) {                                                                                       \
+      const int c4_ = ci0 + 4 * kq, grp_ = c4_ / a.in_gn.gsize;                                                \
+      const float4 ga_ = *reinterpret_cast<const float4*>(a.in_gn.gamma + c4_);                                \
+      const float4 be_ = *reinterpret_cast<const float4*>(a.in_gn.beta + c4_);                                 \
+      _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                                         \
+        const int t_ = max(rn[i] - n_first, 0) * kGnGroups + grp_;                                             \
+        const float mean_ = gnm[t_], rstd_ = gnr[t_];                                                          \
+        rs[i] = make_float4(ga_.x * rstd_, ga_.y * rstd_, ga_.z * rstd_, ga_.w * rstd_);                       \
+        rh[i] = make_float4(be_.x - mean_ * rs[i].x, be_.y - mean_ * rs[i].y, be_.z - mean_ * rs[i].z,         \
+                            be_.w - mean_ * rs[i].w);                                                          \
+      }                                                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
+      const int j_ = tid + 256 * i;                                                                            \
+      const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
+      const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (c_ << 5) + s_ * 8;       \
+      rb[i] = *reinterpret_cast<const uint4*>(wp_);                                                            \
+    }                                                                                                          \
+  }
+#define SERL_STORE_CHUNK(BUF)                                                                                  \
+  {                                                                                                            \
+    uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
+      float4 v = ra[i];                                                                                        \
+      if (a.in_gn.stats) {                                                                                     \
+        const float4 s_ = rs[ONE_IMG ? 0 : i];                                                                 \
+        const float4 h_ = rh[ONE_IMG ? 0 : i];                                                                 \
+        v.x = fmaxf(v.x * s_.x + h_.x, 0.f);                                                                   \
+        v.y = fmaxf(v.y * s_.y + h_.y, 0.f);                                                                   \
+        v.z = fmaxf(v.z * s_.z + h_.z, 0.f);                                                                   \
+        v.w = fmaxf(v.w * s_.w + h_.w, 0.f);                                                                   \
+      }                                                                                                        \
+      if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
+      uint2 hi_, lo_;                                                                                          \
+      split4(v, hi_, lo_);                                                                                     \
+      const int row_ = (tid >> 3) + 32 * i;                                                                    \
+      const int off_ = swz(row_, kq >> 1) + (kq & 1) * 8;                                                      \
+      *reinterpret_cast<uint2*>(st_ + off_) = hi_;                                                             \
+      *reinterpret_cast<uint2*>(st_ + A_PLANE + off_) = lo_;                                                   \
+    }                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
+      const int j_ = tid + 256 * i;                                                                            \
+      const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
+      *reinterpret_cast<uint4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = rb[i];                   \
+    }                                                                                                          \
+  }
+
+  f32x16 acc[TM][TN], accx[TM][TN];  // hi*hi products / cross products (scaled by 2^11)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+
+  const int li = lane & 31, lh = lane >> 5;
+  SERL_LOAD_CHUNK(0);
+  SERL_STORE_CHUNK(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    SERL_LOAD_CHUNK(min(c + 1, nchunks - 1));
+    const uint8_t* st = smemb + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);
+        ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);
+        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + off);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int off = 2 * A_PLANE + swz(wn * WCOLS + tn * 32 + li, 2 * ks + lh);
+        bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);
+        blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    SERL_STORE_CHUNK(buf ^ 1);
+    __syncthreads();
+  }
+#undef SERL_LOAD_CHUNK
+#undef SERL_STORE_CHUNK
+
+  const int wrow0 = m0 + wm * WROWS;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) {
+        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+      }
+    }
+  if (PMODE != 3) {
+    const int gsize = a.Cout / kGnGroups;
+    constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
+    constexpr int NSLOT = WROWS / ROWS;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; ++slot) {
+      const int mrow = wrow0 + slot * ROWS;
+      const bool valid = mrow < a.M;
+      const int n = valid ? mrow / a.P : 0;
+      double* stp = a.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + 8 * (r >> 2);
+            if (row / ROWS == slot) {
+              const float v = acc[tm][tn][r];
+              s += v;
+              q += v * v;
+            }
+          }
+        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+      }
+    }
+  }
+}
+
+__global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc) {
+  const int n = blockIdx.x / kGnGroups, g = blockIdx.x % kGnGroups;
+  const int gs = Cc / kGnGroups;
+  const float* xb = x + (size_t)n * P * Cc + g * gs;
+  double s = 0.0, q = 0.0;
+  for (int e = threadIdx.x; e < P * gs; e += 256) {
+    const int p = e / gs, c = e - p * gs;
+    const float v = xb[(size_t)p * Cc + c];
+    s += v;
+    q += (double)v * v;
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[((size_t)n * kGnGroups + g) * 2] = red[0][0];
+    stats[((size_t)n * kGnGroups + g) * 2 + 1] = red[1][0];
+  }
+}
+
+// w [K][Cout] fp32 -> hi / lo' fp16 [Cout][K]
+__global__ void pack_weights_kernel(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)K * Cout) return;
+  const int n = (int)(e / K), k = (int)(e - (long)n * K);
+  const float v = w[(size_t)k * Cout + n];
+  const _Float16 h = (_Float16)clamp_h(v);
+  const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
+  hi[e] = __builtin_bit_cast(uint16_t, h);
+  lo[e] = __builtin_bit_cast(uint16_t, l);
+}
+
+int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long)K * Cout, 256)), dim3(256), 0, stream, w, hi, lo, K, Cout);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, float* out, double* stats, GnRef in_gn,
+                       int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
+                       hipStream_t stream) {
+  SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
+  ConvArgsB ab{};
+  ConvArgs& a = ab.c;
+  a.in = in; a.w = nullptr; a.out = out; a.stats = stats; a.in_gn = in_gn;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.KH = a.KW = ksz; a.stride = stride;
+  a.pad = std::max((Ho - 1) * stride + ksz - Hi, 0) / 2;
+  a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
+  a.M = N * Ho * Wo; a.P = Ho * Wo;
+  ab.whi = w.hi; ab.wlo = w.lo; ab.K = ksz * ksz * Cin;
+  int cfg = Cout >= 128 ? 0 : 1;
+  if (cfg == 0 && (long)cdiv(a.M, 128) * (Cout / 128) < 512) cfg = 2;
+  const int BM = cfg == 2 ? 64 : 128, BN = cfg == 0 ? 128 : 64;
+  const int wrows = cfg == 0 ? 64 : 32;
+  a.tiles_m = cdiv(a.M, BM); a.tiles_n = Cout / BN;
+  const size_t lds = (size_t)2 * (2 * BM * 64 + 2 * BN * 64) + (size_t)2 * (BM + 1) * 4 * 4;
+  int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
+  if (cfg != 0 && pmode == 1) pmode = 3;
+  const bool one_img = (a.P % BM) == 0;
+  dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  {
+    ProfScope prof(tag, stream);
+#define SERL_LAUNCH_CONV2(WM, WN, TM, TN, PM)                                                                          \
+  do {                                                                                                                 \
+    if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true>), grid, block, lds, stream, ab); \
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false>), grid, block, lds, stream, ab);        \
+  } while (0)
+#define SERL_LAUNCH_CONV(WM, WN, TM, TN)                       \
+  do {                                                         \
+    if (pmode == 0) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 0);      \
+    else if (pmode == 1) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 1); \
+    else if (pmode == 2) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 2); \
+    else SERL_LAUNCH_CONV2(WM, WN, TM, TN, 3);                 \
+  } while (0)
+    if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
+    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 1, 2);
+    else SERL_LAUNCH_CONV(2, 2, 1, 1);
+#undef SERL_LAUNCH_CONV
+#undef SERL_LAUNCH_CONV2
+  }
+  SERL_HIP(hipGetLastError());
+  if (pmode == 3) {
+    hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
+    SERL_HIP(hipGetLastError());
+  }
+  return SERL_OK;
+}
+
+}  // namespace serl

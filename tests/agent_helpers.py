@@ -12,7 +12,7 @@ def product_name(name, image_keys):
     return "/".join(parts)
 
 
-def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0):
+def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0, trunk_mode=None):
     """-> (oracle TrainState, AgentCore) holding identical parameters."""
     from serl_amd.agents.core import AgentCore
     trunk, theta = O.init_params(cfg, seed)
@@ -21,6 +21,8 @@ def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0):
                      ensemble=cfg.ensemble, discount=cfg.discount, tau=cfg.tau, lr=cfg.lr,
                      warmup_steps=cfg.warmup, dropout=cfg.dropout, std_min=cfg.std_min, std_max=cfg.std_max,
                      target_entropy=cfg.target_entropy, seed=agent_seed)
+    if trunk_mode is not None:
+        core.set_trunk_mode(trunk_mode)
     for sec in ("params", "target_params"):
         core.load_flat(sec, trunk)
         core.load_flat(sec, {product_name(k, cfg.image_keys): v for k, v in theta.items()})

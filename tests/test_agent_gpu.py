@@ -12,16 +12,22 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.mark.parametrize("H,W,n", [(64, 64, 6), (128, 128, 5), (128, 64, 3)])
-def test_trunk_forward(gpu, H, W, n):
+MODES = ["f16x3", "f32"]   # split-fp16 trunk convs (default) and exact fp32 MFMA
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("H,W,n", [(64, 64, 6), (128, 128, 5), (128, 64, 3), (128, 128, 70)])
+def test_trunk_forward(gpu, H, W, n, mode):
     cfg = O.Config(image_keys=("a",), H=H, W=W, S=4, A=2)
-    st, core = AH.make_pair(cfg, B=max(n, 4))
+    st, core = AH.make_pair(cfg, B=max(n, 4), trunk_mode=mode)
     rng = np.random.default_rng(1)
     img = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
     ref = O.trunk_forward(st.trunk, torch.tensor(img), torch.float64).numpy()
     got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
     assert got.shape == ref.shape
-    assert AH.rel_err(got, ref) < TOL, AH.rel_err(got, ref)
+    err = AH.rel_err(got, ref)
+    print(f"trunk {mode} {H}x{W} n={n}: rel err vs fp64 = {err:.2e}")
+    assert err < (TOL if mode == "f16x3" else 2e-5), err
 
 
 def _compare_state(cfg, st, core, tol=TOL, steps=1):
@@ -96,10 +102,11 @@ def _check_grads(cfg, core, grads, tap, sl_lo, tol=TOL):
         assert e < tol, (tap, k, e)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B", [16, 40])
-def test_update_critics_matches_oracle(gpu, B):
+def test_update_critics_matches_oracle(gpu, B, mode):
     cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
-    st, core = AH.make_pair(cfg, B)
+    st, core = AH.make_pair(cfg, B, trunk_mode=mode)
     b = AH.synth_batch(cfg, B, seed=3)
     noise = O.make_noise(cfg, B, seed=7)
     info, aux = O.update_critics(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64))
@@ -116,11 +123,12 @@ def test_update_critics_matches_oracle(gpu, B):
     assert core.step == st.step == 1
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("utd", [1, 2])
-def test_update_high_utd_matches_oracle(gpu, utd):
+def test_update_high_utd_matches_oracle(gpu, utd, mode):
     cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
     B = 16
-    st, core = AH.make_pair(cfg, B)
+    st, core = AH.make_pair(cfg, B, trunk_mode=mode)
     b = AH.synth_batch(cfg, B, seed=4)
     noise = O.make_noise(cfg, B, seed=8, utd_ratio=utd)
     info, aux = O.update_high_utd(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64), utd)
