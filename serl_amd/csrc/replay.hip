@@ -129,7 +129,9 @@ struct GatherArgs {
 // Shift one output row out of an LDS-staged source row.  rowb = W*C bytes (multiple of 16).
 // Interior 16-byte chunks: 5 aligned dword LDS reads + v_alignbyte; edge chunks (where the shift
 // clamps to the border pixel) are assembled per byte.
-__device__ __forceinline__ uint4 shifted_chunk(const uint8_t* srow, int q, int sx, int W, int C) {
+template <int CT>
+__device__ __forceinline__ uint4 shifted_chunk(const uint8_t* srow, int q, int sx, int W, int Crt) {
+  const int C = CT > 0 ? CT : Crt;  // compile-time channel count (3) turns the /C, %C below into shifts/mults
   const int o0 = q * 16;
   const int pmin = o0 / C, pmax = (o0 + 15) / C;
   uint4 r;
@@ -161,6 +163,7 @@ __device__ __forceinline__ uint4 shifted_chunk(const uint8_t* srow, int q, int s
   return r;
 }
 
+template <int CT>
 __global__ __launch_bounds__(256) void gather_crop_kernel(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(GatherArgs a) {
                    (size_t)h0 * rowb;
     for (int v = tid; v < nrows * vec_per_row; v += 256) {
       const int r = v / vec_per_row, q = v - r * vec_per_row;
-      const uint4 val = shifted_chunk(lds + r * lds_stride, q, sx, a.W, a.C);
+      const uint4 val = shifted_chunk<CT>(lds + r * lds_stride, q, sx, a.W, a.C);
       *reinterpret_cast<uint4*>(dst + (size_t)r * rowb + q * 16) = val;
     }
   } else if (!a.from_packed) {
@@ -574,7 +577,8 @@ static int launch_gather_crop(GatherArgs& a, hipStream_t stream) {
   const int rec_blocks = a.from_packed ? 0 : cdiv((long)a.batch * a.rec_len, 256);
   const size_t lds = (size_t)kRowsPerBlock * ((size_t)a.W * a.C + 16);
   ProfScope prof("gather_crop", stream);
-  hipLaunchKernelGGL(gather_crop_kernel, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
+  if (a.C == 3) hipLaunchKernelGGL(gather_crop_kernel<3>, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(gather_crop_kernel<0>, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

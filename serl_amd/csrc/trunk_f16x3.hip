@@ -32,26 +32,32 @@ struct ConvArgsB {
   int K;
 };
 
-__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-__device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// float4 -> 4 fp16 hi (packed in uint2) and 4 fp16 lo' = fp16((x - hi) * 2^11)   (round-to-nearest-even)
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+
+// float4 -> 4 fp16 hi (packed in uint2) and 4 fp16 lo' = fp16((x - hi) * 2^11).
+// hi is converted with v_cvt_pkrtz (any hi within one fp16 ulp works: the residual is exact in fp32 and
+// stays in range after the 2^11 scale); lo' is rounded to nearest (v_cvt_pk_f16_f32), so
+// |x - hi - 2^-11 lo'| <= 2^-21 |x|.  Activations are GroupNorm outputs (|x| << 65504): no clamp here,
+// the one-time weight packing clamps.
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  const _Float16 hx = (_Float16)clamp_h(v.x), hy = (_Float16)clamp_h(v.y);
-  const _Float16 hz = (_Float16)clamp_h(v.z), hw = (_Float16)clamp_h(v.w);
-  const _Float16 lx = (_Float16)((v.x - (float)hx) * kLoScale), ly = (_Float16)((v.y - (float)hy) * kLoScale);
-  const _Float16 lz = (_Float16)((v.z - (float)hz) * kLoScale), lw = (_Float16)((v.w - (float)hw) * kLoScale);
-  hi = make_uint2(pack_h2(hx, hy), pack_h2(hz, hw));
-  lo = make_uint2(pack_h2(lx, ly), pack_h2(lz, lw));
+  const h16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+  const h16x2 h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+  const f32x2 r0 = {(v.x - (float)h0[0]) * kLoScale, (v.y - (float)h0[1]) * kLoScale};
+  const f32x2 r1 = {(v.z - (float)h1[0]) * kLoScale, (v.w - (float)h1[1]) * kLoScale};
+  const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
 // byte offset of 16-byte slot `slot` (0..3) of row `row` in a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <int WM, int WN, int TM, int TN, int PMODE, bool ONE_IMG>
-__global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
+template <int WM, int WN, int TM, int TN, int PMODE, bool ONE_IMG, bool HAS_GN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   const ConvArgs& a = ab.c;
   constexpr int WROWS = 32 * TM, WCOLS = 32 * TN;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int n_first = m0 / a.P;
-  if (a.in_gn.stats) {
+  if (HAS_GN) {
     const int n_last = min(a.N - 1, (m0 + BM - 1) / a.P);
     for (int t = tid; t < (n_last - n_first + 1) * kGnGroups; t += 256) {
       const double* st = a.in_gn.stats + ((size_t)n_first * kGnGroups + t) * 2;
@@ -78,20 +84,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
     }
     __syncthreads();
   }
+  // per-thread im2col rows: element offset of the always-valid centre tap (pixel (oy*s, ox*s)) and a
+  // bit mask of the taps that fall inside the image; out-of-image taps load the centre pixel and are
+  // zeroed on the way to LDS, so the per-chunk address math is one select + one add per row.
   const int kq = tid & 7;
-  int rpix[AI], riy[AI], rix[AI], rn[AI];
+  const int ntaps = a.KH * a.KW;
+  long rbase[AI];
+  unsigned rmask[AI];
+  int rn[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + (tid >> 3) + 32 * i;
+    rbase[i] = 0; rmask[i] = 0; rn[i] = 0;
     if (m < a.M) {
       const int n = m / a.P, rem = m - n * a.P;
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
       rn[i] = n;
-      rpix[i] = n * a.Hi * a.Wi;
-      riy[i] = oy * a.stride - a.pad;
-      rix[i] = ox * a.stride - a.padw;
-    } else {
-      rn[i] = 0; rpix[i] = 0; riy[i] = -(1 << 20); rix[i] = -(1 << 20);
+      rbase[i] = ((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin + 4 * kq;
+      for (int t = 0; t < ntaps; ++t) {
+        const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
+        if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) rmask[i] |= 1u << t;
+      }
     }
   }
   const int cpt = a.Cin >> 5;
@@ -107,15 +120,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
     const int c_ = (CIDX);                                                                                     \
     const int tap = c_ / cpt, ci0 = (c_ - tap * cpt) << 5;                                                     \
     const int ky = tap / a.KW, kx = tap - ky * a.KW;                                                           \
+    const int toff_ = ((ky - a.pad) * a.Wi + (kx - a.padw)) * a.Cin + ci0;                                     \
     okmask = 0;                                                                                                \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
-      const int iy = riy[i] + ky, ix = rix[i] + kx;                                                            \
-      const bool ok = (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;                          \
+      const bool ok = (rmask[i] >> tap) & 1u;                                                                  \
       okmask |= (ok ? 1u : 0u) << i;                                                                           \
-      const int cy = min(max(iy, 0), a.Hi - 1), cx = min(max(ix, 0), a.Wi - 1);                                \
-      ra[i] = *reinterpret_cast<const float4*>(a.in + (size_t)(rpix[i] + cy * a.Wi + cx) * a.Cin + ci0 + 4 * kq); \
+      ra[i] = *reinterpret_cast<const float4*>(a.in + rbase[i] + (ok ? toff_ : ci0));                          \
     }                                                                                                          \
-    if (a.in_gn.stats) {                                                                                       \
+    if (HAS_GN) {                                                                                              \
       const int c4_ = ci0 + 4 * kq, grp_ = c4_ / a.in_gn.gsize;                                                \
       const float4 ga_ = *reinterpret_cast<const float4*>(a.in_gn.gamma + c4_);                                \
       const float4 be_ = *reinterpret_cast<const float4*>(a.in_gn.beta + c4_);                                 \
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
     uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       float4 v = ra[i];                                                                                        \
-      if (a.in_gn.stats) {                                                                                     \
+      if (HAS_GN) {                                                                                            \
         const float4 s_ = rs[ONE_IMG ? 0 : i];                                                                 \
         const float4 h_ = rh[ONE_IMG ? 0 : i];                                                                 \
         v.x = fmaxf(v.x * s_.x + h_.x, 0.f);                                                                   \
@@ -324,13 +336,19 @@ int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, flo
   int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   if (cfg != 0 && pmode == 1) pmode = 3;
   const bool one_img = (a.P % BM) == 0;
+  const bool has_gn = in_gn.stats != nullptr;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
   {
     ProfScope prof(tag, stream);
 #define SERL_LAUNCH_CONV2(WM, WN, TM, TN, PM)                                                                          \
   do {                                                                                                                 \
-    if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true>), grid, block, lds, stream, ab); \
-    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false>), grid, block, lds, stream, ab);        \
+    if (has_gn) {                                                                                                      \
+      if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true, true>), grid, block, lds, stream, ab);   \
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false, true>), grid, block, lds, stream, ab);          \
+    } else {                                                                                                           \
+      if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true, false>), grid, block, lds, stream, ab);  \
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false, false>), grid, block, lds, stream, ab);         \
+    }                                                                                                                  \
   } while (0)
 #define SERL_LAUNCH_CONV(WM, WN, TM, TN)                       \
   do {                                                         \
