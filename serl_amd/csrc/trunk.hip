@@ -550,6 +550,7 @@ size_t trunk_packed_bytes() {
       conv_dims(i, k, K, Cout);
       off += 2 * al256((size_t)K * Cout * 2);
     }
+  off += 2 * al256((size_t)64 * 176 * 2);
   return off;
 }
 
@@ -565,6 +566,8 @@ int trunk_packed_bind(TrunkPacked& p, void* mem) {
       p.blk[i][k].hi = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
       p.blk[i][k].lo = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
     }
+  p.init.hi = (uint16_t*)(b + off); off += al256((size_t)64 * 176 * 2);
+  p.init.lo = (uint16_t*)(b + off); off += al256((size_t)64 * 176 * 2);
   p.dirty = true;
   return SERL_OK;
 }
@@ -579,6 +582,10 @@ static int trunk_pack(const TrunkWeights& w, TrunkPacked& p, hipStream_t stream)
       int rc = pack_conv_weights_f16x3(src, p.blk[i][k].hi, p.blk[i][k].lo, K, Cout, stream);
       if (rc) return rc;
     }
+  {
+    int rc = pack_conv_init_f16x3(w.conv_init, p.init.hi, p.init.lo, stream);
+    if (rc) return rc;
+  }
   p.dirty = false;
   return SERL_OK;
 }
@@ -595,7 +602,10 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
   SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kGnLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
   int rc;
-  {  // conv_init
+  if (packed) {
+    PackedConvWeights pw{packed->init.hi, packed->init.lo};
+    if ((rc = launch_conv_init_f16x3(frames, pw, ws.raw_init, stats_of(0), N, d.H, d.W, d.h[0], d.w[0], stream))) return rc;
+  } else {  // conv_init, exact fp32 MFMA
     ConvInitArgs a{};
     a.img = frames; a.w = w.conv_init; a.out = ws.raw_init; a.stats = stats_of(0);
     a.N = N; a.H = d.H; a.W = d.W; a.Ho = d.h[0]; a.Wo = d.w[0];

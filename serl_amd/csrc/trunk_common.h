@@ -82,4 +82,9 @@ int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, flo
 // w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K]
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream);
 
+// conv_init in split-fp16 (weights re-indexed and padded to [64][176])
+int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream);
+int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
+                           int Ho, int Wo, hipStream_t stream);
+
 }  // namespace serl

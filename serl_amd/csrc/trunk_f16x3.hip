@@ -268,6 +268,197 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_init in split-fp16: u8 image -> normalise -> conv 7x7 stride 2 pad 3, 3 -> 64.
+// K is re-indexed as k' = ky*24 + (kx*3 + c) (21 real taps per kernel row + 3 zero-weight pads, 7 rows
+// -> 168, padded to 176 = 11 MFMA k-steps) so that every 8-wide MFMA k-block is a contiguous run of
+// one patch row in LDS.  Persistent workgroups keep the (hi, lo') weights resident in LDS and walk over
+// 16x16 output tiles.
+// ---------------------------------------------------------------------------------------------
+struct ConvInitArgsB {
+  const uint8_t* img;   // [N][H][W][3]
+  const uint16_t* whi;  // [64][176] fp16
+  const uint16_t* wlo;  // [64][176] fp16 residual (unscaled)
+  float* out;           // [N][Ho][Wo][64]
+  double* stats;        // [N][4][2]
+  int N, H, W, Ho, Wo, tiles_y, tiles_x, total_tiles;
+};
+
+constexpr int kCbKP = 176;       // padded K
+constexpr int kCbWP = 184;       // LDS pitch of a weight row (halfs): 368 B, conflict-free ds_read_b128
+constexpr int kCbPatch = 37;     // input rows/cols per 16x16 output tile
+constexpr int kCbPWH = 116;      // LDS pitch of a patch row (halfs): 111 real + slack for the padded k-block
+constexpr int kCbWBytes = 64 * kCbWP * 2;         // one weight plane
+constexpr int kCbPBytes = kCbPatch * kCbPWH * 2;  // one patch plane
+constexpr int kCbLds = 2 * kCbWBytes + 2 * kCbPBytes + 768 * 4;
+
+__global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  uint8_t* w_hi = smemb;
+  uint8_t* w_lo = smemb + kCbWBytes;
+  uint16_t* p_hi = reinterpret_cast<uint16_t*>(smemb + 2 * kCbWBytes);
+  uint16_t* p_lo = reinterpret_cast<uint16_t*>(smemb + 2 * kCbWBytes + kCbPBytes);
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smemb + 2 * kCbWBytes + 2 * kCbPBytes);  // [3][256] (hi | lo' << 16)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  // resident weights: 64 rows x 22 16-byte slots per plane
+  for (int v = tid; v < 2 * 64 * 22; v += 256) {
+    const int plane = v / (64 * 22), r = (v / 22) % 64, sl = v % 22;
+    const uint4 val = *reinterpret_cast<const uint4*>((plane ? a.wlo : a.whi) + (size_t)r * kCbKP + sl * 8);
+    *reinterpret_cast<uint4*>((plane ? w_lo : w_hi) + r * (kCbWP * 2) + sl * 16) = val;
+  }
+  // pixel value -> split-fp16 of the ImageNet-normalised input (x/255 - mean)/std, one entry per (channel, byte)
+  for (int v = tid; v < 768; v += 256) {
+    const int ch = v >> 8;
+    const float mean = ch == 0 ? 0.485f : (ch == 1 ? 0.456f : 0.406f);
+    const float stdv = ch == 0 ? 0.229f : (ch == 1 ? 0.224f : 0.225f);
+    const float val = ((float)(v & 255) / 255.0f - mean) / stdv;
+    const _Float16 h = (_Float16)val;
+    const _Float16 l = (_Float16)(val - (float)h);  // unscaled: |x| = O(1) here, lo stays in fp16's normal range
+    lut[v] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+  }
+  constexpr int PE = (kCbPatch * kCbPWH + 255) / 256;  // patch elements per thread
+  uint32_t pix[PE];  // staged bytes of the NEXT tile: bits 0-7 value, bits 8-9 channel, bit 31 = outside / pad
+#define SERL_CI_FETCH(TILE)                                                                       \
+  {                                                                                               \
+    int b_ = (TILE);                                                                              \
+    const int tx_ = b_ % a.tiles_x;                                                               \
+    b_ /= a.tiles_x;                                                                              \
+    const int ty_ = b_ % a.tiles_y;                                                               \
+    const int n_ = b_ / a.tiles_y;                                                                \
+    const uint8_t* img_ = a.img + (size_t)n_ * a.H * a.W * 3;                                     \
+    const int iy0_ = ty_ * 32 - 3, ix0_ = tx_ * 32 - 3;                                           \
+    _Pragma("unroll") for (int i = 0; i < PE; ++i) {                                              \
+      const int v = tid + 256 * i;                                                                \
+      const int yy = v / kCbPWH, rest = v - yy * kCbPWH;                                          \
+      const int xx = rest / 3, ch = rest - xx * 3;                                                \
+      const int iy = iy0_ + yy, ix = ix0_ + xx;                                                   \
+      const bool ok = v < kCbPatch * kCbPWH && rest < kCbPatch * 3 && (unsigned)iy < (unsigned)a.H && \
+                      (unsigned)ix < (unsigned)a.W;                                               \
+      const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);                     \
+      const uint32_t byte = img_[((size_t)cy * a.W + cx) * 3 + ch];                               \
+      pix[i] = ok ? (byte | ((uint32_t)ch << 8)) : 0x80000000u;                                   \
+    }                                                                                             \
+  }
+  SERL_CI_FETCH(min((int)blockIdx.x, a.total_tiles - 1));
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    __syncthreads();  // previous tile's MFMA reads of the patch are done (weights / LUT are in place)
+#pragma unroll
+    for (int i = 0; i < PE; ++i) {
+      const int v = tid + 256 * i;
+      if (v < kCbPatch * kCbPWH) {
+        const uint32_t e = (pix[i] & 0x80000000u) ? 0u : lut[pix[i] & 0x3FF];
+        p_hi[v] = (uint16_t)(e & 0xFFFF);
+        p_lo[v] = (uint16_t)(e >> 16);
+      }
+    }
+    __syncthreads();
+    SERL_CI_FETCH(min(tile + (int)gridDim.x, a.total_tiles - 1));  // next tile's bytes, in flight under the MFMAs
+    int abase[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int p = wave * 64 + tm * 32 + li;
+      abase[tm] = (2 * (p >> 4)) * kCbPWH + (p & 15) * 6;
+    }
+    f32x16 acc[2][2];  // one accumulator: both operands are O(1), so lo is kept unscaled for conv_init
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < kCbKP / 16; ++ks) {
+      // k-block of this lane half; block 21 (beyond the 7 kernel rows) has zero weights: read block 20
+      const int kb0 = 2 * ks, kb1 = min(2 * ks + 1, 20);
+      const int koff0 = (kb0 / 3) * kCbPWH + (kb0 % 3) * 8, koff1 = (kb1 / 3) * kCbPWH + (kb1 % 3) * 8;
+      const int koff = lh ? koff1 : koff0;
+      f16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(p_hi + abase[tm] + koff);
+        const uint32_t* pl = reinterpret_cast<const uint32_t*>(p_lo + abase[tm] + koff);
+        ahi[tm] = __builtin_bit_cast(f16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+        alo[tm] = __builtin_bit_cast(f16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int off = (tn * 32 + li) * (kCbWP * 2) + (2 * ks + lh) * 16;
+        bhi[tn] = *reinterpret_cast<const f16x8*>(w_hi + off);
+        blo[tn] = *reinterpret_cast<const f16x8*>(w_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+        const bool ok = oy < a.Ho && ox < a.Wo;
+        float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const float v = ok ? acc[tm][tn][r] : 0.f;
+          if (ok) o[tn * 32 + li] = v;
+          s[tn] += v;
+          q[tn] += v * v;
+        }
+      }
+    double* st = a.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
+  }
+}
+
+// conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> hi / lo' fp16 [64][176] (k' = ky*24 + kx*3 + c)
+__global__ void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 64 * kCbKP) return;
+  const int n = e / kCbKP, kp = e - n * kCbKP;
+  const int ky = kp / 24, j = kp - ky * 24;
+  float v = 0.f;
+  if (ky < 7 && j < 21) v = w[(size_t)(ky * 21 + j) * 64 + n];
+  const _Float16 h = (_Float16)clamp_h(v);
+  const _Float16 l = (_Float16)(v - (float)h);  // unscaled (see conv_init_f16x3_kernel)
+  hi[e] = __builtin_bit_cast(uint16_t, h);
+  lo[e] = __builtin_bit_cast(uint16_t, l);
+}
+
+int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_conv_init_kernel, dim3(cdiv(64 * kCbKP, 256)), dim3(256), 0, stream, w, hi, lo);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
+                           int Ho, int Wo, hipStream_t stream) {
+  ConvInitArgsB a{};
+  a.img = img; a.whi = w.hi; a.wlo = w.lo; a.out = out; a.stats = stats;
+  a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.tiles_y = cdiv(Ho, 16); a.tiles_x = cdiv(Wo, 16);
+  a.total_tiles = N * a.tiles_y * a.tiles_x;
+  const int grid = std::min(a.total_tiles, 512);  // 2 persistent workgroups per CU
+  ProfScope prof("conv_init", stream);
+  hipLaunchKernelGGL(conv_init_f16x3_kernel, dim3(grid), dim3(256), kCbLds, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
 __global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc) {
   const int n = blockIdx.x / kGnGroups, g = blockIdx.x % kGnGroups;
   const int gs = Cc / kGnGroups;
