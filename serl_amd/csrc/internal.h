@@ -32,7 +32,7 @@ struct TrunkWorkspace {
   float* raw_init = nullptr;  // [N][h0][w0][64]
   float* pool = nullptr;      // [N][h1][w1][64]
   struct B {
-    float *raw0, *raw1, *rawp, *out;
+    float *raw0, *raw1, *rawp, *out, *norm0;
   } blk[kTrunkStages]{};
   double* stats = nullptr;  // 13 GN layers x [N][4][2]
   void* base = nullptr;     // single allocation backing everything above

@@ -453,6 +453,7 @@ static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int 
     blk[i].raw1 = (float*)take(e);
     blk[i].rawp = (float*)take(e);
     blk[i].out = (float*)take(e);
+    blk[i].norm0 = (float*)take(e);
   }
   double* stats = (double*)take((size_t)kGnLayers * N * kGnGroups * 2 * sizeof(double));
   if (ws) {
@@ -596,16 +597,17 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
     int prc = trunk_pack(w, *packed, stream);
     if (prc) return prc;
   }
+  if (packed) {
+    SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
+    return trunk_forward_f16x3(w, ws, *packed, frames, n, feats_out, stream);
+  }
   SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
   const TrunkDims& d = ws.d;
   const int N = n;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
   SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kGnLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
   int rc;
-  if (packed) {
-    PackedConvWeights pw{packed->init.hi, packed->init.lo};
-    if ((rc = launch_conv_init_f16x3(frames, pw, ws.raw_init, stats_of(0), N, d.H, d.W, d.h[0], d.w[0], stream))) return rc;
-  } else {  // conv_init, exact fp32 MFMA
+  {  // conv_init, exact fp32 MFMA
     ConvInitArgs a{};
     a.img = frames; a.w = w.conv_init; a.out = ws.raw_init; a.stats = stats_of(0);
     a.N = N; a.H = d.H; a.W = d.W; a.Ho = d.h[0]; a.Wo = d.w[0];
@@ -638,10 +640,6 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
                                                   {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
     auto conv = [&](int which, const float* in, const float* wf, float* out, double* st, GnRef g, int hi, int wi,
                     int ci, int ksz, int strd) -> int {
-      if (packed) {
-        PackedConvWeights pw{packed->blk[i][which].hi, packed->blk[i][which].lo};
-        return launch_conv_f16x3(kTags[i][which], in, pw, out, st, g, N, hi, wi, ci, Ho, Wo, f, ksz, strd, stream);
-      }
       return launch_conv(kTags[i][which], in, wf, out, st, g, N, hi, wi, ci, Ho, Wo, f, ksz, strd, stream);
     };
     if ((rc = conv(0, x, bw.conv0, ws.blk[i].raw0, stats_of(l0), none, Hi, Wi, cin, 3, s))) return rc;

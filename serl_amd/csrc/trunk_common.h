@@ -71,16 +71,15 @@ struct ConvArgs {
   int M, P, tiles_m, tiles_n;
 };
 
-// host-side launch of the split-fp16 implicit-GEMM conv (trunk_f16x3.hip); same contract as the fp32 one
 struct PackedConvWeights {
   const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous)
   const uint16_t* lo;  // fp16 [Cout][K]  (w - float(hi)) * 2^11
 };
-int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, float* out, double* stats, GnRef in_gn,
-                       int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                       hipStream_t stream);
 // w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K]
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream);
+// whole trunk in split-fp16 arithmetic (trunk_f16x3.hip)
+int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
+                        float* feats_out, hipStream_t stream);
 
 // conv_init in split-fp16 (weights re-indexed and padded to [64][176])
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream);

@@ -56,34 +56,24 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 // byte offset of 16-byte slot `slot` (0..3) of row `row` in a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <int WM, int WN, int TM, int TN, int PMODE, bool ONE_IMG, bool HAS_GN>
+// A operand = activations already in "split16" layout (written by the elementwise producers below):
+// per 4 channels one 16-byte record {hi x4 fp16 | lo' x4 fp16}, i.e. the same footprint and addressing
+// as the fp32 NHWC tensor.  The conv loader is then a pure 16-byte copy global -> LDS (zero VALU math).
+template <int WM, int WN, int TM, int TN, int PMODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   const ConvArgs& a = ab.c;
   constexpr int WROWS = 32 * TM, WCOLS = 32 * TN;
   constexpr int BM = WROWS * WM, BN = WCOLS * WN;
-  constexpr int AI = BM / 32;   // float4 A loads per thread per chunk
-  constexpr int BI = BN / 32;   // 16-byte B loads per thread per chunk (hi and lo planes together: BN*4 slots*2 / 256)
+  constexpr int AI = BM / 32;   // 16-byte A loads per thread per chunk
+  constexpr int BI = BN / 32;   // 16-byte B loads per thread per chunk (hi and lo planes together)
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  float* gnm = reinterpret_cast<float*>(smemb + 2 * STAGE);
-  float* gnr = gnm + (BM + 1) * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
-  const int n_first = m0 / a.P;
-  if (HAS_GN) {
-    const int n_last = min(a.N - 1, (m0 + BM - 1) / a.P);
-    for (int t = tid; t < (n_last - n_first + 1) * kGnGroups; t += 256) {
-      const double* st = a.in_gn.stats + ((size_t)n_first * kGnGroups + t) * 2;
-      const double mean = st[0] * a.in_gn.inv_count, m2 = st[1] * a.in_gn.inv_count;
-      gnm[t] = (float)mean;
-      gnr[t] = rsqrtf(fmaxf((float)(m2 - mean * mean), 0.f) + 1e-5f);
-    }
-    __syncthreads();
-  }
   // per-thread im2col rows: element offset of the always-valid centre tap (pixel (oy*s, ox*s)) and a
   // bit mask of the taps that fall inside the image; out-of-image taps load the centre pixel and are
   // zeroed on the way to LDS, so the per-chunk address math is one select + one add per row.
@@ -91,15 +81,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   const int ntaps = a.KH * a.KW;
   long rbase[AI];
   unsigned rmask[AI];
-  int rn[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + (tid >> 3) + 32 * i;
-    rbase[i] = 0; rmask[i] = 0; rn[i] = 0;
+    rbase[i] = 0; rmask[i] = 0;
     if (m < a.M) {
       const int n = m / a.P, rem = m - n * a.P;
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-      rn[i] = n;
       rbase[i] = ((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin + 4 * kq;
       for (int t = 0; t < ntaps; ++t) {
         const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
@@ -107,42 +95,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       }
     }
   }
-  const int cpt = a.Cin >> 5;
-  const int nchunks = a.KH * a.KW * cpt;
-  // B loader: item j = tid + 256*i over [plane(hi,lo)][BN rows][4 slots]
-  constexpr int NS = ONE_IMG ? 1 : AI;
-  float4 ra[AI], rs[NS], rh[NS];
-  uint4 rb[BI];
+  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
+  uint4 ra[AI], rb[BI];
   unsigned okmask = 0;
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0;  // chunk counters (chunks are visited strictly in order)
 
 #define SERL_LOAD_CHUNK(CIDX)                                                                                  \
   {                                                                                                            \
     const int c_ = (CIDX);                                                                                     \
-    const int tap = c_ / cpt, ci0 = (c_ - tap * cpt) << 5;                                                     \
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;                                                           \
-    const int toff_ = ((ky - a.pad) * a.Wi + (kx - a.padw)) * a.Cin + ci0;                                     \
+    const int tap = l_tap, ci0 = l_ci0;                                                                        \
+    const int toff_ = ((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + ci0;                                 \
+    /* advance the (tap, ky, kx, ci0) counters to the next chunk: no scalar divisions in the loop */          \
+    if (c_ + 1 < nchunks) {                                                                                    \
+      l_ci0 += 32;                                                                                             \
+      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
+    }                                                                                                          \
     okmask = 0;                                                                                                \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       const bool ok = (rmask[i] >> tap) & 1u;                                                                  \
       okmask |= (ok ? 1u : 0u) << i;                                                                           \
-      ra[i] = *reinterpret_cast<const float4*>(a.in + rbase[i] + (ok ? toff_ : ci0));                          \
-    }                                                                                                          \
-    if (HAS_GN) {                                                                                              \
-      const int c4_ = ci0 + 4 * kq, grp_ = c4_ / a.in_gn.gsize;                                                \
-      const float4 ga_ = *reinterpret_cast<const float4*>(a.in_gn.gamma + c4_);                                \
-      const float4 be_ = *reinterpret_cast<const float4*>(a.in_gn.beta + c4_);                                 \
-      _Pragma("unroll") for (int i = 0; i < NS; ++i) {                                                         \
-        const int t_ = max(rn[i] - n_first, 0) * kGnGroups + grp_;                                             \
-        const float mean_ = gnm[t_], rstd_ = gnr[t_];                                                          \
-        rs[i] = make_float4(ga_.x * rstd_, ga_.y * rstd_, ga_.z * rstd_, ga_.w * rstd_);                       \
-        rh[i] = make_float4(be_.x - mean_ * rs[i].x, be_.y - mean_ * rs[i].y, be_.z - mean_ * rs[i].z,         \
-                            be_.w - mean_ * rs[i].w);                                                          \
-      }                                                                                                        \
+      ra[i] = *reinterpret_cast<const uint4*>(a.in + rbase[i] + (ok ? toff_ : ci0));                           \
     }                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
-      const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (c_ << 5) + s_ * 8;       \
+      const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (min(c_, nchunks - 1) << 5) + s_ * 8; \
       rb[i] = *reinterpret_cast<const uint4*>(wp_);                                                            \
     }                                                                                                          \
   }
@@ -150,22 +127,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   {                                                                                                            \
     uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
-      float4 v = ra[i];                                                                                        \
-      if (HAS_GN) {                                                                                            \
-        const float4 s_ = rs[ONE_IMG ? 0 : i];                                                                 \
-        const float4 h_ = rh[ONE_IMG ? 0 : i];                                                                 \
-        v.x = fmaxf(v.x * s_.x + h_.x, 0.f);                                                                   \
-        v.y = fmaxf(v.y * s_.y + h_.y, 0.f);                                                                   \
-        v.z = fmaxf(v.z * s_.z + h_.z, 0.f);                                                                   \
-        v.w = fmaxf(v.w * s_.w + h_.w, 0.f);                                                                   \
-      }                                                                                                        \
-      if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
-      uint2 hi_, lo_;                                                                                          \
-      split4(v, hi_, lo_);                                                                                     \
+      uint4 v = ra[i];                                                                                         \
+      if (!((okmask >> i) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);                                               \
       const int row_ = (tid >> 3) + 32 * i;                                                                    \
       const int off_ = swz(row_, kq >> 1) + (kq & 1) * 8;                                                      \
-      *reinterpret_cast<uint2*>(st_ + off_) = hi_;                                                             \
-      *reinterpret_cast<uint2*>(st_ + A_PLANE + off_) = lo_;                                                   \
+      *reinterpret_cast<uint2*>(st_ + off_) = make_uint2(v.x, v.y);                                            \
+      *reinterpret_cast<uint2*>(st_ + A_PLANE + off_) = make_uint2(v.z, v.w);                                  \
     }                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
@@ -188,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    SERL_LOAD_CHUNK(min(c + 1, nchunks - 1));
+    SERL_LOAD_CHUNK(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
     const uint8_t* st = smemb + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -505,13 +472,106 @@ int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, i
   return SERL_OK;
 }
 
-int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, float* out, double* stats, GnRef in_gn,
-                       int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                       hipStream_t stream) {
+// ---------------------------------------------------------------------------------------------
+// elementwise producers of the split16 layout
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 to_split16(float4 v) {
+  uint2 hi, lo;
+  split4(v, hi, lo);
+  return make_uint4(hi.x, hi.y, lo.x, lo.y);
+}
+__device__ __forceinline__ float4 from_split16(uint4 u) {
+  const h16x2 h0 = __builtin_bit_cast(h16x2, u.x), h1 = __builtin_bit_cast(h16x2, u.y);
+  const h16x2 l0 = __builtin_bit_cast(h16x2, u.z), l1 = __builtin_bit_cast(h16x2, u.w);
+  return make_float4((float)h0[0] + (float)l0[0] * kLoInv, (float)h0[1] + (float)l0[1] * kLoInv,
+                     (float)h1[0] + (float)l1[0] * kLoInv, (float)h1[1] + (float)l1[1] * kLoInv);
+}
+
+// GN + ReLU + max_pool 3x3/2 SAME -> split16   (resnet_v1.py:257-259)
+__global__ __launch_bounds__(256) void gn_relu_maxpool_split_kernel(const float* x, GnRef gn, uint4* out, int N,
+                                                                   int Hi, int Wi, int Ho, int Wo, int Cc) {
+  const int c4n = Cc / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * Ho * Wo * c4n) return;
+  const int c4 = (int)(e % c4n);
+  long t = e / c4n;
+  const int ox = (int)(t % Wo);
+  t /= Wo;
+  const int oy = (int)(t % Ho);
+  const int n = (int)(t / Ho);
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 + dy;
+    if (iy >= Hi) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 + dx;
+      if (ix >= Wi) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * Hi + iy) * Wi + ix) * Cc + c4 * 4);
+      m.x = fmaxf(m.x, fmaxf(v.x * s.x + h.x, 0.f));
+      m.y = fmaxf(m.y, fmaxf(v.y * s.y + h.y, 0.f));
+      m.z = fmaxf(m.z, fmaxf(v.z * s.z + h.z, 0.f));
+      m.w = fmaxf(m.w, fmaxf(v.w * s.w + h.w, 0.f));
+    }
+  }
+  out[e] = to_split16(m);
+}
+
+// relu(GN(raw)) -> split16: the input of a block's second conv
+__global__ __launch_bounds__(256) void gn_relu_split_kernel(const float* raw, GnRef gn, uint4* out, int N, int P,
+                                                           int Cc) {
+  const int c4n = Cc / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * P * c4n) return;
+  const int c4 = (int)(e % c4n);
+  const int n = (int)(e / ((long)P * c4n));
+  const float4 v = reinterpret_cast<const float4*>(raw)[e];
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
+  out[e] = to_split16(make_float4(fmaxf(v.x * s.x + h.x, 0.f), fmaxf(v.y * s.y + h.y, 0.f),
+                                  fmaxf(v.z * s.z + h.z, 0.f), fmaxf(v.w * s.w + h.w, 0.f)));
+}
+
+// block output: relu(GN(raw_b) + residual); residual = x (split16) or GN(raw_proj); out split16 or fp32
+__global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, GnRef gn, const uint4* res_split,
+                                                             const float* res_raw, GnRef rgn, uint4* out_split,
+                                                             float* out_f32, int N, int P, int Cc) {
+  const int c4n = Cc / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * P * c4n) return;
+  const int c4 = (int)(e % c4n);
+  const int n = (int)(e / ((long)P * c4n));
+  const float4 v = reinterpret_cast<const float4*>(raw)[e];
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
+  float4 r;
+  if (res_raw) {
+    r = reinterpret_cast<const float4*>(res_raw)[e];
+    float4 s2, h2;
+    gn_coef4(rgn, n, c4 * 4, s2, h2);
+    r.x = r.x * s2.x + h2.x; r.y = r.y * s2.y + h2.y; r.z = r.z * s2.z + h2.z; r.w = r.w * s2.w + h2.w;
+  } else {
+    r = from_split16(res_split[e]);
+  }
+  float4 o;
+  o.x = fmaxf(r.x + (v.x * s.x + h.x), 0.f);
+  o.y = fmaxf(r.y + (v.y * s.y + h.y), 0.f);
+  o.z = fmaxf(r.z + (v.z * s.z + h.z), 0.f);
+  o.w = fmaxf(r.w + (v.w * s.w + h.w), 0.f);
+  if (out_f32) reinterpret_cast<float4*>(out_f32)[e] = o;
+  else out_split[e] = to_split16(o);
+}
+
+static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
+                             int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
+                             hipStream_t stream) {
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgsB ab{};
   ConvArgs& a = ab.c;
-  a.in = in; a.w = nullptr; a.out = out; a.stats = stats; a.in_gn = in_gn;
+  a.in = in_split; a.w = nullptr; a.out = out; a.stats = stats;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.KH = a.KW = ksz; a.stride = stride;
   a.pad = std::max((Ho - 1) * stride + ksz - Hi, 0) / 2;
@@ -520,44 +580,98 @@ int launch_conv_f16x3(const char* tag, const float* in, PackedConvWeights w, flo
   ab.whi = w.hi; ab.wlo = w.lo; ab.K = ksz * ksz * Cin;
   int cfg = Cout >= 128 ? 0 : 1;
   if (cfg == 0 && (long)cdiv(a.M, 128) * (Cout / 128) < 512) cfg = 2;
-  const int BM = cfg == 2 ? 64 : 128, BN = cfg == 0 ? 128 : 64;
-  const int wrows = cfg == 0 ? 64 : 32;
+  const int BM = cfg == 2 ? 64 : (cfg == 1 ? 256 : 128), BN = cfg == 0 ? 128 : 64;
+  const int wrows = cfg == 2 ? 32 : 64;
   a.tiles_m = cdiv(a.M, BM); a.tiles_n = Cout / BN;
-  const size_t lds = (size_t)2 * (2 * BM * 64 + 2 * BN * 64) + (size_t)2 * (BM + 1) * 4 * 4;
+  const size_t lds = (size_t)2 * (2 * BM * 64 + 2 * BN * 64);
   int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
-  if (cfg != 0 && pmode == 1) pmode = 3;
-  const bool one_img = (a.P % BM) == 0;
-  const bool has_gn = in_gn.stats != nullptr;
+  if (cfg == 2 && pmode == 1) pmode = 3;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
   {
     ProfScope prof(tag, stream);
-#define SERL_LAUNCH_CONV2(WM, WN, TM, TN, PM)                                                                          \
+#define SERL_LAUNCH_CONV(WM, WN, TM, TN)                                                                               \
   do {                                                                                                                 \
-    if (has_gn) {                                                                                                      \
-      if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true, true>), grid, block, lds, stream, ab);   \
-      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false, true>), grid, block, lds, stream, ab);          \
-    } else {                                                                                                           \
-      if (one_img) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, true, false>), grid, block, lds, stream, ab);  \
-      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, PM, false, false>), grid, block, lds, stream, ab);         \
-    }                                                                                                                  \
-  } while (0)
-#define SERL_LAUNCH_CONV(WM, WN, TM, TN)                       \
-  do {                                                         \
-    if (pmode == 0) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 0);      \
-    else if (pmode == 1) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 1); \
-    else if (pmode == 2) SERL_LAUNCH_CONV2(WM, WN, TM, TN, 2); \
-    else SERL_LAUNCH_CONV2(WM, WN, TM, TN, 3);                 \
+    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 0>), grid, block, lds, stream, ab);      \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 1>), grid, block, lds, stream, ab); \
+    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 2>), grid, block, lds, stream, ab); \
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3>), grid, block, lds, stream, ab);                 \
   } while (0)
     if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
-    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 1, 2);
+    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
     else SERL_LAUNCH_CONV(2, 2, 1, 1);
 #undef SERL_LAUNCH_CONV
-#undef SERL_LAUNCH_CONV2
   }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {
     hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
     SERL_HIP(hipGetLastError());
+  }
+  return SERL_OK;
+}
+
+static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta, int P, int Cc) {
+  GnRef g{};
+  g.stats = stats; g.gamma = gamma; g.beta = beta;
+  g.inv_count = 1.0 / ((double)P * (Cc / kGnGroups));
+  g.gsize = Cc / kGnGroups;
+  return g;
+}
+
+// Trunk forward in split-fp16 arithmetic.  Activations between kernels live in the split16 layout;
+// raw conv outputs (pre-GroupNorm) and the final features stay fp32.
+int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
+                        float* feats_out, hipStream_t stream) {
+  const TrunkDims& d = ws.d;
+  constexpr int kLayers = 1 + 3 * kTrunkStages;
+  auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
+  SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
+  int rc;
+  if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo}, ws.raw_init, stats_of(0), N, d.H,
+                                   d.W, d.h[0], d.w[0], stream))) return rc;
+  {
+    const long tot = (long)N * d.h[1] * d.w[1] * 16;
+    ProfScope prof("gn_relu_maxpool", stream);
+    hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init,
+                       gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+                       reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
+    SERL_HIP(hipGetLastError());
+  }
+  const float* x = ws.pool;  // split16
+  int cin = 64;
+  static const char* kTags[kTrunkStages][3] = {{"conv_igemm/b0_conv0", "conv_igemm/b0_conv1", "conv_igemm/b0_proj"},
+                                                {"conv_igemm/b1_conv0", "conv_igemm/b1_conv1", "conv_igemm/b1_proj"},
+                                                {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
+                                                {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
+  for (int i = 0; i < kTrunkStages; ++i) {
+    const int f = kStageFilters[i], s = kStageStride[i];
+    const int Hi = d.h[1 + i], Wi = d.w[1 + i], Ho = d.h[2 + i], Wo = d.w[2 + i], P = Ho * Wo;
+    const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
+    const TrunkWeights::Block& bw = w.blk[i];
+    const bool has_proj = bw.proj != nullptr;
+    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo}; };
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    if (has_proj)
+      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
+    const long tot = (long)N * P * (f / 4);
+    {
+      ProfScope prof("gn_relu_split", stream);
+      hipLaunchKernelGGL(gn_relu_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw0,
+                         gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), reinterpret_cast<uint4*>(ws.blk[i].norm0), N, P, f);
+      SERL_HIP(hipGetLastError());
+    }
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
+    const bool last = i == kTrunkStages - 1;
+    {
+      ProfScope prof("block_out", stream);
+      hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,
+                         gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f),
+                         has_proj ? nullptr : reinterpret_cast<const uint4*>(x), has_proj ? ws.blk[i].rawp : nullptr,
+                         has_proj ? gn_ref_b(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f) : GnRef{},
+                         last ? nullptr : reinterpret_cast<uint4*>(ws.blk[i].out), last ? feats_out : nullptr, N, P, f);
+      SERL_HIP(hipGetLastError());
+    }
+    x = ws.blk[i].out;
+    cin = f;
   }
   return SERL_OK;
 }
