@@ -131,6 +131,7 @@ def main():
         learner.iteration(args.car)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -148,6 +149,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.check(_lib.lib().serl_profile_enable(0))
+    torch.cuda.synchronize()
     info = core.read_info()
     assert all(np.isfinite(v) for v in info.values()), info
     if world > 1:

@@ -280,7 +280,7 @@ size_t carve(serl_agent* a, void* base) {
   a->encO.enc = a->crit.x; a->encO.ld = a->XA;
   mlp(a->pol.m, B);
   a->pol.pre = b.take<float>(2 * B * A); a->pol.std = b.take<float>(B * A); a->pol.logp = b.take<float>(B);
-  long cap = std::max<long>({(long)c.n_cam * 8 * B * c.bottleneck, N * B * (long)a->XA, 4 * B * Hd, N * B * Hd});
+  long cap = std::max<long>({(long)c.n_cam * 32 * B * c.bottleneck, N * B * (long)a->XA, 8 * B * Hd, 4 * N * B * Hd});
   a->slabs_cap = cap;
   a->slabs = b.take<float>(cap);
   a->dq = b.take<float>(N * B); a->ytgt = b.take<float>(B);
@@ -320,13 +320,13 @@ int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uin
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const long Bfull = a->cur.batch;
-  for (int k = 0; k < c.n_cam; ++k) {
-    const float* x = a->feats + (((long)which * c.n_cam + k) * c.batch + off) * a->HW * 512;
-    const uint8_t* m = mask ? mask + ((long)k * Bfull + off) * a->D : nullptr;
-    RC(sle_fwd(x, P + o.cam[k].sle, m, 1.0f / (1.0f - c.dropout), e.f + (long)k * c.batch * a->D, cnt, a->HW,
-               512, st));
+  {  // SpatialLearnedEmbeddings (+ dropout) of every camera in one launch (grid.y = camera)
+    const float* x = a->feats + (((long)which * c.n_cam) * c.batch + off) * a->HW * 512;
+    const uint8_t* m = mask ? mask + (long)off * a->D : nullptr;
+    RC(sle_fwd(x, P + o.cam[0].sle, m, 1.0f / (1.0f - c.dropout), e.f, cnt, a->HW, 512, c.n_cam,
+               (long)c.batch * a->HW * 512, o.cam_stride, Bfull * a->D, (long)c.batch * a->D, st));
   }
-  const int S = 8;
+  const int S = 32;  // K = 4096 split 32 ways: 128-deep slices, 4 chunks per workgroup
   GemmDesc g{};
   g.A = e.f; g.sAm = a->D; g.sAk = 1; g.sAb = (long)c.batch * a->D;
   g.B = P + o.cam[0].dW; g.sBk = c.bottleneck; g.sBn = 1; g.sBb = o.cam_stride;
@@ -384,9 +384,9 @@ int policy_fwd(serl_agent* a, const float* P, const float* enc, long ld_enc, int
   const Offs& o = a->o;
   PolBuf& pb = a->pol;
   const int Hd = c.hidden, A = c.act_dim;
-  RC(dense_ln_tanh(a, enc, ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0, 1, cnt, a->E, 4,
+  RC(dense_ln_tanh(a, enc, ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0, 1, cnt, a->E, 8,
                    pb.m.h1, pb.m.xh1, pb.m.rs1, st));
-  RC(dense_ln_tanh(a, pb.m.h1, Hd, 0, P + o.a_w2, 0, P + o.a_b2, P + o.a_g2, P + o.a_be2, 0, 1, cnt, Hd, 2,
+  RC(dense_ln_tanh(a, pb.m.h1, Hd, 0, P + o.a_w2, 0, P + o.a_b2, P + o.a_g2, P + o.a_be2, 0, 1, cnt, Hd, 4,
                    pb.m.h2, pb.m.xh2, pb.m.rs2, st));
   GemmDesc g{};
   g.A = pb.m.h2; g.sAm = Hd; g.sAk = 1; g.sAb = 0;
@@ -404,9 +404,9 @@ int critic_fwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, hipStream_t 
   const Offs& o = a->o;
   const int Hd = c.hidden, N = c.ensemble;
   RC(dense_ln_tanh(a, cb.x, a->XA, 0, P + o.c_w1, (long)a->XA * Hd, P + o.c_b1, P + o.c_g1, P + o.c_be1, Hd, N,
-                   cnt, a->XA, 1, cb.m.h1, cb.m.xh1, cb.m.rs1, st));
+                   cnt, a->XA, 4, cb.m.h1, cb.m.xh1, cb.m.rs1, st));
   RC(dense_ln_tanh(a, cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2,
-                   P + o.c_be2, Hd, N, cnt, Hd, 1, cb.m.h2, cb.m.xh2, cb.m.rs2, st));
+                   P + o.c_be2, Hd, N, cnt, Hd, 2, cb.m.h2, cb.m.xh2, cb.m.rs2, st));
   return critic_head_fwd(cb.m.h2, P + o.c_hw, P + o.c_hb, cb.q, N * cnt, st);
 }
 

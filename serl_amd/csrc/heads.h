@@ -36,7 +36,7 @@ int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D
 int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
 int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
-            int Cc, hipStream_t stream);
+            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,
             hipStream_t stream);
 int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);

@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // element strides (transposes are free), zero-filled edges.  Slabs are summed by the consumer
 // (reduce_slabs / ln_tanh_fwd), which keeps the K-split deterministic.
 // =============================================================================================
-constexpr int kGBM = 64, kGBN = 64, kGBK = 16, kGP = 68;
+constexpr int kGBM = 64, kGBN = 64, kGBK = 32, kGP = 68;
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
   __shared__ float As[2][kGBK][kGP];
@@ -30,54 +30,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
   const float* B = g.B + (long)batch * g.sBb;
   float* C = g.C + (long)z * g.sCz;
   const bool a_kfast = g.sAk == 1, b_nfast = g.sBn == 1;
-  float ra[4], rb[4];
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m, k;
-      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
-      const int gm = m0 + m, gk = k0 + k;
-      ra[i] = (gm < g.M && gk < k_end) ? A[(long)gm * g.sAm + (long)gk * g.sAk] : 0.f;
-      int n, kb;
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      rb[i] = (gn < g.N && gkb < k_end) ? B[(long)gkb * g.sBk + (long)gn * g.sBn] : 0.f;
-    }
-  };
-  auto store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m, k;
-      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
-      As[buf][k][m] = ra[i];
-      int n, kb;
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-      Bs[buf][kb][n] = rb[i];
-    }
-  };
+  float ra[8], rb[8];
+#define SERL_GEMM_LOAD(K0)                                                                                   \
+  {                                                                                                          \
+    const int k0_ = (K0);                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+      int m, k;                                                                                              \
+      if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
+      const int gm = m0 + m, gk = k0_ + k;                                                                   \
+      ra[i] = (gm < g.M && gk < k_end) ? A[(long)gm * g.sAm + (long)gk * g.sAk] : 0.f;                       \
+      int n, kb;                                                                                             \
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 31; n = (tid >> 5) + 8 * i; } \
+      const int gn = n0 + n, gkb = k0_ + kb;                                                                 \
+      rb[i] = (gn < g.N && gkb < k_end) ? B[(long)gkb * g.sBk + (long)gn * g.sBn] : 0.f;                     \
+    }                                                                                                        \
+  }
+#define SERL_GEMM_STORE(BUF)                                                                                 \
+  {                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+      int m, k;                                                                                              \
+      if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
+      As[(BUF)][k][m] = ra[i];                                                                               \
+      int n, kb;                                                                                             \
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 31; n = (tid >> 5) + 8 * i; } \
+      Bs[(BUF)][kb][n] = rb[i];                                                                              \
+    }                                                                                                        \
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int li = lane & 31, lh = lane >> 5;
   if (k_begin < k_end) {
-    load(k_begin);
-    store(0);
+    SERL_GEMM_LOAD(k_begin);
+    SERL_GEMM_STORE(0);
     __syncthreads();
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += kGBK) {
-      const bool more = k0 + kGBK < k_end;
-      if (more) load(k0 + kGBK);
+      SERL_GEMM_LOAD(k0 + kGBK);  // past k_end this loads zeros (predicated), keeping the staging regs in SSA form
 #pragma unroll
       for (int ks = 0; ks < kGBK / 2; ++ks) {
         const float a = As[buf][2 * ks + lh][wm * 32 + li];
         const float b = Bs[buf][2 * ks + lh][wn * 32 + li];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
-      if (more) store(buf ^ 1);
+      SERL_GEMM_STORE(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
   }
+#undef SERL_GEMM_LOAD
+#undef SERL_GEMM_STORE
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -284,9 +286,12 @@ int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, i
 // (+ Dropout(0.1) keep-mask, resnet_v1.py:351).  F == 8.
 // =============================================================================================
 __global__ __launch_bounds__(256) void sle_fwd_kernel(const float* x, const float* K, const uint8_t* mask,
-                                                     float keep_scale, float* f, int N, int HW, int Cc) {
+                                                     float keep_scale, float* f, int N, int HW, int Cc, long xs,
+                                                     long ks, long ms, long fs) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)N * Cc) return;
+  x += blockIdx.y * xs; K += blockIdx.y * ks; f += blockIdx.y * fs;  // blockIdx.y = camera
+  if (mask) mask += blockIdx.y * ms;
   const int n = (int)(e / Cc), c = (int)(e - (long)n * Cc);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int hw = 0; hw < HW; ++hw) {
@@ -307,9 +312,9 @@ __global__ __launch_bounds__(256) void sle_fwd_kernel(const float* x, const floa
 }
 
 int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
-            int Cc, hipStream_t stream) {
-  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256)), dim3(256), 0, stream, x, K, mask,
-                     keep_scale, f, N, HW, Cc);
+            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream) {
+  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256), groups), dim3(256), 0, stream, x, K, mask,
+                     keep_scale, f, N, HW, Cc, x_gs, k_gs, mask_gs, f_gs);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -51,6 +51,10 @@ class SerialSchedule:
         import contextlib
         return contextlib.nullcontext()
 
+    def main(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     def produced(self, slot):
         pass
 
@@ -68,16 +72,23 @@ class TorchPipelineSchedule:
     """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream."""
     slots = 2
 
-    def __init__(self, device):
+    def __init__(self, device, prioritise_update=True):
         import torch
         self.torch = torch
         self.device = device
-        self.side_stream = torch.cuda.Stream(device=device)
+        # the update's long chain of small dependent kernels gets the high-priority queue so that it is
+        # not starved by the (throughput-bound) trunk kernels of the next batch
+        self.side_stream = torch.cuda.Stream(device=device, priority=0)
+        self.main_stream = torch.cuda.Stream(device=device, priority=-1) if prioritise_update else None
         self.ev_prod = [torch.cuda.Event() for _ in range(2)]
         self.ev_cons = [None, None]
 
     def side(self):
         return self.torch.cuda.stream(self.side_stream)
+
+    def main(self):
+        import contextlib
+        return self.torch.cuda.stream(self.main_stream) if self.main_stream is not None else contextlib.nullcontext()
 
     def produced(self, slot):
         self.ev_prod[slot].record(self.side_stream)
@@ -159,18 +170,20 @@ class DataParallelLearner:
 
     def update_critics(self):
         """DrQAgent.update_critics over the global batch (one grad-step)."""
-        slot = self._acquire()
-        self._critic()
-        self.sched.consumed(slot)
+        with self.sched.main():
+            slot = self._acquire()
+            self._critic()
+            self.sched.consumed(slot)
 
     def update_high_utd(self):
         """DrQAgent.update_high_utd(utd_ratio=1): critic step, then actor+temperature on the same batch."""
-        slot = self._acquire()
-        self._critic()
-        self.core.actor_grads(self.B, None)
-        self._reduce(APPLY_ACTOR_TEMP)
-        self.core.apply(APPLY_ACTOR_TEMP)
-        self.sched.consumed(slot)
+        with self.sched.main():
+            slot = self._acquire()
+            self._critic()
+            self.core.actor_grads(self.B, None)
+            self._reduce(APPLY_ACTOR_TEMP)
+            self.core.apply(APPLY_ACTOR_TEMP)
+            self.sched.consumed(slot)
 
     def iteration(self, critic_actor_ratio: int = 1):
         """One learner-loop iteration (examples/async_drq_sim/async_drq_sim.py:266-292)."""

@@ -231,3 +231,54 @@ def test_production_noise_runs(gpu):
     info = core.read_info()
     assert all(np.isfinite(v) for v in info.values()), info
     assert not np.array_equal(before, core.get("params", "actor/w1"))
+
+
+def test_grad_view_aliases_library_memory(gpu):
+    """The zero-copy torch view used for the RCCL all-reduce must alias the library's gradient buffer."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    _, core = AH.make_pair(cfg, 8)
+    sl, _ = AH.leaf_slices(cfg)
+    pc = sl["enc/proprio/ln/bias"][1]
+    v = core.grad_view(1)
+    assert v.is_cuda and v.dtype == torch.float32 and v.numel() == pc + 32
+    g = np.random.default_rng(0).standard_normal(pc).astype(np.float32)
+    core.debug_set("g_critic", g)
+    assert np.array_equal(v[:pc].cpu().numpy(), g)
+    v.mul_(2.0)                                    # what all_reduce(SUM) over 2 identical ranks would do
+    torch.cuda.synchronize()
+    assert np.array_equal(core.debug("g_critic", pc), 2 * g)
+    va = core.grad_view(2)
+    assert va.data_ptr() == v.data_ptr() + 4 * pc  # [scalars | actor grads] starts at the scalars
+
+
+def test_pipelined_schedule_matches_serial(gpu):
+    """trunk(i+1) overlapped with update(i) on a second stream gives bit-identical parameters."""
+    import itertools
+    from helpers import make_spaces
+    from serl_amd.agents.batch import DeviceBatch
+    from serl_amd.data.data_store import MemoryEfficientReplayBufferDataStore, gather_crop
+    from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
+    from serl_amd.utils.synthetic import transition_stream
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    outs = []
+    for sched_cls in (SerialSchedule, TorchPipelineSchedule):
+        _, core = AH.make_pair(cfg, 8, agent_seed=5)
+        osp, asp = make_spaces(cfg.image_keys, 64, 64, 3, 1, 5, 3)
+        rb = MemoryEfficientReplayBufferDataStore(osp, asp, 200, image_keys=cfg.image_keys)
+        rb.seed(0)
+        for tr in itertools.islice(transition_stream(cfg.image_keys, 64, 64, 3, 1, 5, 3, 20, 1), 120):
+            rb.insert(tr)
+        dbs = [DeviceBatch(8, 2, 64, 64, 3, 5, 3, 0) for _ in range(2)]
+
+        def gather(parts, co, cn, slot):
+            gather_crop(parts, co, cn, dbs[slot])
+            return dbs[slot]
+
+        sched = sched_cls() if sched_cls is SerialSchedule else sched_cls(torch.device("cuda", 0))
+        lr = DataParallelLearner(core, gather, [rb], [8], schedule=sched, seed=3)
+        for _ in range(4):
+            lr.iteration(critic_actor_ratio=2)
+        torch.cuda.synchronize()
+        outs.append({k: core.get("params", k) for k in ("critic/w1", "actor/w2", "enc/0/dense/kernel", "temp/lagrange")})
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
