@@ -9,6 +9,7 @@
 // EMA round-off (<= 1e-6 relative) -- the target copy is still maintained for export.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -710,6 +711,7 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
   const int B = batch->batch;
   const size_t fbytes = (size_t)c.H * c.W * 3;
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
+    // (sub-batching the run to keep activations in the Infinity Cache was measured: slower -- DESIGN.md)
     return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr);
   }
   for (int w = 0; w < 2; ++w)
