@@ -92,8 +92,16 @@ struct serl_agent {
   bool slot_valid[2] = {false, false};
   EncBuf encP{}, encT{}, encO{};
   CritBuf critT{}, crit{};
-  PolBuf pol{};
-  float* slabs = nullptr; long slabs_cap = 0;
+  PolBuf pol{}, polT{};
+  float* slabs = nullptr; long slabs_cap = 0;  // GEMM split-K scratch of the lane currently being enqueued
+  float* slabs_lane[3] = {nullptr, nullptr, nullptr};
+  // intra-update concurrency: independent chains of small kernels run on side streams (lanes 1, 2) and
+  // parameter-gradient work on `pg`; everything is forked from / joined back into the caller's stream
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipStream_t pg = nullptr, pg_main = nullptr;
+  hipEvent_t evp[32] = {nullptr};
+  int evi = 0;
+  bool concurrent = true;
   float *dq = nullptr, *ytgt = nullptr;
   float *dh2 = nullptr, *da2 = nullptr, *dg2 = nullptr, *dh1 = nullptr, *da1 = nullptr, *dg1 = nullptr;
   float *dx = nullptr, *dz = nullptr, *dgz = nullptr, *df = nullptr, *sle_part = nullptr;
@@ -279,11 +287,14 @@ size_t carve(serl_agent* a, void* base) {
   crit(a->critT); crit(a->crit);
   a->encT.enc = a->critT.x; a->encT.ld = a->XA;
   a->encO.enc = a->crit.x; a->encO.ld = a->XA;
-  mlp(a->pol.m, B);
-  a->pol.pre = b.take<float>(2 * B * A); a->pol.std = b.take<float>(B * A); a->pol.logp = b.take<float>(B);
+  for (PolBuf* pbuf : {&a->pol, &a->polT}) {
+    mlp(pbuf->m, B);
+    pbuf->pre = b.take<float>(2 * B * A); pbuf->std = b.take<float>(B * A); pbuf->logp = b.take<float>(B);
+  }
   long cap = std::max<long>({(long)c.n_cam * 32 * B * c.bottleneck, N * B * (long)a->XA, 8 * B * Hd, 4 * N * B * Hd});
   a->slabs_cap = cap;
-  a->slabs = b.take<float>(cap);
+  for (int k = 0; k < 3; ++k) a->slabs_lane[k] = b.take<float>(cap);
+  a->slabs = a->slabs_lane[0];
   a->dq = b.take<float>(N * B); a->ytgt = b.take<float>(B);
   a->dh2 = b.take<float>(N * B * Hd); a->da2 = b.take<float>(N * B * Hd); a->dg2 = b.take<float>(N * B * Hd);
   a->dh1 = b.take<float>(N * B * Hd); a->da1 = b.take<float>(N * B * Hd); a->dg1 = b.take<float>(N * B * Hd);
@@ -313,6 +324,29 @@ size_t carve(serl_agent* a, void* base) {
     int _rc = (x);       \
     if (_rc) return _rc; \
   } while (0)
+
+// ---- stream fork / join -------------------------------------------------------------------------
+int fork_to(serl_agent* a, hipStream_t from, hipStream_t to) {
+  if (from == to) return SERL_OK;
+  hipEvent_t e = a->evp[a->evi];
+  a->evi = (a->evi + 1) & 31;
+  SERL_HIP(hipEventRecord(e, from));
+  SERL_HIP(hipStreamWaitEvent(to, e, 0));
+  return SERL_OK;
+}
+// lane k: 0 = the caller's stream, 1/2 = side streams; selects the lane's split-K scratch as a side effect
+hipStream_t lane(serl_agent* a, hipStream_t main, int k) {
+  a->slabs = a->slabs_lane[k];
+  return (k == 0 || !a->concurrent) ? main : a->side[k - 1];
+}
+// stream for parameter-gradient kernels (off the critical input-gradient chain); forks from `st`
+hipStream_t pg_lane(serl_agent* a, hipStream_t st) {
+  if (!a->concurrent) return st;
+  (void)fork_to(a, st, a->pg);
+  return a->pg;
+}
+
+hipStream_t pgs(serl_agent* a, hipStream_t st) { return a->concurrent ? a->pg : st; }
 
 // ---- EncodingWrapper forward on precomputed trunk features (encoding.py:26-72) ------------------
 // which: 0 = observations, 1 = next_observations; samples [off, off+cnt) of the current batch.
@@ -379,11 +413,10 @@ int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const
 }
 
 // Policy forward + tanh-Gaussian sample (actor_critic_nets.py:179-227)
-int policy_fwd(serl_agent* a, const float* P, const float* enc, long ld_enc, int cnt, const float* eps,
+int policy_fwd(serl_agent* a, const float* P, PolBuf& pb, const float* enc, long ld_enc, int cnt, const float* eps,
                float* act_out, long ld_act, float* sum_logp, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
-  PolBuf& pb = a->pol;
   const int Hd = c.hidden, A = c.act_dim;
   RC(dense_ln_tanh(a, enc, ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0, 1, cnt, a->E, 8,
                    pb.m.h1, pb.m.xh1, pb.m.rs1, st));
@@ -426,7 +459,7 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
   l.dx = dpre; l.dg = dg;
   RC(ln_tanh_bwd(l, D, st));
   if (G) {
-    RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, st));
+    RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, pg_lane(a, st)));
   }
   return SERL_OK;
 }
@@ -473,12 +506,12 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
                        N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st));
   if (pg)
     RC(wgrad(cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
-             cnt, st));
+             cnt, pgs(a, st)));
   RC(igrad(a->da2, Hd, (long)cnt * Hd, P + o.c_w2, Hd, (long)Hd * Hd, a->dh1, Hd, (long)cnt * Hd, N, cnt, Hd, Hd, st));
   RC(dense_ln_tanh_bwd(a, a->dh1, Hd, (long)cnt * Hd, cb.m.h1, Hd, (long)cnt * Hd, cb.m.xh1, cb.m.rs1, P + o.c_g1, Hd,
                        N, cnt, Hd, a->da1, a->dg1, G, o.c_g1, o.c_be1, o.c_b1, Hd, st));
   if (pg)
-    RC(wgrad(cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, st));
+    RC(wgrad(cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, pgs(a, st)));
   // dx = sum_e da1[e] * W1[e]^T
   RC(igrad(a->da1, Hd, (long)cnt * Hd, P + o.c_w1, Hd, (long)a->XA * Hd, a->slabs, a->XA, (long)cnt * a->XA, N, cnt,
            a->XA, Hd, st));
@@ -495,7 +528,7 @@ int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt
                        c.n_cam, cnt, Bn, a->dz, a->dgz, a->Gc, o.cam[0].lng, o.cam[0].lnb, o.cam[0].db,
                        o.cam_stride, st));
   RC(wgrad(e.f, a->D, (long)c.batch * a->D, a->dz, Bn, (long)cnt * Bn, a->Gc + o.cam[0].dW, Bn, o.cam_stride,
-           c.n_cam, a->D, Bn, cnt, st));
+           c.n_cam, a->D, Bn, cnt, pgs(a, st)));
   RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
            a->D, Bn, st));
   const long sle_n = (long)a->HW * 512 * c.sle_features;
@@ -517,7 +550,7 @@ int proprio_bwd(serl_agent* a, const float* P, const float* dy, long ld_dy, cons
   RC(dense_ln_tanh_bwd(a, dy, ld_dy, 0, y, ld_y, 0, e.pxhat, e.prstd, P + o.p_g, 0, 1, cnt, Pd, a->dp, a->dgp, G,
                        o.p_g - base_off, o.p_be - base_off, o.p_b - base_off, 0, st));
   const float* s = a->cur.state + ((long)which * a->cur.batch + off) * c.state_dim;
-  return wgrad(s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, st);
+  return wgrad(s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, pgs(a, st));
 }
 
 int fetch_noise(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot, int cnt_total,
@@ -581,6 +614,18 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   carve(a, a->arena);
   SERL_HIP(hipMemset(a->arena, 0, bytes));
   bind_trunk_weights(a);
+  {
+    // intra-update multi-stream concurrency is correct but measured 2-3x SLOWER (every cross-stream event wait
+    // costs tens of microseconds on this stack, more than the small kernels it overlaps): off unless
+    // SERL_HEADS_STREAMS=1.  The update chain is shortened by batching/fusing its kernels instead.
+    const char* e = getenv("SERL_HEADS_STREAMS");
+    a->concurrent = e && e[0] == '1';
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+    for (int k = 0; k < 2; ++k) SERL_HIP(hipStreamCreateWithPriority(&a->side[k], hipStreamNonBlocking, hi));
+    SERL_HIP(hipStreamCreateWithPriority(&a->pg, hipStreamNonBlocking, hi));
+    for (int k = 0; k < 32; ++k) SERL_HIP(hipEventCreateWithFlags(&a->evp[k], hipEventDisableTiming));
+  }
   *out = a;
   return SERL_OK;
 }
@@ -589,6 +634,11 @@ int serl_agent_destroy(serl_agent* a) {
   if (!a) return SERL_OK;
   (void)hipSetDevice(a->cfg.device);
   (void)hipDeviceSynchronize();
+  for (int k = 0; k < 2; ++k)
+    if (a->side[k]) (void)hipStreamDestroy(a->side[k]);
+  if (a->pg) (void)hipStreamDestroy(a->pg);
+  for (int k = 0; k < 32; ++k)
+    if (a->evp[k]) (void)hipEventDestroy(a->evp[k]);
   if (a->arena) (void)hipFree(a->arena);
   delete a;
   return SERL_OK;
@@ -764,23 +814,36 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
   const float* eps; const uint8_t* mask;
   RC(fetch_noise(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask, st));
   const int A = c.act_dim;
-  // next actions from the online policy at next_obs (train=True: dropout) -> critT.x[:, E:]
-  RC(encode(a, a->theta, 1, off, cnt, mask, a->encP, st));
-  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, st));
-  // target critic at next_obs with target_params (encoder train=False)
-  RC(encode(a, a->theta_t, 1, off, cnt, nullptr, a->encT, st));
-  RC(critic_fwd(a, a->theta_t, a->critT, cnt, st));
-  // online critic at obs, batch actions
-  RC(encode(a, a->theta, 0, off, cnt, nullptr, a->encO, st));
-  RC(copy_cols(a->cur.action + (long)off * A, A, a->crit.x + a->E, a->XA, cnt, A, st));
-  RC(critic_fwd(a, a->theta, a->crit, cnt, st));
+  // three independent chains: lane 1 = online policy at next_obs (dropout) then the target critic,
+  // lane 2 = target encoder at next_obs, lane 0 (caller's stream) = online critic at obs
+  hipStream_t s1 = lane(a, st, 1);
+  RC(fork_to(a, st, s1));
+  RC(encode(a, a->theta, 1, off, cnt, mask, a->encP, s1));
+  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, cnt, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, s1));
+  hipStream_t s2 = lane(a, st, 2);
+  RC(fork_to(a, st, s2));
+  RC(encode(a, a->theta_t, 1, off, cnt, nullptr, a->encT, s2));  // target_params, encoder train=False
+  RC(fork_to(a, s2, s1));
+  s1 = lane(a, st, 1);
+  RC(critic_fwd(a, a->theta_t, a->critT, cnt, s1));
+  hipStream_t s0 = lane(a, st, 0);
+  RC(encode(a, a->theta, 0, off, cnt, nullptr, a->encO, s0));
+  RC(copy_cols(a->cur.action + (long)off * A, A, a->crit.x + a->E, a->XA, cnt, A, s0));
+  RC(critic_fwd(a, a->theta, a->crit, cnt, s0));
+  RC(fork_to(a, s1, s0));
   const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
   RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
-                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st));
-  RC(critic_bwd(a, a->theta, a->crit, cnt, true, st));
-  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
+                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, s0));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, true, s0));
+  // proprio branch on lane 2 while the camera heads run on the caller's stream
+  s2 = lane(a, st, 2);
+  RC(fork_to(a, s0, s2));
   RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
-                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
+                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, s2));
+  s0 = lane(a, st, 0);
+  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, s0));
+  RC(fork_to(a, s2, s0));
+  RC(fork_to(a, pgs(a, s0), s0));
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -797,38 +860,49 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   RC(fetch_noise(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi, st));
   RC(fetch_noise(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t, st));
   RC(temperature_alpha(a->theta + o.lam, a->aux + X_ALPHA, st));
-  // temperature loss first (its activations are not needed afterwards): entropy of pi(next_obs)
-  RC(encode(a, a->theta, 1, 0, cnt, mask_t, a->encP, st));
-  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps_t, a->act_tmp, A, a->SC + S_LOGP_NEXT, st));
-  // policy loss: a ~ pi_params(obs) (dropout), Q_theta(obs, a) with theta constant (sac.py:193-221)
-  RC(encode(a, a->theta, 0, 0, cnt, mask_pi, a->encP, st));
-  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, cnt, eps_pi, a->crit.x + a->E, a->XA, a->SC + S_LOGP, st));
-  RC(encode(a, a->theta, 0, 0, cnt, nullptr, a->encO, st));
-  RC(critic_fwd(a, a->theta, a->crit, cnt, st));
-  RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, st));
-  RC(fill(a->dq, -1.0f / ((float)c.ensemble * (float)global_count), (long)c.ensemble * cnt, st));
-  RC(critic_bwd(a, a->theta, a->crit, cnt, false, st));
+  // lane 1: temperature loss = entropy of pi(next_obs) (sac.py:223-234); lane 2: critic-side encoding of obs
+  // (train=False); caller's stream: policy loss chain (sac.py:193-221)
+  hipStream_t s1 = lane(a, st, 1);
+  RC(fork_to(a, st, s1));
+  RC(encode(a, a->theta, 1, 0, cnt, mask_t, a->encT, s1));
+  RC(policy_fwd(a, a->theta, a->polT, a->encT.enc, a->encT.ld, cnt, eps_t, a->act_tmp, A, a->SC + S_LOGP_NEXT, s1));
+  hipStream_t s2 = lane(a, st, 2);
+  RC(fork_to(a, st, s2));
+  RC(encode(a, a->theta, 0, 0, cnt, nullptr, a->encO, s2));
+  hipStream_t s0 = lane(a, st, 0);
+  RC(encode(a, a->theta, 0, 0, cnt, mask_pi, a->encP, s0));
+  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, cnt, eps_pi, a->crit.x + a->E, a->XA, a->SC + S_LOGP, s0));
+  RC(fork_to(a, s2, s0));
+  RC(critic_fwd(a, a->theta, a->crit, cnt, s0));
+  RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, s0));
+  RC(fill(a->dq, -1.0f / ((float)c.ensemble * (float)global_count), (long)c.ensemble * cnt, s0));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0));
   RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
-                     1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, st));
-  // policy heads (mean, log_std): nbatch = 2 with uniform stride
+                     1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, s0));
+  // policy heads (mean, log_std): nbatch = 2 with uniform stride; parameter gradients off the critical chain
   const long hs = o.a_Ws - o.a_Wm;
   float* Ga = a->Ga;
   const long b0 = o.Pa0;
-  RC(wgrad(a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, st));
-  RC(colsum(a->dpre, nullptr, 2, cnt, A, Ga + (o.a_bm - b0), hs, false, st));
-  RC(igrad(a->dpre, A, (long)cnt * A, a->theta + o.a_Wm, A, hs, a->slabs, Hd, (long)cnt * Hd, 2, cnt, Hd, A, st));
-  RC(reduce_slabs(a->slabs, 2, (long)cnt * Hd, 1, cnt, Hd, nullptr, 0, a->dh2, Hd, 0, false, st));
+  {
+    hipStream_t pg = pg_lane(a, s0);
+    RC(wgrad(a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, pg));
+    RC(colsum(a->dpre, nullptr, 2, cnt, A, Ga + (o.a_bm - b0), hs, false, pg));
+  }
+  RC(igrad(a->dpre, A, (long)cnt * A, a->theta + o.a_Wm, A, hs, a->slabs, Hd, (long)cnt * Hd, 2, cnt, Hd, A, s0));
+  RC(reduce_slabs(a->slabs, 2, (long)cnt * Hd, 1, cnt, Hd, nullptr, 0, a->dh2, Hd, 0, false, s0));
   RC(dense_ln_tanh_bwd(a, a->dh2, Hd, 0, a->pol.m.h2, Hd, 0, a->pol.m.xh2, a->pol.m.rs2, a->theta + o.a_g2, 0, 1, cnt, Hd,
-                       a->da2, a->dg2, Ga, o.a_g2 - b0, o.a_be2 - b0, o.a_b2 - b0, 0, st));
-  RC(wgrad(a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, st));
-  RC(igrad(a->da2, Hd, 0, a->theta + o.a_w2, Hd, 0, a->dh1, Hd, 0, 1, cnt, Hd, Hd, st));
+                       a->da2, a->dg2, Ga, o.a_g2 - b0, o.a_be2 - b0, o.a_b2 - b0, 0, s0));
+  RC(wgrad(a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, pgs(a, s0)));
+  RC(igrad(a->da2, Hd, 0, a->theta + o.a_w2, Hd, 0, a->dh1, Hd, 0, 1, cnt, Hd, Hd, s0));
   RC(dense_ln_tanh_bwd(a, a->dh1, Hd, 0, a->pol.m.h1, Hd, 0, a->pol.m.xh1, a->pol.m.rs1, a->theta + o.a_g1, 0, 1, cnt, Hd,
-                       a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, st));
-  RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, st));
+                       a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, s0));
+  RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, pgs(a, s0)));
   // image codes are stop-gradiented (encoding.py:48-49); only the proprio slice of d_enc is needed
   const long pc = (long)c.n_cam * c.bottleneck;
-  RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, st));
-  RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, st));
+  RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, s0));
+  RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, s0));
+  RC(fork_to(a, s1, s0));
+  RC(fork_to(a, pgs(a, s0), s0));
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -938,7 +1012,7 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
     RC(fill(a->eps_buf[0], 0.f, (long)n * c.act_dim, st));
     dev_eps = a->eps_buf[0];
   }
-  RC(policy_fwd(a, a->theta, a->encP.enc, a->encP.ld, n, dev_eps, dev_out_actions, c.act_dim, nullptr, st));
+  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, n, dev_eps, dev_out_actions, c.act_dim, nullptr, st));
   a->cur = saved;
   a->has_batch = had;
   a->feats = saved_feats;
