@@ -302,7 +302,7 @@ size_t carve(serl_agent* a, void* base) {
   a->dz = b.take<float>((long)c.n_cam * B * c.bottleneck);
   a->dgz = b.take<float>((long)c.n_cam * B * c.bottleneck);
   a->df = b.take<float>((long)c.n_cam * B * a->D);
-  a->sle_part = b.take<float>((long)kSleSplit * a->HW * 512 * c.sle_features);
+  a->sle_part = b.take<float>((long)c.n_cam * kSleSplit * a->HW * 512 * c.sle_features);
   a->dp = b.take<float>(B * c.proprio_dim); a->dgp = b.take<float>(B * c.proprio_dim);
   a->dpre = b.take<float>(2 * B * A); a->dprop_y = b.take<float>(B * c.proprio_dim);
   for (int k = 0; k < 3; ++k) {
@@ -375,27 +375,17 @@ int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uin
   l.y = e.enc; l.ld_y = e.ld; l.y_goff = c.bottleneck;
   l.xhat = e.xhat; l.rstd = e.rstd;
   RC(ln_tanh_fwd(l, c.bottleneck, st));
-  // proprio branch (encoding.py:55-70)
-  GemmDesc p{};
-  p.A = a->cur.state + ((long)which * Bfull + off) * c.state_dim; p.sAm = c.state_dim; p.sAk = 1; p.sAb = 0;
-  p.B = P + o.p_W; p.sBk = c.proprio_dim; p.sBn = 1; p.sBb = 0;
-  p.C = a->slabs; p.ldc = c.proprio_dim; p.sCz = (long)cnt * c.proprio_dim;
-  p.M = cnt; p.N = c.proprio_dim; p.K = c.state_dim; p.nbatch = 1; p.splitk = 1;
-  RC(gemm_f32(p, st));
-  LnFwdArgs lp{};
-  lp.slabs = a->slabs; lp.S = 1; lp.slab_stride = p.sCz;
-  lp.bias = P + o.p_b; lp.gamma = P + o.p_g; lp.beta = P + o.p_be; lp.pstride = 0;
-  lp.rows = cnt; lp.rows_per_group = cnt;
-  lp.y = e.enc + (long)c.n_cam * c.bottleneck; lp.ld_y = e.ld; lp.y_goff = 0;
-  lp.xhat = e.pxhat; lp.rstd = e.prstd;
-  RC(ln_tanh_fwd(lp, c.proprio_dim, st));
+  // proprio branch (encoding.py:55-70): one fused kernel
+  RC(proprio_fwd(a->cur.state + ((long)which * Bfull + off) * c.state_dim, c.state_dim, P + o.p_W, P + o.p_b, P + o.p_g,
+                 P + o.p_be, cnt, e.enc + (long)c.n_cam * c.bottleneck, e.ld, e.pxhat, e.prstd, st));
   return SERL_OK;
 }
 
 // generic Dense -> LN -> tanh layer on `rows_per_group` rows for `groups` parameter groups
 int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const float* W, long w_gstride,
                   const float* bias, const float* gamma, const float* beta, long p_gstride, int groups,
-                  int rows_per_group, int K, int splitk, float* y, float* xhat, float* rstd, hipStream_t st) {
+                  int rows_per_group, int K, int splitk, float* y, float* xhat, float* rstd, hipStream_t st,
+                  const float* dot_w = nullptr, const float* dot_b = nullptr, float* dot_out = nullptr) {
   const int Hd = a->cfg.hidden;
   GemmDesc g{};
   g.A = X; g.sAm = ldx; g.sAk = 1; g.sAb = x_gstride;
@@ -409,6 +399,7 @@ int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const
   l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
   l.y = y; l.ld_y = Hd; l.y_goff = (long)rows_per_group * Hd;
   l.xhat = xhat; l.rstd = rstd;
+  l.dot_w = dot_w; l.dot_b = dot_b; l.dot_out = dot_out;
   return ln_tanh_fwd(l, Hd, st);
 }
 
@@ -428,8 +419,8 @@ int policy_fwd(serl_agent* a, const float* P, PolBuf& pb, const float* enc, long
   g.C = a->slabs; g.ldc = A; g.sCz = (long)cnt * A;
   g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 1;
   RC(gemm_f32(g, st));
-  RC(reduce_slabs(a->slabs, 1, g.sCz, 2, cnt, A, P + o.a_bm, o.a_bs - o.a_bm, pb.pre, A, (long)cnt * A, false, st));
-  return policy_dist_fwd(pb.pre, eps, cnt, A, c.std_min, c.std_max, act_out, ld_act, pb.logp, pb.std, sum_logp, st);
+  return policy_dist_fwd(a->slabs, P + o.a_bm, P + o.a_bs, pb.pre, eps, cnt, A, c.std_min, c.std_max, act_out, ld_act,
+                         pb.logp, pb.std, sum_logp, st);
 }
 
 // Critic ensemble forward on x = [enc | action] (actor_critic_nets.py:56-73, drq.py:201-207)
@@ -440,8 +431,8 @@ int critic_fwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, hipStream_t 
   RC(dense_ln_tanh(a, cb.x, a->XA, 0, P + o.c_w1, (long)a->XA * Hd, P + o.c_b1, P + o.c_g1, P + o.c_be1, Hd, N,
                    cnt, a->XA, 4, cb.m.h1, cb.m.xh1, cb.m.rs1, st));
   RC(dense_ln_tanh(a, cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2,
-                   P + o.c_be2, Hd, N, cnt, Hd, 2, cb.m.h2, cb.m.xh2, cb.m.rs2, st));
-  return critic_head_fwd(cb.m.h2, P + o.c_hw, P + o.c_hb, cb.q, N * cnt, st);
+                   P + o.c_be2, Hd, N, cnt, Hd, 2, cb.m.h2, cb.m.xh2, cb.m.rs2, st, P + o.c_hw, P + o.c_hb, cb.q));
+  return SERL_OK;  // shared Q head fused into the LN kernel of layer 2
 }
 
 // backward of one Dense->LN->tanh layer.  dy: [groups*rows][Hd] gradient wrt the layer output.
@@ -450,13 +441,15 @@ int critic_fwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, hipStream_t 
 int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, const float* y, long ld_y,
                       long y_goff, const float* xhat, const float* rstd, const float* gamma, long p_gstride,
                       int groups, int rows_per_group, int D, float* dpre, float* dg, float* G, long g_off,
-                      long be_off, long b_off, long pg_gstride, hipStream_t st) {
+                      long be_off, long b_off, long pg_gstride, hipStream_t st, const float* dq = nullptr,
+                      const float* dq_w = nullptr, float dq_const = 0.f) {
   LnBwdArgs l{};
   l.dy = dy; l.ld_dy = ld_dy; l.dy_goff = dy_goff;
   l.y = y; l.ld_y = ld_y; l.y_goff = y_goff;
   l.xhat = xhat; l.rstd = rstd; l.gamma = gamma; l.pstride = p_gstride;
   l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
   l.dx = dpre; l.dg = dg;
+  l.dq = dq; l.dq_w = dq_w; l.dq_const = dq_const;
   RC(ln_tanh_bwd(l, D, st));
   if (G) {
     RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, pg_lane(a, st)));
@@ -487,7 +480,9 @@ int igrad(const float* dY, long ldy, long dy_gstride, const float* W, long ldw, 
 }
 
 // Critic backward from dq [ens][cnt] down to dx [cnt][E+A]; parameter grads into Gc when `pg`.
-int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hipStream_t st) {
+// dq: [ens][cnt] gradient wrt Q, or nullptr with the constant `dq_const` for every element (actor loss)
+int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hipStream_t st, const float* dq,
+               float dq_const) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const int Hd = c.hidden, N = c.ensemble;
@@ -501,9 +496,9 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
     RC(gemm_f32(g, st));
     RC(reduce_slabs(a->slabs, 8, Hd, 1, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, 0, false, st));
   }
-  RC(critic_head_bwd_input(a->dq, P + o.c_hw, a->dh2, N * cnt, st));
-  RC(dense_ln_tanh_bwd(a, a->dh2, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
-                       N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st));
+  // gradient through the shared head dh2 = dq (x) w is formed inside the LN backward kernel (rank-1 mode)
+  RC(dense_ln_tanh_bwd(a, nullptr, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
+                       N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st, dq, P + o.c_hw, dq_const));
   if (pg)
     RC(wgrad(cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
              cnt, pgs(a, st)));
@@ -532,11 +527,12 @@ int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt
   RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
            a->D, Bn, st));
   const long sle_n = (long)a->HW * 512 * c.sle_features;
-  for (int k = 0; k < c.n_cam; ++k) {
-    const float* x = a->feats + (((long)0 * c.n_cam + k) * c.batch + off) * a->HW * 512;
-    RC(sle_bwd(x, a->df + (long)k * cnt * a->D, a->sle_part, cnt, a->HW, 512, kSleSplit, st));
-    RC(reduce_slabs(a->sle_part, kSleSplit, sle_n, 1, 1, (int)sle_n, nullptr, 0, a->Gc + o.cam[k].sle, sle_n, 0,
-                    false, st));
+  {  // dK of every camera: one partial-sum launch (grid.z = camera x batch split) + one reduction
+    const float* x = a->feats + (long)off * a->HW * 512;
+    RC(sle_bwd(x, a->df, a->sle_part, cnt, a->HW, 512, kSleSplit, c.n_cam, (long)c.batch * a->HW * 512,
+               (long)cnt * a->D, (long)kSleSplit * sle_n, st));
+    RC(reduce_slabs(a->sle_part, kSleSplit, sle_n, c.n_cam, 1, (int)sle_n, nullptr, 0, a->Gc + o.cam[0].sle, sle_n,
+                    o.cam_stride, false, st));
   }
   return SERL_OK;
 }
@@ -834,7 +830,7 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
   const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
   RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
                  inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, s0));
-  RC(critic_bwd(a, a->theta, a->crit, cnt, true, s0));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, true, s0, a->dq, 0.f));
   // proprio branch on lane 2 while the camera heads run on the caller's stream
   s2 = lane(a, st, 2);
   RC(fork_to(a, s0, s2));
@@ -875,8 +871,7 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   RC(fork_to(a, s2, s0));
   RC(critic_fwd(a, a->theta, a->crit, cnt, s0));
   RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, s0));
-  RC(fill(a->dq, -1.0f / ((float)c.ensemble * (float)global_count), (long)c.ensemble * cnt, s0));
-  RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0, nullptr, -1.0f / ((float)c.ensemble * (float)global_count)));
   RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
                      1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, s0));
   // policy heads (mean, log_std): nbatch = 2 with uniform stride; parameter gradients off the critical chain

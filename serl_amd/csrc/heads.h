@@ -17,11 +17,15 @@ struct LnFwdArgs {
   float* y; long ld_y; long y_goff;  // y[local_row*ld_y + group*y_goff + col] (column slices / group blocks)
   float* xhat;           // [rows][D] or nullptr
   float* rstd;           // [rows] or nullptr
+  // optional fused row-dot (critic head, actor_critic_nets.py:65-73): dot_out[row] = sum_col y*dot_w + dot_b[0]
+  const float* dot_w; const float* dot_b; float* dot_out;
 };
 int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream);
 
 struct LnBwdArgs {
-  const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y
+  const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y (ignored in rank-1 mode)
+  // rank-1 mode (gradient through the critic head): dy[row][col] = (dq ? dq[row] : dq_const) * dq_w[col]
+  const float* dq; const float* dq_w; float dq_const;
   const float* y; long ld_y; long y_goff;
   const float* xhat; const float* rstd;
   const float* gamma; long pstride;
@@ -37,15 +41,20 @@ int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, i
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
 int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
             int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream);
-int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,
-            hipStream_t stream);
+int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
+            long x_gs, long df_gs, long part_gs, hipStream_t stream);
 int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);
 int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream);
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
                 hipStream_t stream);
-int policy_dist_fwd(const float* pre, const float* eps, int B, int A, float std_min, float std_max, float* act,
-                    long ld_act, float* logp, float* std_out, float* sum_logp, hipStream_t stream);
+// slabs: [2][B][A] raw head GEMM outputs (mean, log_std); biases added here and the result kept in `pre`
+int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
+                    int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
+                    float* sum_logp, hipStream_t stream);
+// proprio branch: y = tanh(LN(state W + b)) with W [S][64] (encoding.py:55-70), one wave per row
+int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
+                int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream);
 int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
                     float std_min, float std_max, float* dpre, hipStream_t stream);

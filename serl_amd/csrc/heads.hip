@@ -133,13 +133,35 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(LnFwdArgs a) {
   const int grp = row / a.rows_per_group;
   constexpr int D = VPL * 64;
   float v[VPL];
+  if (VPL == 4) {  // 16-byte loads, 4 independent slab reads in flight
+    const float* sp = a.slabs + (long)grp * a.S * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + lane * 4;
+    float4 acc4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long)grp * a.pstride + lane * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= a.S; s += 4) {
+      const float4 x0 = *reinterpret_cast<const float4*>(sp + (long)(s + 0) * a.slab_stride);
+      const float4 x1 = *reinterpret_cast<const float4*>(sp + (long)(s + 1) * a.slab_stride);
+      const float4 x2 = *reinterpret_cast<const float4*>(sp + (long)(s + 2) * a.slab_stride);
+      const float4 x3 = *reinterpret_cast<const float4*>(sp + (long)(s + 3) * a.slab_stride);
+      acc4.x += x0.x; acc4.y += x0.y; acc4.z += x0.z; acc4.w += x0.w;
+      acc4.x += x1.x; acc4.y += x1.y; acc4.z += x1.z; acc4.w += x1.w;
+      acc4.x += x2.x; acc4.y += x2.y; acc4.z += x2.z; acc4.w += x2.w;
+      acc4.x += x3.x; acc4.y += x3.y; acc4.z += x3.z; acc4.w += x3.w;
+    }
+    for (; s < a.S; ++s) {
+      const float4 x0 = *reinterpret_cast<const float4*>(sp + (long)s * a.slab_stride);
+      acc4.x += x0.x; acc4.y += x0.y; acc4.z += x0.z; acc4.w += x0.w;
+    }
+    v[0] = acc4.x; v[VPL > 1 ? 1 : 0] = acc4.y; v[VPL > 2 ? 2 : 0] = acc4.z; v[VPL > 3 ? 3 : 0] = acc4.w;
+  } else {
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const int col = lane * VPL + j;
-    float x = a.bias ? a.bias[(long)grp * a.pstride + col] : 0.f;
-    for (int s = 0; s < a.S; ++s)
-      x += a.slabs[(long)(grp * a.S + s) * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + col];
-    v[j] = x;
+    for (int j = 0; j < VPL; ++j) {
+      const int col = lane * VPL + j;
+      float x = a.bias ? a.bias[(long)grp * a.pstride + col] : 0.f;
+      for (int s = 0; s < a.S; ++s)
+        x += a.slabs[(long)(grp * a.S + s) * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + col];
+      v[j] = x;
+    }
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -158,6 +180,18 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(LnFwdArgs a) {
     if (a.xhat) a.xhat[(long)row * D + col] = xh;
   }
   if (a.rstd && lane == 0) a.rstd[row] = rstd;
+  if (a.dot_out) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int col = lane * VPL + j;
+      const float xh = (v[j] - mean) * rstd;
+      d += tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]) * a.dot_w[col];
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off);
+    if (lane == 0) a.dot_out[row] = d + a.dot_b[0];
+  }
 }
 
 int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream) {
@@ -184,7 +218,8 @@ __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(LnBwdArgs a) {
     const int col = lane * VPL + j;
     const long lr = row - grp * a.rows_per_group;
     const float y = a.y[lr * a.ld_y + (long)grp * a.y_goff + col];
-    const float dy = a.dy[lr * a.ld_dy + (long)grp * a.dy_goff + col];
+    const float dy = a.dq_w ? (a.dq ? a.dq[row] : a.dq_const) * a.dq_w[col]
+                            : a.dy[lr * a.ld_dy + (long)grp * a.dy_goff + col];
     dg[j] = dy * (1.f - y * y);
     xh[j] = a.xhat[(long)row * D + col];
     dxh[j] = dg[j] * a.gamma[(long)grp * a.pstride + col];
@@ -321,9 +356,10 @@ int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scal
 
 // dK partial[split][hw][c][j] = sum_{n in split} x[n][hw][c] * df[n][c*8+j]
 __global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const float* df, float* partial, int N,
-                                                     int HW, int Cc, int nsplit) {
-  const int c = blockIdx.x * 256 + threadIdx.x, hw = blockIdx.y, sp = blockIdx.z;
+                                                     int HW, int Cc, int nsplit, long x_gs, long df_gs, long part_gs) {
+  const int c = blockIdx.x * 256 + threadIdx.x, hw = blockIdx.y, sp = blockIdx.z % nsplit, grp = blockIdx.z / nsplit;
   if (c >= Cc) return;
+  x += grp * x_gs; df += grp * df_gs; partial += grp * part_gs;  // grp = camera
   const int per = (N + nsplit - 1) / nsplit;
   const int nb = sp * per, ne = min(N, nb + per);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -339,10 +375,10 @@ __global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const floa
   *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit,
-            hipStream_t stream) {
-  hipLaunchKernelGGL(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit), dim3(256), 0, stream, x, df, partial, N,
-                     HW, Cc, nsplit);
+int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
+            long x_gs, long df_gs, long part_gs, hipStream_t stream) {
+  hipLaunchKernelGGL(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit * groups), dim3(256), 0, stream, x, df, partial, N,
+                     HW, Cc, nsplit, x_gs, df_gs, part_gs);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -437,15 +473,19 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
 // =============================================================================================
 __device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
-__global__ void policy_dist_fwd_kernel(const float* pre, const float* eps, int B, int A, float std_min,
-                                       float std_max, float* act, long ld_act, float* logp, float* std_out,
+__global__ void policy_dist_fwd_kernel(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre,
+                                       const float* eps, int B, int A, float std_min, float std_max, float* act,
+                                       long ld_act, float* logp, float* std_out,
                                        float* sum_logp /* nullable: scalar accumulated by one block */) {
   __shared__ float red[256];
   float local = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) {
-      const float mean = pre[(long)b * A + j], ls = pre[((long)B + b) * A + j], e = eps[(long)b * A + j];
+      const float mean = slabs[(long)b * A + j] + bias_mean[j], ls = slabs[((long)B + b) * A + j] + bias_ls[j];
+      const float e = eps[(long)b * A + j];
+      pre[(long)b * A + j] = mean;
+      pre[((long)B + b) * A + j] = ls;
       const float sd = fminf(fmaxf(expf(ls), std_min), std_max);
       const float u = mean + sd * e;
       act[(long)b * ld_act + j] = tanhf(u);
@@ -465,10 +505,38 @@ __global__ void policy_dist_fwd_kernel(const float* pre, const float* eps, int B
   if (threadIdx.x == 0 && sum_logp) *sum_logp = red[0];
 }
 
-int policy_dist_fwd(const float* pre, const float* eps, int B, int A, float std_min, float std_max, float* act,
-                    long ld_act, float* logp, float* std_out, float* sum_logp, hipStream_t stream) {
-  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(1), dim3(256), 0, stream, pre, eps, B, A, std_min, std_max,
-                     act, ld_act, logp, std_out, sum_logp);
+int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
+                    int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
+                    float* sum_logp, hipStream_t stream) {
+  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(1), dim3(256), 0, stream, slabs, bias_mean, bias_ls, pre, eps, B, A,
+                     std_min, std_max, act, ld_act, logp, std_out, sum_logp);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// proprio branch (encoding.py:55-70): y = tanh(LayerNorm_1e-6(state W + b)), W [S][64]; one wave per row,
+// lane = output feature.  Replaces a GEMM + LN launch pair for this tiny layer.
+__global__ __launch_bounds__(256) void proprio_fwd_kernel(const float* state, int S, const float* W, const float* b,
+                                                         const float* gamma, const float* beta, int rows, float* y,
+                                                         long ld_y, float* xhat, float* rstd_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v = b[lane];
+  for (int s = 0; s < S; ++s) v += state[(long)row * S + s] * W[s * 64 + lane];
+  float s1 = v, s2 = v * v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float mean = s1 * (1.0f / 64), var = fmaxf(s2 * (1.0f / 64) - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-6f), xh = (v - mean) * rstd;
+  y[(long)row * ld_y + lane] = tanhf(xh * gamma[lane] + beta[lane]);
+  if (xhat) xhat[(long)row * 64 + lane] = xh;
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+}
+
+int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
+                int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream) {
+  hipLaunchKernelGGL(proprio_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, state, S, W, b, gamma, beta, rows,
+                     y, ld_y, xhat, rstd);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
