@@ -15,7 +15,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // element strides (transposes are free), zero-filled edges.  Slabs are summed by the consumer
 // (reduce_slabs / ln_tanh_fwd), which keeps the K-split deterministic.
 // =============================================================================================
-constexpr int kGBM = 64, kGBN = 64, kGBK = 32, kGP = 68;
+constexpr int kGBM = 64, kGBN = 64, kGBK = 64, kGP = 68;
+constexpr int kGLD = kGBM * kGBK / 256;  // elements per thread per operand per chunk
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
   __shared__ float As[2][kGBK][kGP];
@@ -30,29 +31,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
   const float* B = g.B + (long)batch * g.sBb;
   float* C = g.C + (long)z * g.sCz;
   const bool a_kfast = g.sAk == 1, b_nfast = g.sBn == 1;
-  float ra[8], rb[8];
+  float ra[kGLD], rb[kGLD];
 #define SERL_GEMM_LOAD(K0)                                                                                   \
   {                                                                                                          \
     const int k0_ = (K0);                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+    _Pragma("unroll") for (int i = 0; i < kGLD; ++i) {                                                       \
       int m, k;                                                                                              \
-      if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
+      if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
       const int gm = m0 + m, gk = k0_ + k;                                                                   \
       ra[i] = (gm < g.M && gk < k_end) ? A[(long)gm * g.sAm + (long)gk * g.sAk] : 0.f;                       \
       int n, kb;                                                                                             \
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 31; n = (tid >> 5) + 8 * i; } \
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 63; n = (tid >> 6) + 4 * i; } \
       const int gn = n0 + n, gkb = k0_ + kb;                                                                 \
       rb[i] = (gn < g.N && gkb < k_end) ? B[(long)gkb * g.sBk + (long)gn * g.sBn] : 0.f;                     \
     }                                                                                                        \
   }
 #define SERL_GEMM_STORE(BUF)                                                                                 \
   {                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+    _Pragma("unroll") for (int i = 0; i < kGLD; ++i) {                                                       \
       int m, k;                                                                                              \
-      if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
+      if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
       As[(BUF)][k][m] = ra[i];                                                                               \
       int n, kb;                                                                                             \
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 31; n = (tid >> 5) + 8 * i; } \
+      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 63; n = (tid >> 6) + 4 * i; } \
       Bs[(BUF)][kb][n] = rb[i];                                                                              \
     }                                                                                                        \
   }
