@@ -239,6 +239,168 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-patch variant for the stride-1 3x3 convs with 64 output channels (stage 0: the largest M and the
+// smallest N, where the im2col loader's 9x re-read of every input pixel through L2 -> LDS is the bound).
+// A K chunk is (ky, 16 input channels): the workgroup stages the TR x (Wo+2) input pixels of that kernel
+// row ONCE and serves the three kx taps from LDS by shifting the pixel index, so the activation operand
+// crosses L2 -> LDS 3x instead of 9x.  256 x 64 output tile = TR = 256/Wo whole output rows of one image.
+// LDS pixel rows are 32 bytes per plane (16 fp16), so MFMA fragment reads (lane -> consecutive pixels)
+// are contiguous and conflict-free without a swizzle.  Epilogue identical to the generic kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgsB ab) {
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
+  constexpr int MAXPIX = 288;                    // 8 x 34 (Wo = 32) or 16 x 18 (Wo = 16)
+  constexpr int A_PLANE = MAXPIX * 32;           // one fp16 plane: [pixel][16 channels]
+  constexpr int B_PLANE = BN * 32, B_TAP = 2 * B_PLANE;  // per tap: [hi | lo'][cout][16 k]
+  constexpr int STAGE = 2 * A_PLANE + 3 * B_TAP;
+  constexpr int AI = (MAXPIX * 4 + 255) / 256;   // 16-byte activation records per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = id * BM, n0 = 0;
+  const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
+  const int pw = a.Wo + 2, npix = (BM / a.Wo) * pw;
+  const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
+  const int rowstep = a.Wi * a.Cin;
+  int rbase[AI];
+  unsigned rmask[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int idx = tid + 256 * i, pix = idx >> 2, q = idx & 3;
+    rbase[i] = 0; rmask[i] = 0;
+    if (pix < npix) {
+      const int sy = pix / pw, sx = pix - sy * pw;
+      const int ix = sx - 1, iy = oy0 + sy;  // centre-row (ky = 1) input pixel of this stage slot
+      const int ixc = min(max(ix, 0), a.Wi - 1);
+      rbase[i] = ((n_img * a.Hi + iy) * a.Wi + ixc) * a.Cin + 4 * q;
+      if (ix == ixc) rmask[i] = (iy > 0 ? 1u : 0u) | 2u | (iy + 1 < a.Hi ? 4u : 0u);
+    }
+  }
+  const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
+  const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
+  u32x4 ra[AI], rb[3];
+  unsigned okmask = 0;
+  int l_ky = 0, l_c16 = 0;
+
+#define SERL_RP_LOAD(CIDX)                                                                       \
+  {                                                                                              \
+    const int ky_ = l_ky, c0_ = l_c16 << 4;                                                      \
+    const int toff_ = (ky_ - 1) * rowstep + c0_;                                                 \
+    if ((CIDX) + 1 < nchunks) { if (++l_c16 == c16n) { l_c16 = 0; ++l_ky; } }                    \
+    okmask = 0;                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                             \
+      const bool ok = (rmask[i] >> ky_) & 1u;                                                    \
+      okmask |= (ok ? 1u : 0u) << i;                                                             \
+      ra[i] = *reinterpret_cast<const u32x4*>(a.in + rbase[i] + (ok ? toff_ : c0_));             \
+    }                                                                                            \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
+      rb[kx] = *reinterpret_cast<const u32x4*>(wrow + (ky_ * 3 + kx) * a.Cin + c0_);             \
+  }
+#define SERL_RP_STORE(BUF)                                                                       \
+  {                                                                                              \
+    uint8_t* st_ = smemb + (BUF) * STAGE;                                                        \
+    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                             \
+      u32x4 v = ra[i];                                                                           \
+      if (!((okmask >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                    \
+      const int idx_ = tid + 256 * i;                                                            \
+      if (idx_ < MAXPIX * 4) {                                                                   \
+        *reinterpret_cast<u32x2*>(st_ + idx_ * 8) = (u32x2){v[0], v[1]};                         \
+        *reinterpret_cast<u32x2*>(st_ + A_PLANE + idx_ * 8) = (u32x2){v[2], v[3]};               \
+      }                                                                                          \
+    }                                                                                            \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
+      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + kx * B_TAP + tid * 16) = rb[kx];             \
+  }
+
+  f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+
+  const int li = lane & 31, lh = lane >> 5;
+  int arow[TM];  // LDS byte offset of this lane's pixel (kx = 0) for each 32-row MFMA tile
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wave * WROWS + tm * 32 + li;
+    const int y = r / a.Wo, x = r - y * a.Wo;
+    arow[tm] = (y * pw + x) * 32 + lh * 16;
+  }
+  const int boff = 2 * A_PLANE + li * 32 + lh * 16;
+  SERL_RP_LOAD(0);
+  SERL_RP_STORE(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    SERL_RP_LOAD(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
+    const uint8_t* st = smemb + buf * STAGE;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        ahi[tm] = *reinterpret_cast<const f16x8*>(st + arow[tm] + kx * 32);
+        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + arow[tm] + kx * 32);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        bhi[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + tn * 32 * 32);
+        blo[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + B_PLANE + tn * 32 * 32);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    SERL_RP_STORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef SERL_RP_LOAD
+#undef SERL_RP_STORE
+
+  const int wrow0 = m0 + wave * WROWS;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* o = a.out + (size_t)m * a.Cout + n0 + li;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+    }
+  {
+    const int gsize = a.Cout / kGnGroups;
+    double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r];
+          s += v;
+          q += v * v;
+        }
+      stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-specialised variant for the large tiles: 4 consumer waves (64x64 MFMA tiles each) + 2 producer
 // waves per workgroup.  Producers stream split16 activation records and fp16 weight slots
 // global -> registers -> a 3-stage LDS ring: two chunks ahead of the consumers in LDS plus one more
@@ -801,7 +963,14 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     // wave-specialised variant: measured slower than two co-resident 4-wave workgroups (the convs are bound
     // by L2->LDS operand bandwidth, not latency); kept for experiments behind SERL_CONV_WS=1
     static const bool use_ws = []() { const char* e = getenv("SERL_CONV_WS"); return e && e[0] == '1'; }();
-    if (use_ws && cfg != 2) {
+    static const bool use_rp = []() { const char* e = getenv("SERL_CONV_ROWPATCH"); return !(e && e[0] == '0'); }();
+    const bool rp_ok = use_rp && ksz == 3 && stride == 1 && Cout == 64 && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
+                       (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 &&
+                       (long)N * Hi * Wi * Cin < (1L << 31);
+    if (rp_ok) {
+      hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),
+                         stream, ab);
+    } else if (use_ws && cfg != 2) {
       const size_t lds_ws = (size_t)3 * (2 * BM * 64 + 2 * BN * 64);
       dim3 block_ws(384);
 #define SERL_LAUNCH_WS(WM, WN)                                                                                            \

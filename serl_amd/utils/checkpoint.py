@@ -1,0 +1,101 @@
+"""Checkpoint save / restore of `agent.state` (next-row N1).
+
+The reference calls `flax.training.checkpoints.save_checkpoint(path, agent.state, step=, keep=)`
+(examples/async_drq_sim/async_drq_sim.py:303-307), which writes `<path>/checkpoint_<step>` containing
+`flax.serialization.to_bytes(state)`: a msgpack map of the state's pytree fields (`step, params,
+target_params, opt_states, rng`; common/common.py:108-114) in which every ndarray is a msgpack ExtType(1)
+holding msgpack((shape, dtype.name, raw bytes)).  flax is not installable here, so this writer/reader
+restates that published format (UNVERIFIED against a flax install) -- the actor side of the reference can
+try `checkpoints.restore_checkpoint` on these files; `restore_checkpoint` below reads them back into the
+HIP agent (params, target_params, Adam moments, step).
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Optional
+
+import msgpack
+import numpy as np
+
+from ..agents.core import TX_NAMES
+from ..agents.flax_tree import theta_paths, _trunk_paths
+
+_EXT_NDARRAY = 1
+
+
+def _pack_default(x):
+    if isinstance(x, (np.ndarray, np.generic)):
+        a = np.asarray(x)
+        return msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes("C")), use_bin_type=True))
+    raise TypeError(f"cannot serialise {type(x)}")
+
+
+def _unpack_ext(code, data):
+    if code == _EXT_NDARRAY:
+        shape, dtype, buf = msgpack.unpackb(data, raw=False)
+        return np.frombuffer(buf, dtype=np.dtype(dtype)).reshape(shape).copy()
+    return msgpack.ExtType(code, data)
+
+
+def state_dict(agent) -> dict:
+    st = agent.state
+    return {"step": np.int64(st.step), "params": st.params, "target_params": st.target_params,
+            "opt_states": st.opt_states, "rng": st.rng}
+
+
+def save_checkpoint(ckpt_dir: str, agent, step: int, prefix: str = "checkpoint_", keep: int = 1, overwrite: bool = False) -> str:
+    os.makedirs(ckpt_dir, exist_ok=True)
+    path = os.path.join(ckpt_dir, f"{prefix}{step}")
+    if os.path.exists(path) and not overwrite:
+        raise ValueError(f"checkpoint {path} exists (overwrite=False)")
+    blob = msgpack.packb(state_dict(agent), default=_pack_default, strict_types=True, use_bin_type=True)
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        f.write(blob)
+    os.replace(tmp, path)
+    # keep the `keep` most recent checkpoints (flax semantics)
+    steps = sorted(int(m.group(1)) for m in (re.fullmatch(re.escape(prefix) + r"(\d+)", n) for n in os.listdir(ckpt_dir)) if m)
+    for s in steps[:-keep] if keep > 0 else []:
+        os.remove(os.path.join(ckpt_dir, f"{prefix}{s}"))
+    return path
+
+
+def latest_checkpoint(ckpt_dir: str, prefix: str = "checkpoint_") -> Optional[str]:
+    if not os.path.isdir(ckpt_dir):
+        return None
+    steps = [int(m.group(1)) for m in (re.fullmatch(re.escape(prefix) + r"(\d+)", n) for n in os.listdir(ckpt_dir)) if m]
+    return os.path.join(ckpt_dir, f"{prefix}{max(steps)}") if steps else None
+
+
+def _walk(tree, path):
+    for p in path:
+        tree = tree[p]
+    return tree
+
+
+def restore_checkpoint(ckpt_dir_or_file: str, agent, step: Optional[int] = None, prefix: str = "checkpoint_"):
+    """Loads params / target_params / Adam moments / step back into the agent's HBM arena."""
+    path = ckpt_dir_or_file
+    if os.path.isdir(path):
+        path = os.path.join(path, f"{prefix}{step}") if step is not None else latest_checkpoint(path, prefix)
+        if path is None:
+            return agent  # flax returns the target unchanged when there is nothing to restore
+    with open(path, "rb") as f:
+        sd = msgpack.unpackb(f.read(), ext_hook=_unpack_ext, raw=False, strict_map_key=False)
+    core, keys = agent.core, agent.image_keys
+    tp = theta_paths(keys)
+    trunk = _trunk_paths()
+    for section, tree in (("params", sd["params"]), ("target_params", sd["target_params"])):
+        for leaf, paths in tp.items():
+            core.set(section, leaf, _walk(tree, paths[0]))
+        for leaf, sub in trunk.items():
+            core.set(section, leaf, _walk(tree, ("modules_actor", "encoder", f"encoder_{keys[0]}", "pretrained_encoder") + sub))
+    for tx in TX_NAMES:
+        for mom in ("mu", "nu"):
+            tree = sd["opt_states"][tx][mom]
+            for leaf, paths in tp.items():
+                # leaves outside the optimizer's support are exact zeros; the C ABI accepts (and checks) them
+                core.set(f"opt/{tx}/{mom}", leaf, np.asarray(_walk(tree, paths[0]), np.float32))
+    core.step = int(sd["step"])
+    return agent

@@ -282,3 +282,47 @@ def test_pipelined_schedule_matches_serial(gpu):
         outs.append({k: core.get("params", k) for k in ("critic/w1", "actor/w2", "enc/0/dense/kernel", "temp/lagrange")})
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json's bench configuration (batch 256, 2 x 128x128x3, 24-dim state): the fp64 oracle is too
+    slow here, so check size-independent properties -- split-fp16 and exact-fp32 trunks agree, shard
+    gradients (2 and 8 ranks) sum to the full-batch gradient, and a learner iteration stays finite."""
+    cfg = O.Config(image_keys=("wrist_1", "wrist_2"), H=128, W=128, S=24, A=7)
+    B = 256
+    _, core = AH.make_pair(cfg, B)
+    b = AH.synth_batch(cfg, B, seed=11)
+    noise = AH.noise_to_device(cfg, O.make_noise(cfg, B, seed=3))
+    db = AH.batch_to_device(cfg, b)
+    frames = db.frames.reshape(-1, cfg.H, cfg.W, 3)
+    core.set_trunk_mode("f32")
+    f32 = core.trunk_forward(frames).cpu().numpy()
+    core.set_trunk_mode("f16x3")
+    f16 = core.trunk_forward(frames).cpu().numpy()
+    assert f32.shape == (4 * B, 4, 4, 512) and np.isfinite(f32).all()
+    assert AH.rel_err(f16, f32) < 2e-5
+
+    sl, _ = AH.leaf_slices(cfg)
+    n = sl["enc/proprio/ln/bias"][1]
+    core.begin_update()
+    core.encode(db)
+    core.critic_grads(0, B, B, noise)
+    full = core.debug("g_critic", n).astype(np.float64)
+    sc_full = core.debug("scalars", 3).astype(np.float64)
+    assert np.isfinite(full).all() and np.abs(full).max() > 0
+    for world in (2, 8):
+        per = B // world
+        acc, sc = np.zeros_like(full), np.zeros_like(sc_full)
+        for r in range(world):
+            core.critic_grads(r * per, per, B, noise)
+            acc += core.debug("g_critic", n)
+            sc += core.debug("scalars", 3)
+        assert AH.rel_err(acc, full) < 1e-5, world
+        assert AH.rel_err(sc, sc_full) < 1e-5, world
+
+    w0 = core.get("params", "critic/w1").copy()
+    core.update_critics(db, noise)
+    core.update_high_utd(db, 1, noise)
+    info = core.read_info()
+    assert all(np.isfinite(v) for v in info.values()), info
+    assert core.step == 3 and not np.array_equal(w0, core.get("params", "critic/w1"))

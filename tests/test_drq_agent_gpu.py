@@ -112,3 +112,24 @@ def test_reference_error_behaviour(gpu):
     with pytest.raises(NotImplementedError, match="Unknown encoder type"):
         DrQAgent.create_drq(0, {"front": np.zeros((1, H, W, 3)), "state": np.zeros((1, S))}, np.zeros(A),
                             encoder_type="bogus", image_keys=("front",))
+
+
+def test_checkpoint_roundtrip(gpu, tmp_path):
+    """N1: save_checkpoint(agent.state) -> restore into a fresh agent -> identical next update."""
+    from serl_amd.utils.checkpoint import latest_checkpoint, restore_checkpoint, save_checkpoint
+    env, rb, agent = _setup(B=8)
+    for _ in range(2):
+        agent.update_high_utd(rb.sample(8, pack_obs_and_next_obs=True, lazy=True), utd_ratio=1)
+    p1 = save_checkpoint(str(tmp_path), agent, step=agent.state.step, keep=2)
+    agent.update_critics(rb.sample(8, pack_obs_and_next_obs=True, lazy=True))
+    p2 = save_checkpoint(str(tmp_path), agent, step=agent.state.step, keep=2)
+    assert latest_checkpoint(str(tmp_path)) == p2 and p1 != p2
+    env2, rb2, fresh = _setup(B=8)
+    restore_checkpoint(str(tmp_path), fresh)
+    assert fresh.state.step == agent.state.step
+    for leaf in ("critic/w1", "actor/w2", "enc/0/dense/kernel", "temp/lagrange", "trunk/block2/conv1"):
+        for sec in ("params", "target_params"):
+            assert np.array_equal(fresh.core.get(sec, leaf), agent.core.get(sec, leaf)), (sec, leaf)
+    for sec, leaf in (("opt/critic/mu", "critic/w2"), ("opt/actor/nu", "actor/w1"), ("opt/temperature/mu", "temp/lagrange"),
+                      ("opt/critic/nu", "enc/proprio/dense/kernel"), ("opt/actor/mu", "enc/proprio/dense/kernel")):
+        assert np.array_equal(fresh.core.get(sec, leaf), agent.core.get(sec, leaf)), (sec, leaf)

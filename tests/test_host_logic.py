@@ -53,3 +53,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.SerlError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_checkpoint_file_format(tmp_path):
+    """flax.serialization layout: msgpack map, ndarrays as ExtType(1, msgpack((shape, dtype, bytes)))."""
+    import msgpack
+    from types import SimpleNamespace
+    from serl_amd.utils import checkpoint as ck
+    tree = {"modules_actor": {"Dense_1": {"kernel": np.arange(6, dtype=np.float32).reshape(2, 3)}}}
+    st = SimpleNamespace(step=7, params=tree, target_params=tree, rng=np.array([0, 3], np.uint32),
+                         opt_states={"critic": {"count": 7, "mu": tree, "nu": tree}})
+    agent = SimpleNamespace(state=st)
+    for s in (5, 6, 7):
+        st.step = s
+        path = ck.save_checkpoint(str(tmp_path), agent, step=s, keep=2)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["checkpoint_6", "checkpoint_7"]
+    assert ck.latest_checkpoint(str(tmp_path)) == path
+    with pytest.raises(ValueError):
+        ck.save_checkpoint(str(tmp_path), agent, step=7)
+    seen = []
+    raw = msgpack.unpackb(open(path, "rb").read(), raw=False, ext_hook=lambda c, d: seen.append(c) or ck._unpack_ext(c, d))
+    assert set(seen) == {1} and set(raw) == {"step", "params", "target_params", "opt_states", "rng"}
+    k = raw["params"]["modules_actor"]["Dense_1"]["kernel"]
+    assert k.dtype == np.float32 and k.shape == (2, 3) and np.array_equal(k, tree["modules_actor"]["Dense_1"]["kernel"])
+    assert raw["rng"].dtype == np.uint32 and int(raw["step"]) == 7
