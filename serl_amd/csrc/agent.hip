@@ -348,6 +348,17 @@ hipStream_t pg_lane(serl_agent* a, hipStream_t st) {
 
 hipStream_t pgs(serl_agent* a, hipStream_t st) { return a->concurrent ? a->pg : st; }
 
+// K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
+// workgroups than kGemmBlockBudget -- at large per-rank batches the update chain runs beside the trunk of
+// the next batch and every extra workgroup waits for a conv workgroup to retire.
+int split_for(int M, int N, int groups, int smax) {
+  static const int budget = []() { const char* e = getenv("SERL_GEMM_BLOCKS"); return e ? std::max(atoi(e), 1) : 256; }();
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
+  int s = smax;
+  while (s > 1 && tiles * s > budget) s >>= 1;
+  return s;
+}
+
 // ---- EncodingWrapper forward on precomputed trunk features (encoding.py:26-72) ------------------
 // which: 0 = observations, 1 = next_observations; samples [off, off+cnt) of the current batch.
 int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uint8_t* mask, EncBuf& e,
@@ -361,7 +372,7 @@ int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uin
     RC(sle_fwd(x, P + o.cam[0].sle, m, 1.0f / (1.0f - c.dropout), e.f, cnt, a->HW, 512, c.n_cam,
                (long)c.batch * a->HW * 512, o.cam_stride, Bfull * a->D, (long)c.batch * a->D, st));
   }
-  const int S = 32;  // K = 4096 split 32 ways: 128-deep slices, 4 chunks per workgroup
+  const int S = split_for(cnt, c.bottleneck, c.n_cam, 32);  // K = 4096: up to 32 slices of 128
   GemmDesc g{};
   g.A = e.f; g.sAm = a->D; g.sAk = 1; g.sAb = (long)c.batch * a->D;
   g.B = P + o.cam[0].dW; g.sBk = c.bottleneck; g.sBn = 1; g.sBb = o.cam_stride;
@@ -387,6 +398,7 @@ int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const
                   int rows_per_group, int K, int splitk, float* y, float* xhat, float* rstd, hipStream_t st,
                   const float* dot_w = nullptr, const float* dot_b = nullptr, float* dot_out = nullptr) {
   const int Hd = a->cfg.hidden;
+  splitk = split_for(rows_per_group, Hd, groups, splitk);
   GemmDesc g{};
   g.A = X; g.sAm = ldx; g.sAk = 1; g.sAb = x_gstride;
   g.B = W; g.sBk = Hd; g.sBn = 1; g.sBb = w_gstride;

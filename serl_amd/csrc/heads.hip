@@ -11,16 +11,141 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // =============================================================================================
 // GEMM  C[z] = A[b] * B[b] over K-split `s`   (z = b*splitk + s)
-// 64x64 tile per 256-thread workgroup (2x2 waves, one 32x32 MFMA tile each), BK = 16, arbitrary
-// element strides (transposes are free), zero-filled edges.  Slabs are summed by the consumer
-// (reduce_slabs / ln_tanh_fwd), which keeps the K-split deterministic.
+// 64x64 tile per 256-thread workgroup (2x2 waves, one 32x32 fp32-MFMA tile each), BK = 32.
+// The update chain runs beside the frozen trunk of the next batch, whose conv workgroups own nearly the
+// whole register file and LDS of every CU; a chain kernel starts only in the space a retiring conv
+// workgroup frees.  The kernel is therefore built lean -- ~60 VGPRs, 18 KB LDS (single-buffered, next chunk
+// prefetched in registers) -- so that several of its workgroups fit into one freed conv slot.
+// Operands are read with 16-byte vectors along whichever dimension is contiguous (transposes are free:
+// A may be k- or m-contiguous, B k- or n-contiguous) and stored k-contiguous in LDS, [row][k] with a
+// 36-float pitch, so one conflict-free ds_read_b128 per operand feeds four MFMAs: inside each block of 8
+// k's, lanes 0-31 take k = 0..3 and lanes 32-63 k = 4..7 (the K order of a sum is free).
+// Edges are zero-filled; slabs are summed by the consumer (reduce_slabs / ln_tanh_fwd), which keeps the
+// K-split deterministic.  Arbitrary element strides fall back to gemm_f32_strided_kernel.
 // =============================================================================================
-constexpr int kGBM = 64, kGBN = 64, kGBK = 64, kGP = 68;
-constexpr int kGLD = kGBM * kGBK / 256;  // elements per thread per operand per chunk
+constexpr int kGBM = 64, kGBN = 64, kGBK = 32, kGP = 36;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // global loads need only 4-byte alignment
 
+// 4 consecutive floats at p of which the first `valid` exist (<= 0: none, >= 4: all); missing ones are 0
+__device__ __forceinline__ f32x4 ld4(const float* p, int valid) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid >= 4) {
+    v = *reinterpret_cast<const f32x4u*>(p);
+  } else if (valid > 0) {
+    v[0] = p[0];
+    if (valid > 1) v[1] = p[1];
+    if (valid > 2) v[2] = p[2];
+  }
+  return v;
+}
+
+// One operand tile X[r0 .. r0+64)[k0 .. k0+32) with element strides (sR, sK), one of which is 1.
+// KFAST: vectors run along k (thread -> row idx>>3, k 4*(idx&7)); otherwise along the rows
+// (thread -> k idx>>4, rows 4*(idx&15)) and are transposed on the way into LDS.
+template <bool KFAST>
+struct OperandLoader {
+  const float* p[2];
+  int lim[2];   // KFAST: row valid ? 1 : 0      else: number of valid rows from this thread's first row
+  int kofs[2];  // k offset of this thread's vector inside the chunk
+  long step;    // pointer advance per chunk
+  __device__ __forceinline__ void init(const float* X, long sR, long sK, int r0, int R, int k_begin, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      if (KFAST) {
+        const int r = idx >> 3;
+        kofs[i] = 4 * (idx & 7);
+        lim[i] = (r0 + r < R) ? 1 : 0;
+        p[i] = X + (long)(r0 + r) * sR + (k_begin + kofs[i]);
+      } else {
+        const int rq = 4 * (idx & 15);
+        kofs[i] = idx >> 4;
+        lim[i] = R - (r0 + rq);
+        p[i] = X + (long)(k_begin + kofs[i]) * sK + (r0 + rq);
+      }
+    }
+    step = KFAST ? kGBK : kGBK * sK;
+  }
+  // loads the chunk starting at k0 (elements at k >= k_end are zero) and advances to the next chunk
+  __device__ __forceinline__ void load(f32x4 (&r)[2], int k0, int k_end) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int krem = k_end - (k0 + kofs[i]);
+      const int valid = KFAST ? (lim[i] ? krem : 0) : (krem > 0 ? lim[i] : 0);
+      r[i] = ld4(p[i], valid);
+      p[i] += step;
+    }
+  }
+  __device__ __forceinline__ void store(float (*S)[kGP], const f32x4 (&r)[2], int tid) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      if (KFAST) {
+        *reinterpret_cast<f32x4*>(&S[idx >> 3][4 * (idx & 7)]) = r[i];
+      } else {
+        const int rq = 4 * (idx & 15), k = idx >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[rq + j][k] = r[i][j];
+      }
+    }
+  }
+};
+
+template <bool A_KFAST, bool B_KFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
-  __shared__ float As[2][kGBK][kGP];
-  __shared__ float Bs[2][kGBK][kGP];
+  __shared__ __attribute__((aligned(16))) float As[kGBM][kGP];  // [m][k]
+  __shared__ __attribute__((aligned(16))) float Bs[kGBN][kGP];  // [n][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z, batch = z / g.splitk, split = z - batch * g.splitk;
+  const int m0 = blockIdx.y * kGBM, n0 = blockIdx.x * kGBN;
+  const int kper = ((g.K + g.splitk - 1) / g.splitk + kGBK - 1) / kGBK * kGBK;
+  const int k_begin = split * kper, k_end = min(g.K, k_begin + kper);
+  float* C = g.C + (long)z * g.sCz;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  if (k_begin < k_end) {
+    OperandLoader<A_KFAST> la;
+    OperandLoader<B_KFAST> lb;
+    la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
+    lb.init(g.B + (long)batch * g.sBb, g.sBn, g.sBk, n0, g.N, k_begin, tid);
+    f32x4 ra[2], rb[2];
+    la.load(ra, k_begin, k_end);
+    lb.load(rb, k_begin, k_end);
+    const float* arow = &As[wm * 32 + li][4 * lh];
+    const float* brow = &Bs[wn * 32 + li][4 * lh];
+    for (int k0 = k_begin; k0 < k_end; k0 += kGBK) {
+      la.store(As, ra, tid);
+      lb.store(Bs, rb, tid);
+      __syncthreads();
+      la.load(ra, k0 + kGBK, k_end);  // past k_end: all-zero vectors, nothing is dereferenced
+      lb.load(rb, k0 + kGBK, k_end);
+#pragma unroll
+      for (int q = 0; q < kGBK / 8; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(brow + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int n = n0 + wn * 32 + li;
+    if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[r];
+  }
+}
+
+// arbitrary element strides: scalar loads, [k][m] LDS tiles
+__global__ __launch_bounds__(256) void gemm_f32_strided_kernel(GemmDesc g) {
+  constexpr int BK = 16, P = 68, LD = kGBM * BK / 256;
+  __shared__ float As[BK][P];
+  __shared__ float Bs[BK][P];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z, batch = z / g.splitk, split = z - batch * g.splitk;
@@ -30,57 +155,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
   const float* A = g.A + (long)batch * g.sAb;
   const float* B = g.B + (long)batch * g.sBb;
   float* C = g.C + (long)z * g.sCz;
-  const bool a_kfast = g.sAk == 1, b_nfast = g.sBn == 1;
-  float ra[kGLD], rb[kGLD];
-#define SERL_GEMM_LOAD(K0)                                                                                   \
-  {                                                                                                          \
-    const int k0_ = (K0);                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < kGLD; ++i) {                                                       \
-      int m, k;                                                                                              \
-      if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
-      const int gm = m0 + m, gk = k0_ + k;                                                                   \
-      ra[i] = (gm < g.M && gk < k_end) ? A[(long)gm * g.sAm + (long)gk * g.sAk] : 0.f;                       \
-      int n, kb;                                                                                             \
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 63; n = (tid >> 6) + 4 * i; } \
-      const int gn = n0 + n, gkb = k0_ + kb;                                                                 \
-      rb[i] = (gn < g.N && gkb < k_end) ? B[(long)gkb * g.sBk + (long)gn * g.sBn] : 0.f;                     \
-    }                                                                                                        \
-  }
-#define SERL_GEMM_STORE(BUF)                                                                                 \
-  {                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < kGLD; ++i) {                                                       \
-      int m, k;                                                                                              \
-      if (a_kfast) { k = tid & 63; m = (tid >> 6) + 4 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }  \
-      As[(BUF)][k][m] = ra[i];                                                                               \
-      int n, kb;                                                                                             \
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 63; n = (tid >> 6) + 4 * i; } \
-      Bs[(BUF)][kb][n] = rb[i];                                                                              \
-    }                                                                                                        \
-  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int li = lane & 31, lh = lane >> 5;
-  if (k_begin < k_end) {
-    SERL_GEMM_LOAD(k_begin);
-    SERL_GEMM_STORE(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += kGBK) {
-      SERL_GEMM_LOAD(k0 + kGBK);  // past k_end this loads zeros (predicated), keeping the staging regs in SSA form
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
-      for (int ks = 0; ks < kGBK / 2; ++ks) {
-        const float a = As[buf][2 * ks + lh][wm * 32 + li];
-        const float b = Bs[buf][2 * ks + lh][wn * 32 + li];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-      }
-      SERL_GEMM_STORE(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+    for (int i = 0; i < LD; ++i) {
+      const int x = tid & 63, k = (tid >> 6) + 4 * i, gk = k0 + k;
+      As[k][x] = (m0 + x < g.M && gk < k_end) ? A[(long)(m0 + x) * g.sAm + (long)gk * g.sAk] : 0.f;
+      Bs[k][x] = (n0 + x < g.N && gk < k_end) ? B[(long)gk * g.sBk + (long)(n0 + x) * g.sBn] : 0.f;
     }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * ks + lh][wm * 32 + li], Bs[2 * ks + lh][wn * 32 + li], acc, 0, 0, 0);
+    __syncthreads();
   }
-#undef SERL_GEMM_LOAD
-#undef SERL_GEMM_STORE
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -92,7 +183,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
 int gemm_f32(const GemmDesc& g, hipStream_t stream) {
   SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
   dim3 grid(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, g);
+  const bool a_k = g.sAk == 1, a_m = g.sAm == 1, b_k = g.sBk == 1, b_n = g.sBn == 1;
+  if ((a_k || a_m) && (b_k || b_n)) {
+    if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
+    else if (a_k) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    else if (b_k) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_f32_strided_kernel, grid, dim3(256), 0, stream, g);
+  }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
