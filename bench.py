@@ -140,7 +140,8 @@ def main():
     for _ in range(args.warmup):
         iteration()
     barrier()
-    _lib.check(_lib.lib().serl_profile_enable(1))
+    # (SERL_BENCH_NOPROF=1: diagnostic run without the per-kernel HIP events -- measures their overhead)
+    _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else 1))
     _lib.check(_lib.lib().serl_profile_reset())
     barrier()
     t0 = time.perf_counter()

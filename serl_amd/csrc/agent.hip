@@ -65,6 +65,9 @@ enum { S_D2 = 0, S_Q = 1, S_Y = 2, S_QPI = 3, S_LOGP = 4, S_LOGP_NEXT = 5 };
 enum { X_ALPHA = 0, X_TGRAD = 1, X_N = 8 };
 // info accumulator slots
 enum { I_CL = 0, I_PQ, I_TQ, I_AL, I_TEMP, I_ENT, I_TL, I_N };
+// adam_ema_kernel's info rider (heads.hip) indexes these slots by number
+static_assert(S_D2 == 0 && S_Q == 1 && S_Y == 2 && S_QPI == 3 && S_LOGP == 4 && S_LOGP_NEXT == 5, "scalar slots");
+static_assert(I_CL == 0 && I_PQ == 1 && I_TQ == 2 && I_AL == 3 && I_TEMP == 4 && I_ENT == 5 && I_TL == 6 && I_N <= 8, "info slots");
 
 }  // namespace
 
@@ -93,15 +96,8 @@ struct serl_agent {
   EncBuf encP{}, encT{}, encO{};
   CritBuf critT{}, crit{};
   PolBuf pol{}, polT{};
-  float* slabs = nullptr; long slabs_cap = 0;  // GEMM split-K scratch of the lane currently being enqueued
-  float* slabs_lane[3] = {nullptr, nullptr, nullptr};
-  // intra-update concurrency: independent chains of small kernels run on side streams (lanes 1, 2) and
-  // parameter-gradient work on `pg`; everything is forked from / joined back into the caller's stream
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipStream_t pg = nullptr, pg_main = nullptr;
-  hipEvent_t evp[32] = {nullptr};
-  int evi = 0;
-  bool concurrent = true;
+  float* slabs = nullptr; long slabs_cap = 0;  // GEMM split-K scratch (== slabs_lane[0])
+  float* slabs_lane[3] = {nullptr, nullptr, nullptr};  // one per instance of a multi-instance launch
   float *dq = nullptr, *ytgt = nullptr;
   float *dh2 = nullptr, *da2 = nullptr, *dg2 = nullptr, *dh1 = nullptr, *da1 = nullptr, *dg1 = nullptr;
   float *dx = nullptr, *dz = nullptr, *dgz = nullptr, *df = nullptr, *sle_part = nullptr;
@@ -118,6 +114,7 @@ struct serl_agent {
   serl_info last_info{};
   float lr_last = 0.f;
   int last_global = 0;
+  bool info_reset = true;
 };
 
 namespace {
@@ -259,7 +256,7 @@ size_t carve(serl_agent* a, void* base) {
   a->m_t = b.take<float>(1); a->v_t = b.take<float>(1);
   a->G = b.take<float>(o.Pc + kScalars + (o.Pa1 - o.Pa0));
   a->Gc = a->G; a->SC = a->G ? a->G + o.Pc : nullptr; a->Ga = a->G ? a->G + o.Pc + kScalars : nullptr;
-  a->info_acc = b.take<float>(I_N);
+  a->info_acc = b.take<float>(8);
   a->aux = b.take<float>(X_N);
   const size_t persistent = b.off;  // zero-initialised region ends here
   for (int k = 0; k < 3; ++k) a->feats_slot[k] = b.take<float>((k < 2 ? 2L : 1L) * c.n_cam * B * a->HW * 512);
@@ -325,32 +322,9 @@ size_t carve(serl_agent* a, void* base) {
     if (_rc) return _rc; \
   } while (0)
 
-// ---- stream fork / join -------------------------------------------------------------------------
-int fork_to(serl_agent* a, hipStream_t from, hipStream_t to) {
-  if (from == to) return SERL_OK;
-  hipEvent_t e = a->evp[a->evi];
-  a->evi = (a->evi + 1) & 31;
-  SERL_HIP(hipEventRecord(e, from));
-  SERL_HIP(hipStreamWaitEvent(to, e, 0));
-  return SERL_OK;
-}
-// lane k: 0 = the caller's stream, 1/2 = side streams; selects the lane's split-K scratch as a side effect
-hipStream_t lane(serl_agent* a, hipStream_t main, int k) {
-  a->slabs = a->slabs_lane[k];
-  return (k == 0 || !a->concurrent) ? main : a->side[k - 1];
-}
-// stream for parameter-gradient kernels (off the critical input-gradient chain); forks from `st`
-hipStream_t pg_lane(serl_agent* a, hipStream_t st) {
-  if (!a->concurrent) return st;
-  (void)fork_to(a, st, a->pg);
-  return a->pg;
-}
-
-hipStream_t pgs(serl_agent* a, hipStream_t st) { return a->concurrent ? a->pg : st; }
-
 // K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
-// workgroups than kGemmBlockBudget -- at large per-rank batches the update chain runs beside the trunk of
-// the next batch and every extra workgroup waits for a conv workgroup to retire.
+// workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
+// next batch and every extra workgroup waits for a conv workgroup to retire.
 int split_for(int M, int N, int groups, int smax) {
   static const int budget = []() { const char* e = getenv("SERL_GEMM_BLOCKS"); return e ? std::max(atoi(e), 1) : 256; }();
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
@@ -360,91 +334,160 @@ int split_for(int M, int N, int groups, int smax) {
 }
 
 // ---- EncodingWrapper forward on precomputed trunk features (encoding.py:26-72) ------------------
-// which: 0 = observations, 1 = next_observations; samples [off, off+cnt) of the current batch.
-int encode(serl_agent* a, const float* P, int which, int off, int cnt, const uint8_t* mask, EncBuf& e,
-           hipStream_t st) {
+// Up to kMaxMulti independent instances (parameter vector x observation side x dropout mask) in four
+// launches: SpatialLearnedEmbeddings, bottleneck Dense (K-split GEMM), LayerNorm+tanh, proprio branch.
+// Instance i uses split-K scratch slabs_lane[i].  Samples [off, off+cnt) of the current batch.
+struct EncJob {
+  const float* P;        // parameter vector (online or target)
+  int which;             // 0 = observations, 1 = next_observations
+  const uint8_t* mask;   // dropout keep-mask, nullptr = train=False
+  EncBuf* e;
+  const float* act_src;  // optional rider: copy [cnt][A] actions (ld A) to act_dst (ld XA)
+  float* act_dst;
+};
+int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const long Bfull = a->cur.batch;
-  {  // SpatialLearnedEmbeddings (+ dropout) of every camera in one launch (grid.y = camera)
-    const float* x = a->feats + (((long)which * c.n_cam) * c.batch + off) * a->HW * 512;
-    const uint8_t* m = mask ? mask + (long)off * a->D : nullptr;
-    RC(sle_fwd(x, P + o.cam[0].sle, m, 1.0f / (1.0f - c.dropout), e.f, cnt, a->HW, 512, c.n_cam,
-               (long)c.batch * a->HW * 512, o.cam_stride, Bfull * a->D, (long)c.batch * a->D, st));
+  SERL_REQUIRE(n >= 1 && n <= 3, "bad encode instance count");
+  SleFwdArgs sv[3];
+  GemmDesc gd[3];
+  LnFwdArgs lv[3];
+  ProprioArgs pv[3];
+  const int S = split_for(cnt, c.bottleneck, c.n_cam * n, 32);  // K = 4096: up to 32 slices of 128
+  for (int i = 0; i < n; ++i) {
+    const EncJob& j = jobs[i];
+    EncBuf& e = *j.e;
+    sv[i].x = a->feats + (((long)j.which * c.n_cam) * c.batch + off) * a->HW * 512;
+    sv[i].K = j.P + o.cam[0].sle;
+    sv[i].mask = j.mask ? j.mask + (long)off * a->D : nullptr;
+    sv[i].f = e.f;
+    GemmDesc& g = gd[i];
+    g = GemmDesc{};
+    g.A = e.f; g.sAm = a->D; g.sAk = 1; g.sAb = (long)c.batch * a->D;
+    g.B = j.P + o.cam[0].dW; g.sBk = c.bottleneck; g.sBn = 1; g.sBb = o.cam_stride;
+    g.C = a->slabs_lane[i]; g.ldc = c.bottleneck; g.sCz = (long)cnt * c.bottleneck;
+    g.M = cnt; g.N = c.bottleneck; g.K = a->D; g.nbatch = c.n_cam; g.splitk = S;
+    LnFwdArgs& l = lv[i];
+    l = LnFwdArgs{};
+    l.slabs = a->slabs_lane[i]; l.S = S; l.slab_stride = g.sCz;
+    l.bias = j.P + o.cam[0].db; l.gamma = j.P + o.cam[0].lng; l.beta = j.P + o.cam[0].lnb; l.pstride = o.cam_stride;
+    l.rows = c.n_cam * cnt; l.rows_per_group = cnt;
+    l.y = e.enc; l.ld_y = e.ld; l.y_goff = c.bottleneck;
+    l.xhat = e.xhat; l.rstd = e.rstd;
+    ProprioArgs& pr = pv[i];
+    pr = ProprioArgs{};
+    pr.state = a->cur.state + ((long)j.which * Bfull + off) * c.state_dim;
+    pr.W = j.P + o.p_W; pr.b = j.P + o.p_b; pr.gamma = j.P + o.p_g; pr.beta = j.P + o.p_be;
+    pr.y = e.enc + (long)c.n_cam * c.bottleneck; pr.ld_y = e.ld; pr.xhat = e.pxhat; pr.rstd = e.prstd;
+    if (j.act_dst) {
+      pr.copy_src = j.act_src; pr.ld_copy_src = c.act_dim; pr.copy_dst = j.act_dst; pr.ld_copy_dst = a->XA;
+      pr.copy_cols = c.act_dim;
+    }
   }
-  const int S = split_for(cnt, c.bottleneck, c.n_cam, 32);  // K = 4096: up to 32 slices of 128
-  GemmDesc g{};
-  g.A = e.f; g.sAm = a->D; g.sAk = 1; g.sAb = (long)c.batch * a->D;
-  g.B = P + o.cam[0].dW; g.sBk = c.bottleneck; g.sBn = 1; g.sBb = o.cam_stride;
-  g.C = a->slabs; g.ldc = c.bottleneck; g.sCz = (long)cnt * c.bottleneck;
-  g.M = cnt; g.N = c.bottleneck; g.K = a->D; g.nbatch = c.n_cam; g.splitk = S;
-  RC(gemm_f32(g, st));
-  LnFwdArgs l{};
-  l.slabs = a->slabs; l.S = S; l.slab_stride = g.sCz;
-  l.bias = P + o.cam[0].db; l.gamma = P + o.cam[0].lng; l.beta = P + o.cam[0].lnb; l.pstride = o.cam_stride;
-  l.rows = c.n_cam * cnt; l.rows_per_group = cnt;
-  l.y = e.enc; l.ld_y = e.ld; l.y_goff = c.bottleneck;
-  l.xhat = e.xhat; l.rstd = e.rstd;
-  RC(ln_tanh_fwd(l, c.bottleneck, st));
-  // proprio branch (encoding.py:55-70): one fused kernel
-  RC(proprio_fwd(a->cur.state + ((long)which * Bfull + off) * c.state_dim, c.state_dim, P + o.p_W, P + o.p_b, P + o.p_g,
-                 P + o.p_be, cnt, e.enc + (long)c.n_cam * c.bottleneck, e.ld, e.pxhat, e.prstd, st));
-  return SERL_OK;
+  RC(sle_fwd_multi(sv, n, 1.0f / (1.0f - c.dropout), cnt, a->HW, 512, c.n_cam, (long)c.batch * a->HW * 512, o.cam_stride,
+                   Bfull * a->D, (long)c.batch * a->D, st));
+  RC(gemm_f32_multi(gd, n, st));
+  RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
+  return proprio_fwd_multi(pv, n, c.state_dim, cnt, st);
 }
 
-// generic Dense -> LN -> tanh layer on `rows_per_group` rows for `groups` parameter groups
-int dense_ln_tanh(serl_agent* a, const float* X, long ldx, long x_gstride, const float* W, long w_gstride,
-                  const float* bias, const float* gamma, const float* beta, long p_gstride, int groups,
-                  int rows_per_group, int K, int splitk, float* y, float* xhat, float* rstd, hipStream_t st,
-                  const float* dot_w = nullptr, const float* dot_b = nullptr, float* dot_out = nullptr) {
+// generic Dense -> LN -> tanh layer on `rows_per_group` rows for `groups` parameter groups, for n independent
+// instances with identical shapes (instance i: operands of job i, split-K scratch slabs_lane[i])
+struct DenseJob {
+  const float* X; long ldx, x_gstride;
+  const float* W; long w_gstride;
+  const float *bias, *gamma, *beta; long p_gstride;
+  float *y, *xhat, *rstd;
+  const float *dot_w, *dot_b; float* dot_out;  // optional fused row-dot (shared critic head)
+};
+int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, int rows_per_group, int K, int splitk,
+                        hipStream_t st) {
   const int Hd = a->cfg.hidden;
-  splitk = split_for(rows_per_group, Hd, groups, splitk);
-  GemmDesc g{};
-  g.A = X; g.sAm = ldx; g.sAk = 1; g.sAb = x_gstride;
-  g.B = W; g.sBk = Hd; g.sBn = 1; g.sBb = w_gstride;
-  g.C = a->slabs; g.ldc = Hd; g.sCz = (long)rows_per_group * Hd;
-  g.M = rows_per_group; g.N = Hd; g.K = K; g.nbatch = groups; g.splitk = splitk;
-  RC(gemm_f32(g, st));
-  LnFwdArgs l{};
-  l.slabs = a->slabs; l.S = splitk; l.slab_stride = g.sCz;
-  l.bias = bias; l.gamma = gamma; l.beta = beta; l.pstride = p_gstride;
-  l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
-  l.y = y; l.ld_y = Hd; l.y_goff = (long)rows_per_group * Hd;
-  l.xhat = xhat; l.rstd = rstd;
-  l.dot_w = dot_w; l.dot_b = dot_b; l.dot_out = dot_out;
-  return ln_tanh_fwd(l, Hd, st);
+  SERL_REQUIRE(n >= 1 && n <= 3, "bad dense instance count");
+  splitk = split_for(rows_per_group, Hd, groups * n, splitk);
+  GemmDesc gd[3];
+  LnFwdArgs lv[3];
+  for (int i = 0; i < n; ++i) {
+    const DenseJob& j = jobs[i];
+    GemmDesc& g = gd[i];
+    g = GemmDesc{};
+    g.A = j.X; g.sAm = j.ldx; g.sAk = 1; g.sAb = j.x_gstride;
+    g.B = j.W; g.sBk = Hd; g.sBn = 1; g.sBb = j.w_gstride;
+    g.C = a->slabs_lane[i]; g.ldc = Hd; g.sCz = (long)rows_per_group * Hd;
+    g.M = rows_per_group; g.N = Hd; g.K = K; g.nbatch = groups; g.splitk = splitk;
+    LnFwdArgs& l = lv[i];
+    l = LnFwdArgs{};
+    l.slabs = a->slabs_lane[i]; l.S = splitk; l.slab_stride = g.sCz;
+    l.bias = j.bias; l.gamma = j.gamma; l.beta = j.beta; l.pstride = j.p_gstride;
+    l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
+    l.y = j.y; l.ld_y = Hd; l.y_goff = (long)rows_per_group * Hd;
+    l.xhat = j.xhat; l.rstd = j.rstd;
+    l.dot_w = j.dot_w; l.dot_b = j.dot_b; l.dot_out = j.dot_out;
+  }
+  RC(gemm_f32_multi(gd, n, st));
+  return ln_tanh_fwd_multi(lv, n, Hd, st);
 }
 
-// Policy forward + tanh-Gaussian sample (actor_critic_nets.py:179-227)
-int policy_fwd(serl_agent* a, const float* P, PolBuf& pb, const float* enc, long ld_enc, int cnt, const float* eps,
-               float* act_out, long ld_act, float* sum_logp, hipStream_t st) {
+// Policy forward + tanh-Gaussian sample (actor_critic_nets.py:179-227) for n independent inputs
+struct PolJob {
+  const float* P; PolBuf* pb;
+  const float* enc; long ld_enc;
+  const float* eps;
+  float* act_out; long ld_act;
+  float* sum_logp;
+  float* alpha_out;  // optional rider: alpha = softplus(lagrange) of P (lagrange.py:49-50)
+};
+int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const int Hd = c.hidden, A = c.act_dim;
-  RC(dense_ln_tanh(a, enc, ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0, 1, cnt, a->E, 8,
-                   pb.m.h1, pb.m.xh1, pb.m.rs1, st));
-  RC(dense_ln_tanh(a, pb.m.h1, Hd, 0, P + o.a_w2, 0, P + o.a_b2, P + o.a_g2, P + o.a_be2, 0, 1, cnt, Hd, 4,
-                   pb.m.h2, pb.m.xh2, pb.m.rs2, st));
-  GemmDesc g{};
-  g.A = pb.m.h2; g.sAm = Hd; g.sAk = 1; g.sAb = 0;
-  g.B = P + o.a_Wm; g.sBk = A; g.sBn = 1; g.sBb = o.a_Ws - o.a_Wm;
-  g.C = a->slabs; g.ldc = A; g.sCz = (long)cnt * A;
-  g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 1;
-  RC(gemm_f32(g, st));
-  return policy_dist_fwd(a->slabs, P + o.a_bm, P + o.a_bs, pb.pre, eps, cnt, A, c.std_min, c.std_max, act_out, ld_act,
-                         pb.logp, pb.std, sum_logp, st);
+  SERL_REQUIRE(n >= 1 && n <= 3, "bad policy instance count");
+  DenseJob d1[3], d2[3];
+  GemmDesc gd[3];
+  PolicyDistArgs pv[3];
+  for (int i = 0; i < n; ++i) {
+    const PolJob& j = jobs[i];
+    const float* P = j.P;
+    PolBuf& pb = *j.pb;
+    d1[i] = DenseJob{j.enc, j.ld_enc, 0, P + o.a_w1, 0, P + o.a_b1, P + o.a_g1, P + o.a_be1, 0,
+                     pb.m.h1, pb.m.xh1, pb.m.rs1, nullptr, nullptr, nullptr};
+    d2[i] = DenseJob{pb.m.h1, Hd, 0, P + o.a_w2, 0, P + o.a_b2, P + o.a_g2, P + o.a_be2, 0,
+                     pb.m.h2, pb.m.xh2, pb.m.rs2, nullptr, nullptr, nullptr};
+    GemmDesc& g = gd[i];
+    g = GemmDesc{};
+    g.A = pb.m.h2; g.sAm = Hd; g.sAk = 1; g.sAb = 0;
+    g.B = P + o.a_Wm; g.sBk = A; g.sBn = 1; g.sBb = o.a_Ws - o.a_Wm;
+    g.C = a->slabs_lane[i]; g.ldc = A; g.sCz = (long)cnt * A;
+    g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 1;
+    pv[i] = PolicyDistArgs{a->slabs_lane[i], P + o.a_bm, P + o.a_bs, pb.pre, j.eps, j.act_out, j.ld_act, pb.logp, pb.std,
+                           j.sum_logp, P + o.lam, j.alpha_out};
+  }
+  RC(dense_ln_tanh_multi(a, d1, n, 1, cnt, a->E, 8, st));
+  RC(dense_ln_tanh_multi(a, d2, n, 1, cnt, Hd, 4, st));
+  RC(gemm_f32_multi(gd, n, st));
+  return policy_dist_fwd_multi(pv, n, cnt, A, c.std_min, c.std_max, st);
 }
 
-// Critic ensemble forward on x = [enc | action] (actor_critic_nets.py:56-73, drq.py:201-207)
-int critic_fwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, hipStream_t st) {
+// Critic ensemble forward on x = [enc | action] (actor_critic_nets.py:56-73, drq.py:201-207) for n independent
+// (parameters, input) pairs; the shared Q head is fused into the LN kernel of layer 2
+struct CritJob { const float* P; CritBuf* cb; };
+int critic_fwd_multi(serl_agent* a, const CritJob* jobs, int n, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const int Hd = c.hidden, N = c.ensemble;
-  RC(dense_ln_tanh(a, cb.x, a->XA, 0, P + o.c_w1, (long)a->XA * Hd, P + o.c_b1, P + o.c_g1, P + o.c_be1, Hd, N,
-                   cnt, a->XA, 4, cb.m.h1, cb.m.xh1, cb.m.rs1, st));
-  RC(dense_ln_tanh(a, cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2,
-                   P + o.c_be2, Hd, N, cnt, Hd, 2, cb.m.h2, cb.m.xh2, cb.m.rs2, st, P + o.c_hw, P + o.c_hb, cb.q));
-  return SERL_OK;  // shared Q head fused into the LN kernel of layer 2
+  SERL_REQUIRE(n >= 1 && n <= 3, "bad critic instance count");
+  DenseJob d1[3], d2[3];
+  for (int i = 0; i < n; ++i) {
+    const float* P = jobs[i].P;
+    CritBuf& cb = *jobs[i].cb;
+    d1[i] = DenseJob{cb.x, a->XA, 0, P + o.c_w1, (long)a->XA * Hd, P + o.c_b1, P + o.c_g1, P + o.c_be1, Hd,
+                     cb.m.h1, cb.m.xh1, cb.m.rs1, nullptr, nullptr, nullptr};
+    d2[i] = DenseJob{cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2, P + o.c_be2, Hd,
+                     cb.m.h2, cb.m.xh2, cb.m.rs2, P + o.c_hw, P + o.c_hb, cb.q};
+  }
+  RC(dense_ln_tanh_multi(a, d1, n, N, cnt, a->XA, 4, st));
+  return dense_ln_tanh_multi(a, d2, n, N, cnt, Hd, 2, st);
 }
 
 // backward of one Dense->LN->tanh layer.  dy: [groups*rows][Hd] gradient wrt the layer output.
@@ -464,7 +507,7 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
   l.dq = dq; l.dq_w = dq_w; l.dq_const = dq_const;
   RC(ln_tanh_bwd(l, D, st));
   if (G) {
-    RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, pg_lane(a, st)));
+    RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, st));
   }
   return SERL_OK;
 }
@@ -513,12 +556,12 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
                        N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st, dq, P + o.c_hw, dq_const));
   if (pg)
     RC(wgrad(cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
-             cnt, pgs(a, st)));
+             cnt, st));
   RC(igrad(a->da2, Hd, (long)cnt * Hd, P + o.c_w2, Hd, (long)Hd * Hd, a->dh1, Hd, (long)cnt * Hd, N, cnt, Hd, Hd, st));
   RC(dense_ln_tanh_bwd(a, a->dh1, Hd, (long)cnt * Hd, cb.m.h1, Hd, (long)cnt * Hd, cb.m.xh1, cb.m.rs1, P + o.c_g1, Hd,
                        N, cnt, Hd, a->da1, a->dg1, G, o.c_g1, o.c_be1, o.c_b1, Hd, st));
   if (pg)
-    RC(wgrad(cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, pgs(a, st)));
+    RC(wgrad(cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, st));
   // dx = sum_e da1[e] * W1[e]^T
   RC(igrad(a->da1, Hd, (long)cnt * Hd, P + o.c_w1, Hd, (long)a->XA * Hd, a->slabs, a->XA, (long)cnt * a->XA, N, cnt,
            a->XA, Hd, st));
@@ -535,7 +578,7 @@ int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt
                        c.n_cam, cnt, Bn, a->dz, a->dgz, a->Gc, o.cam[0].lng, o.cam[0].lnb, o.cam[0].db,
                        o.cam_stride, st));
   RC(wgrad(e.f, a->D, (long)c.batch * a->D, a->dz, Bn, (long)cnt * Bn, a->Gc + o.cam[0].dW, Bn, o.cam_stride,
-           c.n_cam, a->D, Bn, cnt, pgs(a, st)));
+           c.n_cam, a->D, Bn, cnt, st));
   RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
            a->D, Bn, st));
   const long sle_n = (long)a->HW * 512 * c.sle_features;
@@ -558,42 +601,35 @@ int proprio_bwd(serl_agent* a, const float* P, const float* dy, long ld_dy, cons
   RC(dense_ln_tanh_bwd(a, dy, ld_dy, 0, y, ld_y, 0, e.pxhat, e.prstd, P + o.p_g, 0, 1, cnt, Pd, a->dp, a->dgp, G,
                        o.p_g - base_off, o.p_be - base_off, o.p_b - base_off, 0, st));
   const float* s = a->cur.state + ((long)which * a->cur.batch + off) * c.state_dim;
-  return wgrad(s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, pgs(a, st));
+  return wgrad(s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, st);
 }
 
-int fetch_noise(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot, int cnt_total,
-                const float** eps, const uint8_t** mask, hipStream_t st) {
+// Noise of one update phase: caller-provided tensors are used as they are (parity mode), missing ones are
+// generated on the device -- all of them by ONE launch (NoiseBatch::flush).
+struct NoiseBatch {
+  NoiseJob jobs[kMaxMulti];
+  int n = 0;
+  int flush(hipStream_t st) { return n ? gen_noise_multi(jobs, n, st) : SERL_OK; }
+};
+void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const uint8_t* given_mask, int slot,
+                 int cnt_total, const float** eps, const uint8_t** mask) {
   const serl_agent_cfg& c = a->cfg;
   if (given_eps) *eps = given_eps;
   else {
-    RC(gen_normal(a->eps_buf[slot], (long)cnt_total * c.act_dim, c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr)), st));
+    nb.jobs[nb.n++] = NoiseJob{a->eps_buf[slot], (long)cnt_total * c.act_dim, c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr)), 0, 0.f};
     *eps = a->eps_buf[slot];
   }
   if (given_mask) *mask = given_mask;
   else {
-    RC(gen_mask(a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D, c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)),
-                1.0f - c.dropout, st));
+    nb.jobs[nb.n++] = NoiseJob{a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D,
+                               c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)), 1, 1.0f - c.dropout};
     *mask = a->mask_buf[slot];
   }
-  return SERL_OK;
 }
 
 float lr_at(const serl_agent_cfg& c, int64_t count) {  // optimizers.py:23-30
   if (count < c.warmup_steps) return c.lr * (float)count / (float)c.warmup_steps;
   return c.lr;
-}
-
-__global__ void info_critic_kernel(const float* sc, float* acc, float inv_eb, float inv_b, float w) {
-  acc[I_CL] += w * sc[S_D2] * inv_eb;
-  acc[I_PQ] += w * sc[S_Q] * inv_eb;
-  acc[I_TQ] += w * sc[S_Y] * inv_b;
-}
-__global__ void info_actor_kernel(const float* sc, float* acc, float inv_b, float target_entropy, const float* aux) {
-  const float alpha = aux[X_ALPHA];
-  acc[I_AL] = -(sc[S_QPI] - alpha * sc[S_LOGP]) * inv_b;
-  acc[I_TEMP] = alpha;
-  acc[I_ENT] = -sc[S_LOGP] * inv_b;
-  acc[I_TL] = alpha * (-sc[S_LOGP_NEXT] * inv_b - target_entropy);
 }
 
 }  // namespace
@@ -622,18 +658,6 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   carve(a, a->arena);
   SERL_HIP(hipMemset(a->arena, 0, bytes));
   bind_trunk_weights(a);
-  {
-    // intra-update multi-stream concurrency is correct but measured 2-3x SLOWER (every cross-stream event wait
-    // costs tens of microseconds on this stack, more than the small kernels it overlaps): off unless
-    // SERL_HEADS_STREAMS=1.  The update chain is shortened by batching/fusing its kernels instead.
-    const char* e = getenv("SERL_HEADS_STREAMS");
-    a->concurrent = e && e[0] == '1';
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
-    for (int k = 0; k < 2; ++k) SERL_HIP(hipStreamCreateWithPriority(&a->side[k], hipStreamNonBlocking, hi));
-    SERL_HIP(hipStreamCreateWithPriority(&a->pg, hipStreamNonBlocking, hi));
-    for (int k = 0; k < 32; ++k) SERL_HIP(hipEventCreateWithFlags(&a->evp[k], hipEventDisableTiming));
-  }
   *out = a;
   return SERL_OK;
 }
@@ -642,11 +666,6 @@ int serl_agent_destroy(serl_agent* a) {
   if (!a) return SERL_OK;
   (void)hipSetDevice(a->cfg.device);
   (void)hipDeviceSynchronize();
-  for (int k = 0; k < 2; ++k)
-    if (a->side[k]) (void)hipStreamDestroy(a->side[k]);
-  if (a->pg) (void)hipStreamDestroy(a->pg);
-  for (int k = 0; k < 32; ++k)
-    if (a->evp[k]) (void)hipEventDestroy(a->evp[k]);
   if (a->arena) (void)hipFree(a->arena);
   delete a;
   return SERL_OK;
@@ -796,7 +815,8 @@ int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream) {
 int serl_agent_begin_update(serl_agent* a, void* stream) {
   SERL_REQUIRE(a, "NULL agent");
   SERL_HIP(hipSetDevice(a->cfg.device));
-  SERL_HIP(hipMemsetAsync(a->info_acc, 0, sizeof(float) * I_N, (hipStream_t)stream));
+  (void)stream;
+  a->info_reset = true;  // the next critic step's info kernel zeroes the accumulators (no memset launch)
   return SERL_OK;
 }
 
@@ -820,38 +840,28 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
   }
   SERL_REQUIRE(i0 >= 0 && i0 < c.ensemble && i1 >= 0 && i1 < c.ensemble, "REDQ index out of range");
   const float* eps; const uint8_t* mask;
-  RC(fetch_noise(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask, st));
+  NoiseBatch nb;
+  fetch_noise(a, nb, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask);
+  RC(nb.flush(st));
   const int A = c.act_dim;
-  // three independent chains: lane 1 = online policy at next_obs (dropout) then the target critic,
-  // lane 2 = target encoder at next_obs, lane 0 (caller's stream) = online critic at obs
-  hipStream_t s1 = lane(a, st, 1);
-  RC(fork_to(a, st, s1));
-  RC(encode(a, a->theta, 1, off, cnt, mask, a->encP, s1));
-  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, cnt, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, s1));
-  hipStream_t s2 = lane(a, st, 2);
-  RC(fork_to(a, st, s2));
-  RC(encode(a, a->theta_t, 1, off, cnt, nullptr, a->encT, s2));  // target_params, encoder train=False
-  RC(fork_to(a, s2, s1));
-  s1 = lane(a, st, 1);
-  RC(critic_fwd(a, a->theta_t, a->critT, cnt, s1));
-  hipStream_t s0 = lane(a, st, 0);
-  RC(encode(a, a->theta, 0, off, cnt, nullptr, a->encO, s0));
-  RC(copy_cols(a->cur.action + (long)off * A, A, a->crit.x + a->E, a->XA, cnt, A, s0));
-  RC(critic_fwd(a, a->theta, a->crit, cnt, s0));
-  RC(fork_to(a, s1, s0));
+  // the three encoder passes of the critic loss in one set of launches: online policy input at next_obs
+  // (dropout), target-critic input at next_obs (target_params, train=False), online-critic input at obs
+  // (train=False; the batch's actions ride along into [enc | action])
+  const EncJob ej[3] = {{a->theta, 1, mask, &a->encP, nullptr, nullptr},
+                        {a->theta_t, 1, nullptr, &a->encT, nullptr, nullptr},
+                        {a->theta, 0, nullptr, &a->encO, a->cur.action + (long)off * A, a->crit.x + a->E}};
+  RC(encode_multi(a, ej, 3, off, cnt, st));
+  const PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, nullptr};
+  RC(policy_fwd_multi(a, &pj, 1, cnt, st));
+  const CritJob cj[2] = {{a->theta_t, &a->critT}, {a->theta, &a->crit}};  // target and online ensembles together
+  RC(critic_fwd_multi(a, cj, 2, cnt, st));
   const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
   RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
-                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, s0));
-  RC(critic_bwd(a, a->theta, a->crit, cnt, true, s0, a->dq, 0.f));
-  // proprio branch on lane 2 while the camera heads run on the caller's stream
-  s2 = lane(a, st, 2);
-  RC(fork_to(a, s0, s2));
+                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st));
+  RC(critic_bwd(a, a->theta, a->crit, cnt, true, st, a->dq, 0.f));
   RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
-                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, s2));
-  s0 = lane(a, st, 0);
-  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, s0));
-  RC(fork_to(a, s2, s0));
-  RC(fork_to(a, pgs(a, s0), s0));
+                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
+  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -865,23 +875,22 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   const int cnt = a->cur.batch, A = c.act_dim, Hd = c.hidden;
   SERL_REQUIRE(global_count >= cnt, "global_count < local batch");
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
-  RC(fetch_noise(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi, st));
-  RC(fetch_noise(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t, st));
-  RC(temperature_alpha(a->theta + o.lam, a->aux + X_ALPHA, st));
-  // lane 1: temperature loss = entropy of pi(next_obs) (sac.py:223-234); lane 2: critic-side encoding of obs
-  // (train=False); caller's stream: policy loss chain (sac.py:193-221)
-  hipStream_t s1 = lane(a, st, 1);
-  RC(fork_to(a, st, s1));
-  RC(encode(a, a->theta, 1, 0, cnt, mask_t, a->encT, s1));
-  RC(policy_fwd(a, a->theta, a->polT, a->encT.enc, a->encT.ld, cnt, eps_t, a->act_tmp, A, a->SC + S_LOGP_NEXT, s1));
-  hipStream_t s2 = lane(a, st, 2);
-  RC(fork_to(a, st, s2));
-  RC(encode(a, a->theta, 0, 0, cnt, nullptr, a->encO, s2));
-  hipStream_t s0 = lane(a, st, 0);
-  RC(encode(a, a->theta, 0, 0, cnt, mask_pi, a->encP, s0));
-  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, cnt, eps_pi, a->crit.x + a->E, a->XA, a->SC + S_LOGP, s0));
-  RC(fork_to(a, s2, s0));
-  RC(critic_fwd(a, a->theta, a->crit, cnt, s0));
+  NoiseBatch nb;
+  fetch_noise(a, nb, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi);
+  fetch_noise(a, nb, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t);
+  RC(nb.flush(st));
+  hipStream_t s0 = st;
+  // encoder passes of the actor step in one set of launches: temperature loss input (next_obs, dropout;
+  // sac.py:223-234), critic-side encoding of obs (train=False), policy input at obs (dropout; sac.py:193-221)
+  const EncJob ej[3] = {{a->theta, 1, mask_t, &a->encT, nullptr, nullptr},
+                        {a->theta, 0, nullptr, &a->encO, nullptr, nullptr},
+                        {a->theta, 0, mask_pi, &a->encP, nullptr, nullptr}};
+  RC(encode_multi(a, ej, 3, 0, cnt, s0));
+  const PolJob pj[2] = {{a->theta, &a->polT, a->encT.enc, a->encT.ld, eps_t, a->act_tmp, A, a->SC + S_LOGP_NEXT, a->aux + X_ALPHA},
+                        {a->theta, &a->pol, a->encP.enc, a->encP.ld, eps_pi, a->crit.x + a->E, a->XA, a->SC + S_LOGP, nullptr}};
+  RC(policy_fwd_multi(a, pj, 2, cnt, s0));
+  const CritJob cj{a->theta, &a->crit};
+  RC(critic_fwd_multi(a, &cj, 1, cnt, s0));
   RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, s0));
   RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0, nullptr, -1.0f / ((float)c.ensemble * (float)global_count)));
   RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
@@ -890,26 +899,21 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   const long hs = o.a_Ws - o.a_Wm;
   float* Ga = a->Ga;
   const long b0 = o.Pa0;
-  {
-    hipStream_t pg = pg_lane(a, s0);
-    RC(wgrad(a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, pg));
-    RC(colsum(a->dpre, nullptr, 2, cnt, A, Ga + (o.a_bm - b0), hs, false, pg));
-  }
+  RC(wgrad(a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, s0));
+  RC(colsum(a->dpre, nullptr, 2, cnt, A, Ga + (o.a_bm - b0), hs, false, s0));
   RC(igrad(a->dpre, A, (long)cnt * A, a->theta + o.a_Wm, A, hs, a->slabs, Hd, (long)cnt * Hd, 2, cnt, Hd, A, s0));
   RC(reduce_slabs(a->slabs, 2, (long)cnt * Hd, 1, cnt, Hd, nullptr, 0, a->dh2, Hd, 0, false, s0));
   RC(dense_ln_tanh_bwd(a, a->dh2, Hd, 0, a->pol.m.h2, Hd, 0, a->pol.m.xh2, a->pol.m.rs2, a->theta + o.a_g2, 0, 1, cnt, Hd,
                        a->da2, a->dg2, Ga, o.a_g2 - b0, o.a_be2 - b0, o.a_b2 - b0, 0, s0));
-  RC(wgrad(a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, pgs(a, s0)));
+  RC(wgrad(a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, s0));
   RC(igrad(a->da2, Hd, 0, a->theta + o.a_w2, Hd, 0, a->dh1, Hd, 0, 1, cnt, Hd, Hd, s0));
   RC(dense_ln_tanh_bwd(a, a->dh1, Hd, 0, a->pol.m.h1, Hd, 0, a->pol.m.xh1, a->pol.m.rs1, a->theta + o.a_g1, 0, 1, cnt, Hd,
                        a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, s0));
-  RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, pgs(a, s0)));
+  RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, s0));
   // image codes are stop-gradiented (encoding.py:48-49); only the proprio slice of d_enc is needed
   const long pc = (long)c.n_cam * c.bottleneck;
   RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, s0));
   RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, s0));
-  RC(fork_to(a, s1, s0));
-  RC(fork_to(a, pgs(a, s0), s0));
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -936,16 +940,14 @@ int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) 
   ad.bc2 = 1.0f - powf(0.999f, (float)t);
   ad.tau = c.tau; ad.target_entropy = c.target_entropy;
   ad.inv_batch = a->last_global > 0 ? 1.0f / (float)a->last_global : 0.f;
-  if (crit) {
-    hipLaunchKernelGGL(info_critic_kernel, dim3(1), dim3(1), 0, st, a->SC, a->info_acc,
-                       1.0f / ((float)c.ensemble * (float)a->last_global), 1.0f / (float)a->last_global, info_weight);
-  } else {
-    hipLaunchKernelGGL(info_actor_kernel, dim3(1), dim3(1), 0, st, a->SC, a->info_acc, 1.0f / (float)a->last_global,
-                       c.target_entropy, a->aux);
-  }
-  SERL_HIP(hipGetLastError());
+  ad.frozen = a->trunk; ad.frozen_target = a->trunk_t; ad.n_frozen = a->trunk_count;  // common.py:124-134 covers every leaf
+  ad.info_mode = crit ? 1 : 2;
+  ad.info_reset = (crit && a->info_reset) ? 1 : 0;
+  if (crit) a->info_reset = false;
+  ad.scalars = a->SC; ad.alpha = a->aux + X_ALPHA; ad.info_acc = a->info_acc;
+  ad.info_w = info_weight;
+  ad.inv_eb = a->last_global > 0 ? 1.0f / ((float)c.ensemble * (float)a->last_global) : 0.f;
   RC(adam_ema(ad, st));
-  if (crit) RC(ema(a->trunk, a->trunk_t, c.tau, a->trunk_count, st));  // common.py:124-134 covers every leaf
   a->step += 1;
   a->lr_last = lr;
   return SERL_OK;
@@ -1014,12 +1016,14 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   a->cur = serl_batch{};
   a->cur.batch = n;
   a->cur.state = const_cast<float*>(dev_state);
-  RC(encode(a, a->theta, 0, 0, n, nullptr, a->encP, st));  // train=False: no dropout
+  const EncJob ej{a->theta, 0, nullptr, &a->encP, nullptr, nullptr};  // train=False: no dropout
+  RC(encode_multi(a, &ej, 1, 0, n, st));
   if (!dev_eps) {  // argmax -> mode = tanh(mean): zero noise
     RC(fill(a->eps_buf[0], 0.f, (long)n * c.act_dim, st));
     dev_eps = a->eps_buf[0];
   }
-  RC(policy_fwd(a, a->theta, a->pol, a->encP.enc, a->encP.ld, n, dev_eps, dev_out_actions, c.act_dim, nullptr, st));
+  const PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, dev_eps, dev_out_actions, c.act_dim, nullptr, nullptr};
+  RC(policy_fwd_multi(a, &pj, 1, n, st));
   a->cur = saved;
   a->has_batch = had;
   a->feats = saved_feats;

@@ -4,6 +4,15 @@
 
 namespace serl {
 
+// The update chain is a long sequence of small dependent kernels, each costing ~5 us of launch/drain latency
+// whatever its size: independent instances of the same kind of work (the three EncodingWrapper passes of a
+// loss, the online and target critics, the two policy evaluations of the actor step) share one launch.
+constexpr int kMaxMulti = 4;
+template <typename T>
+struct Multi { T v[kMaxMulti]; };
+constexpr int kMaxGemmGroups = 6;
+int gemm_f32_multi(const GemmDesc* groups, int n, hipStream_t stream);  // same operand layout in every group
+
 int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int rows, int N, const float* bias,
                  long bias_gstride, float* out, long ld_out, long out_gstride, bool accumulate,
                  hipStream_t stream, float scale = 1.0f);
@@ -21,6 +30,7 @@ struct LnFwdArgs {
   const float* dot_w; const float* dot_b; float* dot_out;
 };
 int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream);
+int ln_tanh_fwd_multi(const LnFwdArgs* a, int n, int D, hipStream_t stream);
 
 struct LnBwdArgs {
   const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y (ignored in rank-1 mode)
@@ -41,6 +51,9 @@ int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, i
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
 int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
             int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream);
+struct SleFwdArgs { const float* x; const float* K; const uint8_t* mask; float* f; };
+int sle_fwd_multi(const SleFwdArgs* v, int n, float keep_scale, int N, int HW, int Cc, int groups, long x_gs, long k_gs,
+                  long mask_gs, long f_gs, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
             long x_gs, long df_gs, long part_gs, hipStream_t stream);
 int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);
@@ -52,6 +65,18 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
 int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
                     int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
                     float* sum_logp, hipStream_t stream);
+struct PolicyDistArgs {
+  const float* slabs; const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
+  float* act; long ld_act; float* logp; float* std_out; float* sum_logp;
+  const float* lam; float* alpha_out;  // optional rider: alpha_out[0] = softplus(lam[0])
+};
+int policy_dist_fwd_multi(const PolicyDistArgs* v, int n, int B, int A, float std_min, float std_max, hipStream_t stream);
+struct ProprioArgs {
+  const float* state; const float *W, *b, *gamma, *beta;
+  float* y; long ld_y; float* xhat; float* rstd;
+  const float* copy_src; long ld_copy_src; float* copy_dst; long ld_copy_dst; int copy_cols;  // optional rider
+};
+int proprio_fwd_multi(const ProprioArgs* v, int n, int S, int rows, hipStream_t stream);
 // proprio branch: y = tanh(LN(state W + b)) with W [S][64] (encoding.py:55-70), one wave per row
 int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
                 int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream);
@@ -72,9 +97,18 @@ struct AdamArgs {
   float* temp_grad_out;        // device scalar (debug/export)
   int critic_on, actor_on, temp_on;
   float lr_c, lr_a, lr_t, bc1, bc2, tau, target_entropy, inv_batch;
+  // frozen (trunk) leaves appended to the index space when critic_on: target EMA only (common.py:124-134)
+  const float* frozen; float* frozen_target; long n_frozen;
+  // info rider: 0 = none, 1 = critic step, 2 = actor/temperature step.  Slot order of `scalars` / `info_acc` as in
+  // agent.hip (S_* / I_* enums); info_acc has 8 floats.
+  int info_mode, info_reset;
+  const float* scalars; const float* alpha; float* info_acc;
+  float info_w, inv_eb;
 };
 int adam_ema(const AdamArgs& a, hipStream_t stream);
 int ema(const float* p, float* tp, float tau, long n, hipStream_t stream);
+struct NoiseJob { void* out; long n; uint64_t seed; int kind; float keep; };  // kind 0: N(0,1) f32, 1: keep-mask u8
+int gen_noise_multi(const NoiseJob* v, int n, hipStream_t stream);
 int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream);
 int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream);
 

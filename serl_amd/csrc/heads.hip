@@ -2,6 +2,8 @@
 // the fused elementwise/normalisation kernels around it (LayerNorm+tanh forward/backward,
 // SpatialLearnedEmbeddings, tanh-Gaussian policy head, REDQ target, losses, 3x Adam + target EMA).
 // Reference semantics are cited per kernel (paths relative to serl_launcher/serl_launcher/).
+#include <algorithm>
+
 #include "heads.h"
 #include "prof.h"
 
@@ -92,14 +94,26 @@ struct OperandLoader {
   }
 };
 
+// Several independent GEMMs in one launch (the chain is latency-bound: one launch per *kind* of work, not per
+// instance): group i owns blockIdx.z in [zend[i-1], zend[i]); the x/y grid is the maximum over the groups.
+struct GemmMulti {
+  GemmDesc d[kMaxGemmGroups];
+  int zend[kMaxGemmGroups];
+  int n;
+};
+
 template <bool A_KFAST, bool B_KFAST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmDesc g) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
   __shared__ __attribute__((aligned(16))) float As[kGBM][kGP];  // [m][k]
   __shared__ __attribute__((aligned(16))) float Bs[kGBN][kGP];  // [n][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z, batch = z / g.splitk, split = z - batch * g.splitk;
+  int grp = 0;
+  while (grp + 1 < mm.n && (int)blockIdx.z >= mm.zend[grp]) ++grp;
+  const GemmDesc& g = mm.d[grp];
+  const int z = blockIdx.z - (grp ? mm.zend[grp - 1] : 0), batch = z / g.splitk, split = z - batch * g.splitk;
   const int m0 = blockIdx.y * kGBM, n0 = blockIdx.x * kGBN;
+  if (m0 >= g.M || n0 >= g.N) return;
   const int kper = ((g.K + g.splitk - 1) / g.splitk + kGBK - 1) / kGBK * kGBK;
   const int k_begin = split * kper, k_end = min(g.K, k_begin + kper);
   float* C = g.C + (long)z * g.sCz;
@@ -180,21 +194,42 @@ __global__ __launch_bounds__(256) void gemm_f32_strided_kernel(GemmDesc g) {
   }
 }
 
-int gemm_f32(const GemmDesc& g, hipStream_t stream) {
-  SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
-  dim3 grid(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk);
-  const bool a_k = g.sAk == 1, a_m = g.sAm == 1, b_k = g.sBk == 1, b_n = g.sBn == 1;
-  if ((a_k || a_m) && (b_k || b_n)) {
-    if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, g);
-    else if (a_k) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, g);
-    else if (b_k) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, g);
+int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxGemmGroups, "bad GEMM group count %d", n);
+  GemmMulti mm{};
+  mm.n = n;
+  int gx = 0, gy = 0, z = 0;
+  const bool a_k = gs[0].sAk == 1, a_m = gs[0].sAm == 1, b_k = gs[0].sBk == 1, b_n = gs[0].sBn == 1;
+  const bool vec = (a_k || a_m) && (b_k || b_n);
+  for (int i = 0; i < n; ++i) {
+    const GemmDesc& g = gs[i];
+    SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
+    if (vec)  // one kernel instantiation per launch: every group must have the layout of the first
+      SERL_REQUIRE((a_k ? g.sAk == 1 : g.sAm == 1) && (b_k ? g.sBk == 1 : g.sBn == 1), "mixed operand layouts in a GEMM group");
+    mm.d[i] = g;
+    gx = std::max(gx, cdiv(g.N, kGBN));
+    gy = std::max(gy, cdiv(g.M, kGBM));
+    z += g.nbatch * g.splitk;
+    mm.zend[i] = z;
+  }
+  dim3 grid(gx, gy, z);
+  if (vec) {
+    if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
+    else if (a_k) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
+    else if (b_k) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, mm);
   } else {
-    hipLaunchKernelGGL(gemm_f32_strided_kernel, grid, dim3(256), 0, stream, g);
+    for (int i = 0; i < n; ++i) {
+      const GemmDesc& g = gs[i];
+      hipLaunchKernelGGL(gemm_f32_strided_kernel, dim3(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk), dim3(256), 0,
+                         stream, g);
+    }
   }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
+
+int gemm_f32(const GemmDesc& g, hipStream_t stream) { return gemm_f32_multi(&g, 1, stream); }
 
 // out[g][row][col] (+)= bias[g][col] + sum_s slab[g*S + s][row][col]
 __global__ void reduce_slabs_kernel(const float* slabs, int S, long slab_stride, int rows, int N,
@@ -227,7 +262,8 @@ int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int ro
 // encoding.py:66-68.   pre = bias[g] + sum_s slab[s][row];  y = tanh(gamma[g]*xhat + beta[g])
 // =============================================================================================
 template <int VPL>
-__global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(LnFwdArgs a) {
+__global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
+  const LnFwdArgs& a = mv.v[blockIdx.y];  // blockIdx.y = independent instance (variant)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= a.rows) return;
   const int grp = row / a.rows_per_group;
@@ -294,14 +330,19 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(LnFwdArgs a) {
   }
 }
 
-int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream) {
+int ln_tanh_fwd_multi(const LnFwdArgs* as, int n, int D, hipStream_t stream) {
   SERL_REQUIRE(D == 256 || D == 64, "LayerNorm width %d unsupported (64 or 256)", D);
-  dim3 grid(cdiv(a.rows, 4));
-  if (D == 256) hipLaunchKernelGGL(ln_tanh_fwd_kernel<4>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(ln_tanh_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<LnFwdArgs> mv{};
+  int rows = 0;
+  for (int i = 0; i < n; ++i) { mv.v[i] = as[i]; rows = std::max(rows, as[i].rows); }
+  dim3 grid(cdiv(rows, 4), n);
+  if (D == 256) hipLaunchKernelGGL(ln_tanh_fwd_kernel<4>, grid, dim3(256), 0, stream, mv);
+  else hipLaunchKernelGGL(ln_tanh_fwd_kernel<1>, grid, dim3(256), 0, stream, mv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
+int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream) { return ln_tanh_fwd_multi(&a, 1, D, stream); }
 
 // backward of y = tanh(gamma*xhat + beta), xhat = (x-mean)*rstd:
 //   dg = dy*(1-y^2);  dxhat = dg*gamma;  dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
@@ -420,13 +461,15 @@ int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, i
 // SpatialLearnedEmbeddings (resnet_v1.py:94-111): f[n][c*F+j] = sum_hw x[n][hw][c]*K[hw][c][j]
 // (+ Dropout(0.1) keep-mask, resnet_v1.py:351).  F == 8.
 // =============================================================================================
-__global__ __launch_bounds__(256) void sle_fwd_kernel(const float* x, const float* K, const uint8_t* mask,
-                                                     float keep_scale, float* f, int N, int HW, int Cc, long xs,
-                                                     long ks, long ms, long fs) {
+__global__ __launch_bounds__(256) void sle_fwd_kernel(Multi<SleFwdArgs> mv, float keep_scale, int N, int HW, int Cc,
+                                                     long xs, long ks, long ms, long fs) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long)N * Cc) return;
-  x += blockIdx.y * xs; K += blockIdx.y * ks; f += blockIdx.y * fs;  // blockIdx.y = camera
-  if (mask) mask += blockIdx.y * ms;
+  const SleFwdArgs& v = mv.v[blockIdx.z];  // blockIdx.z = instance, blockIdx.y = camera
+  const float* x = v.x + blockIdx.y * xs;
+  const float* K = v.K + blockIdx.y * ks;
+  float* f = v.f + blockIdx.y * fs;
+  const uint8_t* mask = v.mask ? v.mask + blockIdx.y * ms : nullptr;
   const int n = (int)(e / Cc), c = (int)(e - (long)n * Cc);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int hw = 0; hw < HW; ++hw) {
@@ -446,12 +489,21 @@ __global__ __launch_bounds__(256) void sle_fwd_kernel(const float* x, const floa
   *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
-            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream) {
-  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256), groups), dim3(256), 0, stream, x, K, mask,
-                     keep_scale, f, N, HW, Cc, x_gs, k_gs, mask_gs, f_gs);
+int sle_fwd_multi(const SleFwdArgs* vs, int n, float keep_scale, int N, int HW, int Cc, int groups, long x_gs, long k_gs,
+                  long mask_gs, long f_gs, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<SleFwdArgs> mv{};
+  for (int i = 0; i < n; ++i) mv.v[i] = vs[i];
+  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256), groups, n), dim3(256), 0, stream, mv, keep_scale, N,
+                     HW, Cc, x_gs, k_gs, mask_gs, f_gs);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
+}
+
+int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
+            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream) {
+  const SleFwdArgs v{x, K, mask, f};
+  return sle_fwd_multi(&v, 1, keep_scale, N, HW, Cc, groups, x_gs, k_gs, mask_gs, f_gs, stream);
 }
 
 // dK partial[split][hw][c][j] = sum_{n in split} x[n][hw][c] * df[n][c*8+j]
@@ -573,27 +625,25 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
 // =============================================================================================
 __device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
-__global__ void policy_dist_fwd_kernel(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre,
-                                       const float* eps, int B, int A, float std_min, float std_max, float* act,
-                                       long ld_act, float* logp, float* std_out,
-                                       float* sum_logp /* nullable: scalar accumulated by one block */) {
+__global__ void policy_dist_fwd_kernel(Multi<PolicyDistArgs> mv, int B, int A, float std_min, float std_max) {
+  const PolicyDistArgs& v = mv.v[blockIdx.x];  // one workgroup per instance
   __shared__ float red[256];
   float local = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) {
-      const float mean = slabs[(long)b * A + j] + bias_mean[j], ls = slabs[((long)B + b) * A + j] + bias_ls[j];
-      const float e = eps[(long)b * A + j];
-      pre[(long)b * A + j] = mean;
-      pre[((long)B + b) * A + j] = ls;
+      const float mean = v.slabs[(long)b * A + j] + v.bias_mean[j], ls = v.slabs[((long)B + b) * A + j] + v.bias_ls[j];
+      const float e = v.eps[(long)b * A + j];
+      v.pre[(long)b * A + j] = mean;
+      v.pre[((long)B + b) * A + j] = ls;
       const float sd = fminf(fmaxf(expf(ls), std_min), std_max);
       const float u = mean + sd * e;
-      act[(long)b * ld_act + j] = tanhf(u);
-      std_out[(long)b * A + j] = sd;
+      v.act[(long)b * v.ld_act + j] = tanhf(u);
+      v.std_out[(long)b * A + j] = sd;
       lp += -0.5f * e * e - logf(sd) - 0.91893853320467274f;
       lp -= 2.f * (0.69314718055994531f - u - softplusf(-2.f * u));
     }
-    logp[b] = lp;
+    v.logp[b] = lp;
     local += lp;
   }
   red[threadIdx.x] = local;
@@ -602,43 +652,63 @@ __global__ void policy_dist_fwd_kernel(const float* slabs, const float* bias_mea
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && sum_logp) *sum_logp = red[0];
+  if (threadIdx.x == 0 && v.sum_logp) *v.sum_logp = red[0];
+  if (threadIdx.x == 0 && v.alpha_out) v.alpha_out[0] = softplusf(v.lam[0]);
+}
+
+int policy_dist_fwd_multi(const PolicyDistArgs* vs, int n, int B, int A, float std_min, float std_max, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<PolicyDistArgs> mv{};
+  for (int i = 0; i < n; ++i) mv.v[i] = vs[i];
+  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(n), dim3(256), 0, stream, mv, B, A, std_min, std_max);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
 }
 
 int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
                     int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
                     float* sum_logp, hipStream_t stream) {
-  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(1), dim3(256), 0, stream, slabs, bias_mean, bias_ls, pre, eps, B, A,
-                     std_min, std_max, act, ld_act, logp, std_out, sum_logp);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
+  const PolicyDistArgs v{slabs, bias_mean, bias_ls, pre, eps, act, ld_act, logp, std_out, sum_logp, nullptr, nullptr};
+  return policy_dist_fwd_multi(&v, 1, B, A, std_min, std_max, stream);
 }
 
 // proprio branch (encoding.py:55-70): y = tanh(LayerNorm_1e-6(state W + b)), W [S][64]; one wave per row,
 // lane = output feature.  Replaces a GEMM + LN launch pair for this tiny layer.
-__global__ __launch_bounds__(256) void proprio_fwd_kernel(const float* state, int S, const float* W, const float* b,
-                                                         const float* gamma, const float* beta, int rows, float* y,
-                                                         long ld_y, float* xhat, float* rstd_out) {
+__global__ __launch_bounds__(256) void proprio_fwd_kernel(Multi<ProprioArgs> mv, int S, int rows) {
+  const ProprioArgs& a = mv.v[blockIdx.y];
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  float v = b[lane];
-  for (int s = 0; s < S; ++s) v += state[(long)row * S + s] * W[s * 64 + lane];
+  float v = a.b[lane];
+  for (int s = 0; s < S; ++s) v += a.state[(long)row * S + s] * a.W[s * 64 + lane];
   float s1 = v, s2 = v * v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
   const float mean = s1 * (1.0f / 64), var = fmaxf(s2 * (1.0f / 64) - mean * mean, 0.f);
   const float rstd = rsqrtf(var + 1e-6f), xh = (v - mean) * rstd;
-  y[(long)row * ld_y + lane] = tanhf(xh * gamma[lane] + beta[lane]);
-  if (xhat) xhat[(long)row * 64 + lane] = xh;
-  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+  a.y[(long)row * a.ld_y + lane] = tanhf(xh * a.gamma[lane] + a.beta[lane]);
+  if (a.xhat) a.xhat[(long)row * 64 + lane] = xh;
+  if (a.rstd && lane == 0) a.rstd[row] = rstd;
+  // optional column copy riding along (the batch's actions into the critic input [enc | action])
+  if (a.copy_dst && lane < a.copy_cols) a.copy_dst[(long)row * a.ld_copy_dst + lane] = a.copy_src[(long)row * a.ld_copy_src + lane];
+}
+
+int proprio_fwd_multi(const ProprioArgs* vs, int n, int S, int rows, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<ProprioArgs> mv{};
+  for (int i = 0; i < n; ++i) {
+    mv.v[i] = vs[i];
+    SERL_REQUIRE(!vs[i].copy_dst || vs[i].copy_cols <= 64, "copy_cols > 64");
+  }
+  hipLaunchKernelGGL(proprio_fwd_kernel, dim3(cdiv(rows, 4), n), dim3(256), 0, stream, mv, S, rows);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
 }
 
 int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
                 int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream) {
-  hipLaunchKernelGGL(proprio_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, state, S, W, b, gamma, beta, rows,
-                     y, ld_y, xhat, rstd);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
+  ProprioArgs v{};
+  v.state = state; v.W = W; v.b = b; v.gamma = gamma; v.beta = beta; v.y = y; v.ld_y = ld_y; v.xhat = xhat; v.rstd = rstd;
+  return proprio_fwd_multi(&v, 1, S, rows, stream);
 }
 
 // backward of the actor loss through the distribution:
@@ -734,7 +804,28 @@ int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream) {
 // =============================================================================================
 __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.P) return;
+  if (i == 0 && a.info_mode) {  // info dict of this step (riding along: one launch less on the chain)
+    const float* sc = a.scalars;
+    float* acc = a.info_acc;
+    if (a.info_mode == 1) {  // critic step (sac.py:118-191); weighted mean over UTD minibatches
+      if (a.info_reset)
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      acc[0] += a.info_w * sc[0] * a.inv_eb;   // critic_loss
+      acc[1] += a.info_w * sc[1] * a.inv_eb;   // predicted_qs
+      acc[2] += a.info_w * sc[2] * a.inv_batch;  // target_qs
+    } else {  // actor + temperature step (sac.py:193-234)
+      const float alpha = a.alpha[0];
+      acc[3] = -(sc[3] - alpha * sc[4]) * a.inv_batch;  // actor_loss
+      acc[4] = alpha;                                   // temperature
+      acc[5] = -sc[4] * a.inv_batch;                    // entropy
+      acc[6] = alpha * (-sc[5] * a.inv_batch - a.target_entropy);  // temperature_loss
+    }
+  }
+  if (i >= a.P) {  // frozen-trunk leaves: no optimizer touches them, the target EMA still covers them
+    const long k = i - a.P;
+    if (a.critic_on && k < a.n_frozen) a.frozen_target[k] = a.frozen[k] * a.tau + a.frozen_target[k] * (1.f - a.tau);
+    return;
+  }
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   float p = a.theta[i];
   float ua = 0.f, uc = 0.f, ut = 0.f;
@@ -772,7 +863,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
 
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
   ProfScope prof("adam_ema", stream);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P, 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P + (a.critic_on ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -796,29 +887,38 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__global__ void gen_normal_kernel(float* out, long n, uint64_t seed) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t r = mix64(seed ^ mix64((uint64_t)i));
-  const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);
-  const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
-  out[i] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+__device__ __forceinline__ void gen_one(const NoiseJob& j, long i) {
+  if (i >= j.n) return;
+  if (j.kind == 0) {
+    const uint64_t r = mix64(j.seed ^ mix64((uint64_t)i));
+    const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    static_cast<float*>(j.out)[i] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+  } else {
+    const uint64_t r = mix64(j.seed ^ mix64((uint64_t)i + 0x51ED270Bull));
+    static_cast<uint8_t*>(j.out)[i] = ((float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f)) < j.keep ? 1 : 0;
+  }
 }
-__global__ void gen_mask_kernel(uint8_t* out, long n, uint64_t seed, float keep) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t r = mix64(seed ^ mix64((uint64_t)i + 0x51ED270Bull));
-  out[i] = ((float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f)) < keep ? 1 : 0;
+// all the noise of one update phase in one launch: blockIdx.y = job (a normal tensor or a keep-mask)
+__global__ void gen_noise_kernel(Multi<NoiseJob> mv) {
+  gen_one(mv.v[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x);
+}
+int gen_noise_multi(const NoiseJob* vs, int n, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad job count %d", n);
+  Multi<NoiseJob> mv{};
+  long nmax = 0;
+  for (int i = 0; i < n; ++i) { mv.v[i] = vs[i]; nmax = std::max(nmax, vs[i].n); }
+  hipLaunchKernelGGL(gen_noise_kernel, dim3(cdiv(nmax, 256), n), dim3(256), 0, stream, mv);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
 }
 int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
-  hipLaunchKernelGGL(gen_normal_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, n, seed);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
+  const NoiseJob j{out, n, seed, 0, 0.f};
+  return gen_noise_multi(&j, 1, stream);
 }
 int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream) {
-  hipLaunchKernelGGL(gen_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, n, seed, keep);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
+  const NoiseJob j{out, n, seed, 1, keep};
+  return gen_noise_multi(&j, 1, stream);
 }
 
 }  // namespace serl
