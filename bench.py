@@ -57,6 +57,9 @@ class _DictSp:
         self.spaces = spaces
 
 
+PROFILE_EVERY = 4   # HIP events around every 4th launch of each kernel tag inside the timed region
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +144,7 @@ def main():
         iteration()
     barrier()
     # (SERL_BENCH_NOPROF=1: diagnostic run without the per-kernel HIP events -- measures their overhead)
-    _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else 1))
+    _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else PROFILE_EVERY))
     _lib.check(_lib.lib().serl_profile_reset())
     barrier()
     t0 = time.perf_counter()
@@ -151,6 +154,14 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_read()
     _lib.check(_lib.lib().serl_profile_enable(0))
+    torch.cuda.synchronize()
+    # host cost of enqueueing one iteration on empty queues (diagnostic: is the chain launch-bound?)
+    host_ms = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        iteration()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     info = core.read_info()
     assert all(np.isfinite(v) for v in info.values()), info
@@ -166,7 +177,7 @@ def main():
     n_img = 2 * len(KEYS) * Bl
     per_kernel, tot_flop, tot_ms = {}, 0.0, 0.0
     for tag, (ms, cnt) in sorted(prof.items()):
-        ent = {"avg_us": 1e3 * ms / cnt, "launches": cnt}
+        ent = {"avg_us": 1e3 * ms / cnt, "timed_launches": cnt}
         if tag in macs:
             fl = 2.0 * macs[tag] * n_img
             ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
@@ -192,13 +203,14 @@ def main():
         # 3x the algorithmic FLOPs, and that executed rate is what the fp16-MFMA roofline bounds
         executed = 3.0 * achieved
         roofline = {"bound": "mfma",
-                    "kernel": "conv_igemm_f16x3_kernel (split-fp16 MFMA implicit GEMM, fp32 accumulate; 11 launches per trunk pass)",
+                    "kernel": "conv_igemm_f16x3_kernel + conv3x3_rowpatch_f16x3_kernel (split-fp16 MFMA implicit GEMM, fp32 accumulate; 11 launches per trunk pass)",
                     "achieved": round(executed, 3), "peak": PEAK_F16_MFMA, "unit": "TFLOP/s",
                     "frac": round(executed / PEAK_F16_MFMA, 4), "traffic": traffic,
                     "algorithmic_tflops": round(achieved, 3),
                     "algorithmic_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4),
                     "note": "achieved = 3 x algorithmic fp32 conv FLOP/s (executed fp16 MFMA work); "
-                            "algorithmic_tflops = 2*M*K*N per launch / HIP-event duration",
+                            "algorithmic_tflops = 2*M*K*N per launch / HIP-event duration; "
+                            f"HIP events around every {PROFILE_EVERY}th launch of each kernel inside the timed region",
                     "flop_per_launch_avg": tot_flop / n_launch, "per_kernel": per_kernel}
     else:
         roofline = {"bound": "mfma",
@@ -225,7 +237,7 @@ def main():
                    "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
         "roofline": roofline,
         "last_info": {k: round(float(v), 6) for k, v in info.items()},
-        "setup": {"replay_fill_s": round(fill_s, 2)},
+        "host_enqueue_ms_per_iteration": round(min(host_ms), 4), "setup": {"replay_fill_s": round(fill_s, 2)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -38,8 +38,10 @@ int serl_version(void);
 /* number of visible HIP devices (0 if none); does not fail without a GPU */
 int serl_device_count(void);
 
-/* Per-launch HIP-event timing of the hot kernels (off by default).  serl_profile_read returns, per
- * instrumented kernel tag, the summed duration and launch count since the last reset:
+/* HIP-event timing of the hot kernels (off by default).  serl_profile_enable(k): k = 0 off, k >= 1 times every
+ * k-th launch of each instrumented tag (an event pair costs a few microseconds on the stream, which matters
+ * once the step itself is below a millisecond).  serl_profile_read returns, per tag, the summed duration and
+ * the number of TIMED launches since the last reset:
  * names is char[max_entries][64]. Used by bench.py for the live roofline numbers. */
 int serl_profile_enable(int on);
 int serl_profile_reset(void);

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libserl_mi355.so")
+# SERL_MI355_LIB: load another build of the same ABI (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("SERL_MI355_LIB") or os.path.join(_HERE, "lib", "libserl_mi355.so")
 
 MAX_CAMS = 4
 MAX_BUFFERS = 2

@@ -11,13 +11,14 @@ namespace {
 struct Pair { hipEvent_t a, b; int key; };
 struct State {
   std::mutex mu;
-  bool on = false;
+  int period = 0;  // 0 = off, k >= 1: time every k-th launch of each tag
   std::vector<std::string> names;
   std::map<std::string, int> index;
   std::vector<Pair> pairs;       // recorded, not yet resolved
   std::vector<hipEvent_t> pool;  // free events
   std::vector<double> total_ms;
   std::vector<long long> count;
+  std::vector<long long> seen;   // launches of the tag since the last reset (timed or not)
 };
 State g;
 
@@ -43,7 +44,7 @@ void resolve_locked() {
 }  // namespace
 
 ProfScope::ProfScope(const char* name, hipStream_t s) : stream(s) {
-  if (!g.on) return;
+  if (!g.period) return;
   std::lock_guard<std::mutex> l(g.mu);
   auto it = g.index.find(name);
   int key;
@@ -53,7 +54,9 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : stream(s) {
     g.index[name] = key;
     g.total_ms.push_back(0.0);
     g.count.push_back(0);
+    g.seen.push_back(0);
   } else key = it->second;
+  if ((g.seen[key]++) % g.period) return;  // sampled: the events themselves cost a few us on the stream
   Pair p{get_event(), get_event(), key};
   (void)hipEventRecord(p.a, stream);
   g.pairs.push_back(p);
@@ -70,7 +73,7 @@ ProfScope::~ProfScope() {
 extern "C" {
 int serl_profile_enable(int on) {
   std::lock_guard<std::mutex> l(serl::g.mu);
-  serl::g.on = on != 0;
+  serl::g.period = on > 0 ? on : 0;
   return SERL_OK;
 }
 int serl_profile_reset(void) {
@@ -78,6 +81,7 @@ int serl_profile_reset(void) {
   serl::resolve_locked();
   for (auto& v : serl::g.total_ms) v = 0.0;
   for (auto& v : serl::g.count) v = 0;
+  for (auto& v : serl::g.seen) v = 0;
   return SERL_OK;
 }
 int serl_profile_read(int max_entries, char* names /* [max][64] */, double* total_ms, int64_t* counts, int* n_out) {
