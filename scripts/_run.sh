@@ -1,9 +1,14 @@
 mkdir -p gpurun_out/ab
-run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
-import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'], 'frac', d['roofline']['frac'])" || tail -3 gpurun_out/ab/$tag.err; }
-run n1 timeout 200 python bench.py --no-cpu-baseline
-run e8 timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8
-SERL_BENCH_NOPROF=1 run e8_noprof timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8
-run e4 timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 4
-run e2 timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 2
-timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+show() { python - "$1" <<'PY'
+import json,sys
+d=json.loads(open(f"gpurun_out/ab/{sys.argv[1]}.json").read().strip().splitlines()[-1])
+pk=d['roofline']['per_kernel']
+print(sys.argv[1], d['value'], d['ms_per_step'], ' '.join(f"{k}={v['avg_us']:.0f}" for k,v in pk.items() if not k.startswith('conv_igemm')))
+PY
+}
+P=$GRAFT_REPO_ROOT/serl_amd/lib/libserl_prev.so
+timeout 200 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/ab/pool_new.json 2>gpurun_out/ab/err; show pool_new
+SERL_MI355_LIB=$P timeout 200 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/ab/pool_prev.json 2>gpurun_out/ab/err; show pool_prev
+timeout 200 python bench.py --no-cpu-baseline --steps 60 --no-pipeline > gpurun_out/ab/pool_new_s.json 2>gpurun_out/ab/err; show pool_new_s
+SERL_MI355_LIB=$P timeout 200 python bench.py --no-cpu-baseline --steps 60 --no-pipeline > gpurun_out/ab/pool_prev_s.json 2>gpurun_out/ab/err; show pool_prev_s
+timeout 300 python -m pytest tests/test_agent_gpu.py -x -q -k "trunk_forward" 2>&1 | tail -2

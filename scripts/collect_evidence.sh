@@ -12,4 +12,11 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python $R/bench
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --no-cpu-baseline --no-pipeline --fill 1500 --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
 done
-ls -R $O | head -30
+cd $R
+python scripts/pmc_to_json.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_traffic.json
+python scripts/rocprof_summary.py $(find $O/stats -name '*results.db' | head -1) $O/kernel_stats.csv || true
+# multi-GPU projection: one rank's share of a world-size-N job on this GPU (no collective)
+for w in 2 4 8; do timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world $w > $O/bench_emulate_world$w.json 2> $O/bench_emu$w.err; done
+timeout 200 python bench.py --no-cpu-baseline --no-pipeline > $O/bench_serial.json 2> $O/bench_serial.err
+find $O -name '*.csv' -size +8M -delete
+ls -R $O | head -40

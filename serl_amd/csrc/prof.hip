@@ -56,7 +56,10 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : stream(s) {
     g.count.push_back(0);
     g.seen.push_back(0);
   } else key = it->second;
-  if ((g.seen[key]++) % g.period) return;  // sampled: the events themselves cost a few us on the stream
+  // sampled (the events themselves cost a few us on the stream); the phase drifts by one every `period`
+  // launches so that a tag launched `period` times per step with different shapes is sampled evenly
+  const long long n = g.seen[key]++;
+  if ((n + n / g.period) % g.period) return;
   Pair p{get_event(), get_event(), key};
   (void)hipEventRecord(p.a, stream);
   g.pairs.push_back(p);
