@@ -74,6 +74,8 @@ def main():
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
@@ -86,9 +88,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert B % world == 0
     Bl = B // world
@@ -128,8 +131,10 @@ def main():
     from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
     sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank))
     learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world,
-                                  all_reduce=(lambda t: dist.all_reduce(t)) if world > 1 else (lambda t: None),
+                                  all_reduce=(lambda t: dist.all_reduce(t)) if dist is not None else (lambda t: None),
                                   seed=7, schedule=sched)
+
+    learner.force_reduce = args.force_collective
 
     def iteration():
         learner.iteration(args.car)
@@ -241,10 +246,19 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    # the JSON line must be the last thing on stdout: librccl prints its version banner through C stdio, which is
+    # block-buffered when stdout is a pipe/file and would otherwise surface after this line at exit
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(budget_s):

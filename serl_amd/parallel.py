@@ -125,6 +125,7 @@ class DataParallelLearner:
         self._redq_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 2])))
         self._gv = {}
         self._pending = None   # slot of the prefetched (sampled + gathered + encoded) batch
+        self.force_reduce = False   # diagnostic: issue the collectives even with one rank
         self._next_slot = 0
 
     def _view(self, which):
@@ -133,7 +134,7 @@ class DataParallelLearner:
         return self._gv[which]
 
     def _reduce(self, which):
-        if self.world > 1:
+        if self.world > 1 or self.force_reduce:
             self.all_reduce(self._view(which))
 
     def _produce(self):

@@ -326,3 +326,35 @@ def test_full_size_properties(gpu):
     info = core.read_info()
     assert all(np.isfinite(v) for v in info.values()), info
     assert core.step == 3 and not np.array_equal(w0, core.get("params", "critic/w1"))
+
+
+def test_rccl_all_reduce_on_the_zero_copy_gradient_view(gpu):
+    """The data-parallel step all-reduces the library's gradient memory in place through a torch view that the
+    caching allocator does not own.  A one-rank RCCL group runs the real ProcessGroupNCCL path (stream
+    bookkeeping on foreign memory included) on this single GPU; N > 1 is covered on CPU with gloo."""
+    import os
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+        _, core = AH.make_pair(cfg, 8)
+        sl, _ = AH.leaf_slices(cfg)
+        pc = sl["enc/proprio/ln/bias"][1]
+        g = np.random.default_rng(0).standard_normal(pc).astype(np.float32)
+        core.debug_set("g_critic", g)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for which in (1, 2):
+                dist.all_reduce(core.grad_view(which))
+        torch.cuda.synchronize()
+        assert np.array_equal(core.debug("g_critic", pc), g)
+    finally:
+        dist.destroy_process_group()
