@@ -62,7 +62,10 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot
 // A operand = activations already in "split16" layout (written by the elementwise producers below):
 // per 4 channels one 16-byte record {hi x4 fp16 | lo' x4 fp16}, i.e. the same footprint and addressing
 // as the fp32 NHWC tensor.  The conv loader is then a pure 16-byte copy global -> LDS (zero VALU math).
-template <int WM, int WN, int TM, int TN, int PMODE>
+// DEEP = 2 / 3: that many K chunks in flight in registers instead of one (0).  With the 64x64 tile (small M: one rank's share of a
+// data-parallel batch) there is about one workgroup per CU and a chunk is only 6 MFMAs per wave, so the K loop runs
+// at global-load latency (~1 us per chunk with one chunk in flight); the register budget of that tile allows more.
+template <int WM, int WN, int TM, int TN, int PMODE, int DEEP = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   const ConvArgs& a = ab.c;
@@ -99,11 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     }
   }
   const int nchunks = a.KH * a.KW * (a.Cin >> 5);
-  uint4 ra[AI], rb[BI];
-  unsigned okmask = 0;
+  // (native vector types: HIP's uint4 struct copies lower to memcpy and keep the arrays out of registers)
+  u32x4 ra[AI], rb[BI], ra2[DEEP >= 2 ? AI : 1], rb2[DEEP >= 2 ? BI : 1], ra3[DEEP >= 3 ? AI : 1], rb3[DEEP >= 3 ? BI : 1];
+  unsigned okmask = 0, okmask2 = 0, okmask3 = 0;
   int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0;  // chunk counters (chunks are visited strictly in order)
 
-#define SERL_LOAD_CHUNK(CIDX)                                                                                  \
+#define SERL_LOAD_CHUNK_(CIDX, RA, RB, OK)                                                                                \
   {                                                                                                            \
     const int c_ = (CIDX);                                                                                     \
     const int tap = l_tap, ci0 = l_ci0;                                                                        \
@@ -113,34 +117,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       l_ci0 += 32;                                                                                             \
       if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
     }                                                                                                          \
-    okmask = 0;                                                                                                \
+    OK = 0;                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       const bool ok = (rmask[i] >> tap) & 1u;                                                                  \
-      okmask |= (ok ? 1u : 0u) << i;                                                                           \
-      ra[i] = *reinterpret_cast<const uint4*>(a.in + rbase[i] + (ok ? toff_ : ci0));                           \
+      OK |= (ok ? 1u : 0u) << i;                                                                               \
+      RA[i] = *reinterpret_cast<const u32x4*>(a.in + rbase[i] + (ok ? toff_ : ci0));                           \
     }                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
       const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (min(c_, nchunks - 1) << 5) + s_ * 8; \
-      rb[i] = *reinterpret_cast<const uint4*>(wp_);                                                            \
+      RB[i] = *reinterpret_cast<const u32x4*>(wp_);                                                            \
     }                                                                                                          \
   }
-#define SERL_STORE_CHUNK(BUF)                                                                                  \
+#define SERL_STORE_CHUNK_(BUF, RA, RB, OK)                                                                                  \
   {                                                                                                            \
     uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
-      uint4 v = ra[i];                                                                                         \
-      if (!((okmask >> i) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);                                               \
+      u32x4 v = RA[i];                                                                                         \
+      if (!((OK >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                                      \
       const int row_ = (tid >> 3) + 32 * i;                                                                    \
       const int off_ = swz(row_, kq >> 1) + (kq & 1) * 8;                                                      \
-      *reinterpret_cast<uint2*>(st_ + off_) = make_uint2(v.x, v.y);                                            \
-      *reinterpret_cast<uint2*>(st_ + A_PLANE + off_) = make_uint2(v.z, v.w);                                  \
+      *reinterpret_cast<u32x2*>(st_ + off_) = (u32x2){v[0], v[1]};                                             \
+      *reinterpret_cast<u32x2*>(st_ + A_PLANE + off_) = (u32x2){v[2], v[3]};                                   \
     }                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
-      *reinterpret_cast<uint4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = rb[i];                   \
+      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = RB[i];                   \
     }                                                                                                          \
   }
 
@@ -152,41 +156,68 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
 
-  const int li = lane & 31, lh = lane >> 5;
-  SERL_LOAD_CHUNK(0);
-  SERL_STORE_CHUNK(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    SERL_LOAD_CHUNK(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
-    const uint8_t* st = smemb + buf * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);
-        ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);
-        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + off);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int off = 2 * A_PLANE + swz(wn * WCOLS + tn * 32 + li, 2 * ks + lh);
-        bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);
-        blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-        }
-    }
-    SERL_STORE_CHUNK(buf ^ 1);
-    __syncthreads();
+#define SERL_LOAD_CHUNK(CIDX) SERL_LOAD_CHUNK_(CIDX, ra, rb, okmask)
+#define SERL_STORE_CHUNK(BUF) SERL_STORE_CHUNK_(BUF, ra, rb, okmask)
+#define SERL_COMPUTE_CHUNK(BUF)                                                                                \
+  {                                                                                                            \
+    const uint8_t* st = smemb + (BUF) * STAGE;                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];                                                                \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                      \
+        const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);                                           \
+        ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
+        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + off);                                         \
+      }                                                                                                        \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                      \
+        const int off = 2 * A_PLANE + swz(wn * WCOLS + tn * 32 + li, 2 * ks + lh);                             \
+        bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
+        blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);                                         \
+      }                                                                                                        \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                        \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                    \
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);      \
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);      \
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);        \
+        }                                                                                                      \
+    }                                                                                                          \
   }
+  const int li = lane & 31, lh = lane >> 5;
+  if (!DEEP) {
+    SERL_LOAD_CHUNK(0);
+    SERL_STORE_CHUNK(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      const int buf = c & 1;
+      SERL_LOAD_CHUNK(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
+      SERL_COMPUTE_CHUNK(buf);
+      SERL_STORE_CHUNK(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // register set (c mod DEEP) holds chunk c+1 while chunk c is computed; its loads were issued DEEP iterations ago
+    SERL_LOAD_CHUNK(0);
+    SERL_STORE_CHUNK(0);
+    SERL_LOAD_CHUNK(1);
+    SERL_LOAD_CHUNK_(2, ra2, rb2, okmask2);
+    if (DEEP >= 3) SERL_LOAD_CHUNK_(3, ra3, rb3, okmask3);
+    __syncthreads();
+#define SERL_DEEP_STEP(C, RA, RB, OK)                    \
+  {                                                      \
+    SERL_COMPUTE_CHUNK((C) & 1);                         \
+    SERL_STORE_CHUNK_(((C) + 1) & 1, RA, RB, OK);        \
+    SERL_LOAD_CHUNK_((C) + 1 + DEEP, RA, RB, OK);        \
+    __syncthreads();                                     \
+  }
+    for (int c = 0; c < nchunks; c += DEEP) {
+      SERL_DEEP_STEP(c, ra, rb, okmask);
+      if (c + 1 < nchunks) SERL_DEEP_STEP(c + 1, ra2, rb2, okmask2);
+      if (DEEP >= 3 && c + 2 < nchunks) SERL_DEEP_STEP(c + 2, ra3, rb3, okmask3);
+    }
+#undef SERL_DEEP_STEP
+  }
+#undef SERL_COMPUTE_CHUNK
+#undef SERL_LOAD_CHUNK_
+#undef SERL_STORE_CHUNK_
 #undef SERL_LOAD_CHUNK
 #undef SERL_STORE_CHUNK
 
@@ -985,7 +1016,20 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
 #undef SERL_LAUNCH_WS
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
-    else SERL_LAUNCH_CONV(2, 2, 1, 1);
+    else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
+      static const int deep = []() { const char* e = getenv("SERL_CONV_DEEP"); return e ? atoi(e) : 3; }();
+#define SERL_LAUNCH_DEEP(D)                                                                                                      \
+  do {                                                                                                                           \
+    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 0, D>), grid, block, lds, stream, ab);                \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 1, D>), grid, block, lds, stream, ab);           \
+    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 2, D>), grid, block, lds, stream, ab);           \
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 3, D>), grid, block, lds, stream, ab);                           \
+  } while (0)
+      if (deep >= 3) SERL_LAUNCH_DEEP(3);
+      else if (deep == 2) SERL_LAUNCH_DEEP(2);
+      else SERL_LAUNCH_CONV(2, 2, 1, 1);
+#undef SERL_LAUNCH_DEEP
+    }
 #undef SERL_LAUNCH_CONV
   }
   SERL_HIP(hipGetLastError());
