@@ -215,6 +215,11 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
 #define SERL_APPLY_ACTOR_TEMP 2
 int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream);
 int serl_agent_begin_update(serl_agent* a, void* stream); /* clears the info accumulator */
+/* Batch-sharded data parallelism: the batches this agent is given are rows [global_offset, global_offset + local
+ * batch) of a global batch of `global_batch` rows.  Device-generated noise (noise == NULL) is then indexed by the
+ * GLOBAL row, so a sample gets the same eps / dropout mask whichever rank owns it and results do not depend on the
+ * world size (the dormant pmean of common.py:213-214 made real).  global_batch = 0: not sharded (default). */
+int serl_agent_set_shard(serl_agent* a, int64_t global_offset, int64_t global_batch);
 /* which = SERL_APPLY_CRITIC: [critic grads | scalars]; SERL_APPLY_ACTOR_TEMP: [scalars | actor grads] */
 int serl_agent_grad_view(serl_agent* a, int which, float** dev_ptr, int64_t* count);
 

@@ -52,6 +52,7 @@ def declare(lib):
         "serl_agent_actor_grads": [vp, i32, P(SerlNoise), vp],
         "serl_agent_apply": [vp, i32, f32, vp],
         "serl_agent_begin_update": [vp, vp],
+        "serl_agent_set_shard": [vp, i64, i64],
         "serl_agent_grad_view": [vp, i32, P(vp), P(i64)],
         "serl_agent_sample_actions": [vp, vp, vp, i32, vp, vp, vp],
         "serl_agent_trunk_forward": [vp, vp, i32, vp, vp],

@@ -115,6 +115,10 @@ class AgentCore:
         return {n: getattr(info, n) for n, _ in SerlInfo._fields_}
 
     # ---- data-parallel phases --------------------------------------------------------------
+    def set_shard(self, global_offset: int, global_batch: int):
+        """This agent's batches are rows [global_offset, ...) of a global batch: device noise is indexed globally."""
+        _lib.check(self.L.serl_agent_set_shard(self._h, int(global_offset), int(global_batch)))
+
     def begin_update(self):
         _lib.check(self.L.serl_agent_begin_update(self._h, self._stream()))
 

@@ -115,6 +115,9 @@ struct serl_agent {
   float lr_last = 0.f;
   int last_global = 0;
   bool info_reset = true;
+  // batch-sharded data parallelism: this rank's local batch is rows [shard_off, shard_off + local) of a global
+  // batch of shard_global rows (0 = not sharded); device noise is indexed by the global row
+  int64_t shard_off = 0, shard_global = 0;
 };
 
 namespace {
@@ -616,13 +619,15 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
   const serl_agent_cfg& c = a->cfg;
   if (given_eps) *eps = given_eps;
   else {
-    nb.jobs[nb.n++] = NoiseJob{a->eps_buf[slot], (long)cnt_total * c.act_dim, c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr)), 0, 0.f};
+    nb.jobs[nb.n++] = NoiseJob{a->eps_buf[slot], (long)cnt_total * c.act_dim, c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr)), 0, 0.f,
+                               cnt_total, a->shard_global, a->shard_off, c.act_dim};
     *eps = a->eps_buf[slot];
   }
   if (given_mask) *mask = given_mask;
   else {
     nb.jobs[nb.n++] = NoiseJob{a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D,
-                               c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)), 1, 1.0f - c.dropout};
+                               c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)), 1, 1.0f - c.dropout,
+                               cnt_total, a->shard_global, a->shard_off, a->D};
     *mask = a->mask_buf[slot];
   }
 }
@@ -817,6 +822,15 @@ int serl_agent_begin_update(serl_agent* a, void* stream) {
   SERL_HIP(hipSetDevice(a->cfg.device));
   (void)stream;
   a->info_reset = true;  // the next critic step's info kernel zeroes the accumulators (no memset launch)
+  return SERL_OK;
+}
+
+int serl_agent_set_shard(serl_agent* a, int64_t global_offset, int64_t global_batch) {
+  SERL_REQUIRE(a, "NULL agent");
+  SERL_REQUIRE(global_batch == 0 || (global_offset >= 0 && global_offset < global_batch), "bad shard [%lld of %lld]",
+               (long long)global_offset, (long long)global_batch);
+  a->shard_off = global_batch ? global_offset : 0;
+  a->shard_global = global_batch;
   return SERL_OK;
 }
 

@@ -107,7 +107,10 @@ struct AdamArgs {
 };
 int adam_ema(const AdamArgs& a, hipStream_t stream);
 int ema(const float* p, float* tp, float tau, long n, hipStream_t stream);
-struct NoiseJob { void* out; long n; uint64_t seed; int kind; float keep; };  // kind 0: N(0,1) f32, 1: keep-mask u8
+// kind 0: N(0,1) f32, 1: keep-mask u8.  The tensor is [planes][rows_local][row_elems]; the value of an element is a
+// hash of its position in the GLOBAL tensor [planes][rows_global][row_elems] (rows row_offset.. of it), so that a
+// batch-sharded job draws the same noise for a sample whichever rank owns it (rows_global == 0: local == global)
+struct NoiseJob { void* out; long n; uint64_t seed; int kind; float keep; long rows_local, rows_global, row_offset, row_elems; };
 int gen_noise_multi(const NoiseJob* v, int n, hipStream_t stream);
 int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream);
 int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream);

@@ -887,16 +887,21 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__device__ __forceinline__ void gen_one(const NoiseJob& j, long i) {
-  if (i >= j.n) return;
+__device__ __forceinline__ void gen_one(const NoiseJob& j, long i0) {
+  if (i0 >= j.n) return;
+  long i = i0;  // position in the global tensor
+  if (j.rows_global) {
+    const long e = i0 % j.row_elems, rr = i0 / j.row_elems, r = rr % j.rows_local, plane = rr / j.rows_local;
+    i = (plane * j.rows_global + j.row_offset + r) * j.row_elems + e;
+  }
   if (j.kind == 0) {
     const uint64_t r = mix64(j.seed ^ mix64((uint64_t)i));
     const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);
     const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
-    static_cast<float*>(j.out)[i] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    static_cast<float*>(j.out)[i0] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
   } else {
     const uint64_t r = mix64(j.seed ^ mix64((uint64_t)i + 0x51ED270Bull));
-    static_cast<uint8_t*>(j.out)[i] = ((float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f)) < j.keep ? 1 : 0;
+    static_cast<uint8_t*>(j.out)[i0] = ((float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f)) < j.keep ? 1 : 0;
   }
 }
 // all the noise of one update phase in one launch: blockIdx.y = job (a normal tensor or a keep-mask)
@@ -913,11 +918,11 @@ int gen_noise_multi(const NoiseJob* vs, int n, hipStream_t stream) {
   return SERL_OK;
 }
 int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
-  const NoiseJob j{out, n, seed, 0, 0.f};
+  const NoiseJob j{out, n, seed, 0, 0.f, 0, 0, 0, 1};
   return gen_noise_multi(&j, 1, stream);
 }
 int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream) {
-  const NoiseJob j{out, n, seed, 1, keep};
+  const NoiseJob j{out, n, seed, 1, keep, 0, 0, 0, 1};
   return gen_noise_multi(&j, 1, stream);
 }
 

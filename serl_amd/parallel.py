@@ -126,6 +126,8 @@ class DataParallelLearner:
         self._gv = {}
         self._pending = None   # slot of the prefetched (sampled + gathered + encoded) batch
         self.force_reduce = False   # diagnostic: issue the collectives even with one rank
+        if world > 1 and hasattr(core, "set_shard"):
+            core.set_shard(rank * self.Bl, self.B)   # device noise indexed by the global sample id
         self._next_slot = 0
 
     def _view(self, which):

@@ -358,3 +358,35 @@ def test_rccl_all_reduce_on_the_zero_copy_gradient_view(gpu):
         assert np.array_equal(core.debug("g_critic", pc), g)
     finally:
         dist.destroy_process_group()
+
+
+def test_device_noise_is_indexed_by_the_global_sample(gpu):
+    """Production noise (noise=None) in a batch-sharded job: with set_shard every rank draws, for each of its
+    samples, the eps / dropout mask the single-GPU run draws for that sample, so the shard gradients still sum
+    to the full-batch gradient (results independent of the world size)."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    B = 16
+    sl, _ = AH.leaf_slices(cfg)
+    n = sl["enc/proprio/ln/bias"][1]
+    b = AH.synth_batch(cfg, B, seed=5)
+    redq = {"redq_idx": np.array([[1, 7]], np.int32)}
+
+    def run(parts):
+        g = np.zeros(n, np.float64)
+        per = B // parts
+        for r in range(parts):
+            _, core = AH.make_pair(cfg, per)     # a fresh agent per shard = one rank: same seed, same noise counter
+            sub = {k: ({c: v[r * per:(r + 1) * per] for c, v in val.items()} if isinstance(val, dict) else val[r * per:(r + 1) * per])
+                   for k, val in b.items()}
+            db = AH.batch_to_device(cfg, sub)
+            core.set_shard(r * per, B if parts > 1 else 0)
+            core.begin_update()
+            core.encode(db)
+            core.critic_grads(0, per, B, redq)
+            g += core.debug("g_critic", n)
+        return g
+
+    full, halves, quarters = run(1), run(2), run(4)
+    assert np.abs(full).max() > 0
+    assert AH.rel_err(halves, full) < 1e-5
+    assert AH.rel_err(quarters, full) < 1e-5
