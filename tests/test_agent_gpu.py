@@ -390,3 +390,37 @@ def test_device_noise_is_indexed_by_the_global_sample(gpu):
     assert np.abs(full).max() > 0
     assert AH.rel_err(halves, full) < 1e-5
     assert AH.rel_err(quarters, full) < 1e-5
+
+
+# The shapes of BASELINE.json's other configurations at parity-test size:
+#   C3 async_drq_sim + demos: 2 cams, S=7, A=4, CAR=8 (7x update_critics + 1x update_high_utd)
+#   C4 peg insertion: wrist_1/wrist_2, S=19, A=6          C5 fwbw: front/wrist_1, S=19, A=7
+#   literal "1 camera" variant of C2
+@pytest.mark.parametrize("name,keys,S,A,car", [
+    ("C2_one_cam", ("front",), 7, 4, 1),
+    ("C3_demos_car8", ("front", "wrist"), 7, 4, 8),
+    ("C4_peg", ("wrist_1", "wrist_2"), 19, 6, 2),
+    ("C5_fwbw", ("front", "wrist_1"), 19, 7, 2),
+])
+def test_baseline_config_shapes_match_oracle(gpu, name, keys, S, A, car):
+    cfg = O.Config(image_keys=keys, H=64, W=64, S=S, A=A)
+    B = 8
+    st, core = AH.make_pair(cfg, B)
+    for it in range(car):
+        b = AH.synth_batch(cfg, B, seed=50 + it)
+        noise = O.make_noise(cfg, B, seed=60 + it)
+        tb, tn = AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64)
+        db, dn = AH.batch_to_device(cfg, b), AH.noise_to_device(cfg, noise)
+        if it < car - 1:
+            info, _ = O.update_critics(st, tb, tn)
+            core.update_critics(db, dn)
+            keys_ = ("critic_loss", "predicted_qs", "target_qs")
+        else:
+            info, _ = O.update_high_utd(st, tb, tn, 1)
+            core.update_high_utd(db, 1, dn)
+            keys_ = ("critic_loss", "predicted_qs", "target_qs", "actor_loss", "temperature", "entropy", "temperature_loss")
+        got = core.read_info()
+        for k in keys_:
+            assert abs(got[k] - info[k]) < 2 * TOL * max(1.0, abs(info[k])), (name, it, k, got[k], info[k])
+    _compare_state(cfg, st, core, tol=5e-4 if car > 2 else TOL, steps=car + 1)
+    assert core.step == st.step == car + 1
