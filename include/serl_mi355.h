@@ -134,7 +134,9 @@ typedef struct serl_agent serl_agent;
  * agents/continuous/drq.py:24-242) with encoder_type == "resnet-pretrained". */
 typedef struct serl_agent_cfg {
   int device;
-  int n_cam, H, W;         /* image_keys order is the caller's; C == 3 */
+  int n_cam, H, W;         /* image_keys order is the caller's; C == 3.  n_cam == 0: state-only SAC
+                            * (SACAgent.create_states, sac.py:486-542): no encoder, observations are the flat
+                            * state vectors, one Dense(1) Q head per ensemble member; H, W ignored */
   int state_dim, act_dim;
   int batch;               /* max samples per update call on THIS rank */
   int ensemble;            /* critic_ensemble_size (10) */
@@ -142,7 +144,8 @@ typedef struct serl_agent_cfg {
   int bottleneck;          /* encoder bottleneck_dim (256) */
   int sle_features;        /* num_spatial_blocks (8) */
   int proprio_dim;         /* proprio_latent_dim (64) */
-  int warmup_steps;        /* optimizers.py:23-30 (0 for DrQ) */
+  int warmup_steps;        /* optimizers.py:23-30: actor and critic optimizers (0 for DrQ, 2000 for make_sac_agent) */
+  int temp_warmup_steps;   /* temperature optimizer's own warm-up; < 0: same as warmup_steps (sac.py:333-343: none) */
   float discount, tau, lr;
   float dropout;           /* 0.1, resnet_v1.py:351 */
   float std_min, std_max;  /* 1e-5, 5 */

@@ -58,6 +58,8 @@ class Config:
     std_min: float = 1e-5           # launcher.py:97-98
     std_max: float = 5.0
     target_entropy: float = None    # drq.py:88-89: -A/2
+    temp_warmup: int = None         # temperature optimizer's own warm-up (None: same as `warmup`); SACAgent.create
+                                    # defaults: actor/critic warmup 2000, temperature none (sac.py:333-343)
 
     def __post_init__(self):
         if self.target_entropy is None:
@@ -66,6 +68,12 @@ class Config:
     @property
     def n_cam(self):
         return len(self.image_keys)
+
+    @property
+    def state_only(self):
+        """SACAgent.create_states (sac.py:486-542): no encoder, observations are flat state vectors, and the
+        ensemblized Critic carries one Dense(1) head PER member (actor_critic_nets.py:49-73 under ensemblize)."""
+        return len(self.image_keys) == 0
 
     @property
     def feat_hw(self):  # trunk output spatial size: /2 (conv), /2 (pool), /2 /2 /2 (blocks 1-3)
@@ -83,6 +91,8 @@ class Config:
 
     @property
     def enc_dim(self):
+        if self.state_only:
+            return self.S
         return self.bottleneck * self.n_cam + self.proprio_dim
 
 
@@ -122,8 +132,15 @@ def trainable_param_shapes(cfg: Config):
         "critic/w1": (N, E + A, Hd), "critic/b1": (N, Hd), "critic/ln1/scale": (N, Hd), "critic/ln1/bias": (N, Hd),
         "critic/w2": (N, Hd, Hd), "critic/b2": (N, Hd), "critic/ln2/scale": (N, Hd), "critic/ln2/bias": (N, Hd),
         "critic/head/kernel": (Hd, 1), "critic/head/bias": (1,),
-        "enc/proprio/dense/kernel": (cfg.S, cfg.proprio_dim), "enc/proprio/dense/bias": (cfg.proprio_dim,),
-        "enc/proprio/ln/scale": (cfg.proprio_dim,), "enc/proprio/ln/bias": (cfg.proprio_dim,),
+    })
+    if cfg.state_only:
+        sh["critic/head/kernel"], sh["critic/head/bias"] = (N, Hd, 1), (N,)
+    else:
+        sh.update({
+            "enc/proprio/dense/kernel": (cfg.S, cfg.proprio_dim), "enc/proprio/dense/bias": (cfg.proprio_dim,),
+            "enc/proprio/ln/scale": (cfg.proprio_dim,), "enc/proprio/ln/bias": (cfg.proprio_dim,),
+        })
+    sh.update({
         "actor/w1": (E, Hd), "actor/b1": (Hd,), "actor/ln1/scale": (Hd,), "actor/ln1/bias": (Hd,),
         "actor/w2": (Hd, Hd), "actor/b2": (Hd,), "actor/ln2/scale": (Hd,), "actor/ln2/bias": (Hd,),
         "actor/mean/kernel": (Hd, A), "actor/mean/bias": (A,),
@@ -153,7 +170,7 @@ def init_params(cfg: Config, seed: int = 42, perturb: bool = True):
         return ((0.1 * rng.standard_normal(shape)) if perturb else np.zeros(shape)).astype(np.float32)
 
     trunk = {}
-    for name, shp in trunk_param_shapes().items():
+    for name, shp in ({} if cfg.state_only else trunk_param_shapes()).items():
         if len(shp) == 4:
             trunk[name] = normal(shp, math.sqrt(2.0 / (shp[0] * shp[1] * shp[2])))
         elif name.endswith("scale"):
@@ -166,6 +183,8 @@ def init_params(cfg: Config, seed: int = 42, perturb: bool = True):
             theta[name] = normal(shp, math.sqrt(1.0 / (shp[0] * shp[1] * shp[2])))
         elif name.startswith("enc/") and name.endswith("dense/kernel") and "proprio" not in name:
             theta[name] = normal(shp, math.sqrt(1.0 / shp[0]))        # nn.Dense default lecun_normal
+        elif name == "critic/head/kernel" and len(shp) == 3:
+            theta[name] = xavier(shp, shp[1], shp[2])                 # per-member heads (state-only SAC)
         elif name.endswith("kernel") or name in ("actor/w1", "actor/w2"):
             theta[name] = xavier(shp, shp[0], shp[1])                 # default_init / xavier_uniform
         elif name in ("critic/w1", "critic/w2"):
@@ -262,6 +281,8 @@ def sle(feats, kernel):
 def encode(th, cfg, feats, state, drop_masks=None, stop_gradient=False):
     """EncodingWrapper (encoding.py:26-72) on precomputed trunk features.
     feats: {cam: [N,h,w,512]}; state [N,S]; drop_masks: {cam: [N,4096] keep-mask} or None."""
+    if cfg.state_only:
+        return state        # encoder=None (actor_critic_nets.py:59-60,185-186)
     codes = []
     for k in cfg.image_keys:
         f = sle(feats[k], th[f"enc/{k}/sle"])
@@ -305,6 +326,8 @@ def critic_forward(th, cfg, enc, act):
     h = torch.tanh(layer_norm(h, th["critic/ln1/scale"][:, None, :], th["critic/ln1/bias"][:, None, :]))
     h = torch.einsum("ebi,eio->ebo", h, th["critic/w2"]) + th["critic/b2"][:, None, :]
     h = torch.tanh(layer_norm(h, th["critic/ln2/scale"][:, None, :], th["critic/ln2/bias"][:, None, :]))
+    if cfg.state_only:  # ensemblize vmaps the whole Critic: every member has its own Dense(1)
+        return torch.einsum("ebi,eio->ebo", h, th["critic/head/kernel"]).squeeze(-1) + th["critic/head/bias"][:, None]
     return (h @ th["critic/head/kernel"]).squeeze(-1) + th["critic/head/bias"]
 
 
@@ -328,10 +351,11 @@ class TrainState:
                          "mu": {k: torch.zeros_like(v) for k, v in self.params.items()},
                          "nu": {k: torch.zeros_like(v) for k, v in self.params.items()}} for tx in TX_NAMES}
 
-    def lr_at(self, count):  # optimizers.py:23-30 join_schedules([linear(0,lr,warmup), constant(lr)],[warmup])
+    def lr_at(self, count, tx="critic"):  # optimizers.py:23-30 join_schedules([linear(0,lr,warmup), constant(lr)],[warmup])
         c = self.cfg
-        if count < c.warmup:
-            return c.lr * count / c.warmup
+        warm = c.warmup if (tx != "temperature" or c.temp_warmup is None) else c.temp_warmup
+        if count < warm:
+            return c.lr * count / warm
         return c.lr
 
 
@@ -343,7 +367,7 @@ def apply_gradients(st: TrainState, grads):
     updates = {}
     for tx in TX_NAMES:
         o = st.opt[tx]
-        lr = st.lr_at(o["count"])
+        lr = st.lr_at(o["count"], tx)
         o["count"] += 1
         t = o["count"]
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
@@ -436,6 +460,8 @@ def actor_temp_update(st: TrainState, feats_obs, feats_next, state, next_state, 
 def features(st: TrainState, frames_u8, chunk=64):
     """frames_u8 {cam: [N,H,W,3] uint8 torch} -> {cam: [N,h,w,512]} through the frozen trunk."""
     out = {}
+    if st.cfg.state_only:
+        return out
     with torch.no_grad():
         for k, v in frames_u8.items():
             parts = [trunk_forward(st.trunk, v[i:i + chunk], st.dtype) for i in range(0, v.shape[0], chunk)]

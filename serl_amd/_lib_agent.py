@@ -9,7 +9,7 @@ class SerlAgentCfg(C.Structure):
         ("device", C.c_int), ("n_cam", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("state_dim", C.c_int), ("act_dim", C.c_int), ("batch", C.c_int), ("ensemble", C.c_int),
         ("hidden", C.c_int), ("bottleneck", C.c_int), ("sle_features", C.c_int),
-        ("proprio_dim", C.c_int), ("warmup_steps", C.c_int),
+        ("proprio_dim", C.c_int), ("warmup_steps", C.c_int), ("temp_warmup_steps", C.c_int),
         ("discount", C.c_float), ("tau", C.c_float), ("lr", C.c_float), ("dropout", C.c_float),
         ("std_min", C.c_float), ("std_max", C.c_float), ("target_entropy", C.c_float),
         ("seed", C.c_uint64),

@@ -18,11 +18,11 @@ class AgentCore:
     def __init__(self, *, device=0, n_cam, H, W, state_dim, act_dim, batch, ensemble=10, hidden=256,
                  bottleneck=256, sle_features=8, proprio_dim=64, warmup_steps=0, discount=0.96,
                  tau=0.005, lr=3e-4, dropout=0.1, std_min=1e-5, std_max=5.0, target_entropy=None,
-                 seed=0):
+                 seed=0, temp_warmup_steps=-1):
         if target_entropy is None:
             target_entropy = -act_dim / 2
         self.cfg = SerlAgentCfg(device, n_cam, H, W, state_dim, act_dim, batch, ensemble, hidden,
-                                bottleneck, sle_features, proprio_dim, warmup_steps, discount, tau,
+                                bottleneck, sle_features, proprio_dim, warmup_steps, temp_warmup_steps, discount, tau,
                                 lr, dropout, std_min, std_max, target_entropy, seed)
         self._h = C.c_void_p()
         self.L = _lib.lib()
@@ -165,7 +165,7 @@ class AgentCore:
         n = state.shape[0]
         out = torch.empty((n, self.cfg.act_dim), dtype=torch.float32, device=self.device)
         _lib.check(self.L.serl_agent_sample_actions(
-            self._h, frames_u8.contiguous().data_ptr(), state.contiguous().data_ptr(), n,
+            self._h, None if frames_u8 is None else frames_u8.contiguous().data_ptr(), state.contiguous().data_ptr(), n,
             None if eps is None else eps.contiguous().data_ptr(), out.data_ptr(), self._stream()))
         return out
 

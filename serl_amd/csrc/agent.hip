@@ -74,6 +74,7 @@ static_assert(I_CL == 0 && I_PQ == 1 && I_TQ == 2 && I_AL == 3 && I_TEMP == 4 &&
 struct serl_agent {
   serl_agent_cfg cfg{};
   int E = 0, D = 0, HW = 0, XA = 0;  // enc dim, sle dim, feature pixels, E + A
+  bool state_only = false;           // n_cam == 0: SACAgent.create_states
   Offs o{};
   std::vector<Leaf> theta_leaves, trunk_leaves;
   long trunk_count = 0;
@@ -112,7 +113,7 @@ struct serl_agent {
   int64_t step = 0;
   uint64_t noise_ctr = 0;
   serl_info last_info{};
-  float lr_last = 0.f;
+  float lr_last = 0.f, lr_t_last = 0.f;
   int last_global = 0;
   bool info_reset = true;
   // batch-sharded data parallelism: this rank's local batch is rows [shard_off, shard_off + local) of a global
@@ -140,10 +141,11 @@ struct Bump {
 
 void build_layout(serl_agent* a) {
   const serl_agent_cfg& c = a->cfg;
-  const TrunkDims d = trunk_dims(c.H, c.W);
-  a->HW = d.h[5] * d.w[5];
-  a->D = 512 * c.sle_features;
-  a->E = c.bottleneck * c.n_cam + c.proprio_dim;
+  const TrunkDims d = c.n_cam > 0 ? trunk_dims(c.H, c.W) : TrunkDims{};
+  a->state_only = c.n_cam == 0;
+  a->HW = a->state_only ? 0 : d.h[5] * d.w[5];
+  a->D = a->state_only ? 0 : 512 * c.sle_features;
+  a->E = a->state_only ? c.state_dim : c.bottleneck * c.n_cam + c.proprio_dim;
   a->XA = a->E + c.act_dim;
   long off = 0;
   auto leaf = [&](std::vector<Leaf>& v, const std::string& n, long cnt) {
@@ -172,13 +174,17 @@ void build_layout(serl_agent* a) {
   o.c_b2 = leaf(L, "critic/b2", N * Hd);
   o.c_g2 = leaf(L, "critic/ln2/scale", N * Hd);
   o.c_be2 = leaf(L, "critic/ln2/bias", N * Hd);
-  o.c_hw = leaf(L, "critic/head/kernel", Hd);
-  o.c_hb = leaf(L, "critic/head/bias", 1);
+  // DrQ: one Dense(1) head shared by the ensemble (drq.py:201-207); state-only SAC: ensemblize vmaps the whole
+  // Critic, so every member has its own head (actor_critic_nets.py:49-73,156-164)
+  o.c_hw = leaf(L, "critic/head/kernel", a->state_only ? N * Hd : Hd);
+  o.c_hb = leaf(L, "critic/head/bias", a->state_only ? N : 1);
   o.Pa0 = off;
-  o.p_W = leaf(L, "enc/proprio/dense/kernel", (long)c.state_dim * c.proprio_dim);
-  o.p_b = leaf(L, "enc/proprio/dense/bias", c.proprio_dim);
-  o.p_g = leaf(L, "enc/proprio/ln/scale", c.proprio_dim);
-  o.p_be = leaf(L, "enc/proprio/ln/bias", c.proprio_dim);
+  if (!a->state_only) {
+    o.p_W = leaf(L, "enc/proprio/dense/kernel", (long)c.state_dim * c.proprio_dim);
+    o.p_b = leaf(L, "enc/proprio/dense/bias", c.proprio_dim);
+    o.p_g = leaf(L, "enc/proprio/ln/scale", c.proprio_dim);
+    o.p_be = leaf(L, "enc/proprio/ln/bias", c.proprio_dim);
+  }
   o.Pc = off;
   o.a_w1 = leaf(L, "actor/w1", (long)a->E * Hd);
   o.a_b1 = leaf(L, "actor/b1", Hd);
@@ -197,6 +203,8 @@ void build_layout(serl_agent* a) {
   o.P = off;
   // trunk
   off = 0;
+  a->trunk_count = 0;
+  if (a->state_only) return;
   std::vector<Leaf>& T = a->trunk_leaves;
   leaf(T, "trunk/conv_init", 7 * 7 * 3 * 64);
   leaf(T, "trunk/norm_init/scale", 64);
@@ -310,11 +318,13 @@ size_t carve(serl_agent* a, void* base) {
     a->mask_buf[k] = b.take<uint8_t>((long)c.n_cam * B * a->D);
   }
   a->act_tmp = b.take<float>(B * A);
-  const int nimg = 2 * c.n_cam * c.batch;
-  void* tmem = b.take<uint8_t>(trunk_workspace_bytes(nimg, c.H, c.W));
-  if (base) trunk_workspace_bind(a->tws, tmem, nimg, c.H, c.W);
-  void* pmem = b.take<uint8_t>(trunk_packed_bytes());
-  if (base) trunk_packed_bind(a->tpk, pmem);
+  if (!a->state_only) {
+    const int nimg = 2 * c.n_cam * c.batch;
+    void* tmem = b.take<uint8_t>(trunk_workspace_bytes(nimg, c.H, c.W));
+    if (base) trunk_workspace_bind(a->tws, tmem, nimg, c.H, c.W);
+    void* pmem = b.take<uint8_t>(trunk_packed_bytes());
+    if (base) trunk_packed_bind(a->tpk, pmem);
+  }
   (void)persistent;
   return b.off;
 }
@@ -353,6 +363,16 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   const Offs& o = a->o;
   const long Bfull = a->cur.batch;
   SERL_REQUIRE(n >= 1 && n <= 3, "bad encode instance count");
+  if (a->state_only) {  // encoder=None: the "encoding" is the state vector itself (+ the actions rider)
+    CopyJob cj[kMaxMulti];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      const EncJob& j = jobs[i];
+      cj[m++] = CopyJob{a->cur.state + ((long)j.which * Bfull + off) * c.state_dim, c.state_dim, j.e->enc, j.e->ld, c.state_dim};
+      if (j.act_dst) cj[m++] = CopyJob{j.act_src, c.act_dim, j.act_dst, a->XA, c.act_dim};
+    }
+    return copy_cols_multi(cj, m, cnt, st);
+  }
   SleFwdArgs sv[3];
   GemmDesc gd[3];
   LnFwdArgs lv[3];
@@ -402,7 +422,8 @@ struct DenseJob {
   const float* W; long w_gstride;
   const float *bias, *gamma, *beta; long p_gstride;
   float *y, *xhat, *rstd;
-  const float *dot_w, *dot_b; float* dot_out;  // optional fused row-dot (shared critic head)
+  const float *dot_w, *dot_b; float* dot_out;  // optional fused row-dot (critic head)
+  long dot_gstride = 0, dot_b_gstride = 0;      // per-group heads (state-only SAC) or 0 = shared
 };
 int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, int rows_per_group, int K, int splitk,
                         hipStream_t st) {
@@ -427,6 +448,7 @@ int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, 
     l.y = j.y; l.ld_y = Hd; l.y_goff = (long)rows_per_group * Hd;
     l.xhat = j.xhat; l.rstd = j.rstd;
     l.dot_w = j.dot_w; l.dot_b = j.dot_b; l.dot_out = j.dot_out;
+    l.dot_gstride = j.dot_gstride; l.dot_b_gstride = j.dot_b_gstride;
   }
   RC(gemm_f32_multi(gd, n, st));
   return ln_tanh_fwd_multi(lv, n, Hd, st);
@@ -488,6 +510,8 @@ int critic_fwd_multi(serl_agent* a, const CritJob* jobs, int n, int cnt, hipStre
                      cb.m.h1, cb.m.xh1, cb.m.rs1, nullptr, nullptr, nullptr};
     d2[i] = DenseJob{cb.m.h1, Hd, (long)cnt * Hd, P + o.c_w2, (long)Hd * Hd, P + o.c_b2, P + o.c_g2, P + o.c_be2, Hd,
                      cb.m.h2, cb.m.xh2, cb.m.rs2, P + o.c_hw, P + o.c_hb, cb.q};
+    d2[i].dot_gstride = a->state_only ? Hd : 0;
+    d2[i].dot_b_gstride = a->state_only ? 1 : 0;
   }
   RC(dense_ln_tanh_multi(a, d1, n, N, cnt, a->XA, 4, st));
   return dense_ln_tanh_multi(a, d2, n, N, cnt, Hd, 2, st);
@@ -500,14 +524,14 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
                       long y_goff, const float* xhat, const float* rstd, const float* gamma, long p_gstride,
                       int groups, int rows_per_group, int D, float* dpre, float* dg, float* G, long g_off,
                       long be_off, long b_off, long pg_gstride, hipStream_t st, const float* dq = nullptr,
-                      const float* dq_w = nullptr, float dq_const = 0.f) {
+                      const float* dq_w = nullptr, float dq_const = 0.f, long dq_w_gstride = 0) {
   LnBwdArgs l{};
   l.dy = dy; l.ld_dy = ld_dy; l.dy_goff = dy_goff;
   l.y = y; l.ld_y = ld_y; l.y_goff = y_goff;
   l.xhat = xhat; l.rstd = rstd; l.gamma = gamma; l.pstride = p_gstride;
   l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
   l.dx = dpre; l.dg = dg;
-  l.dq = dq; l.dq_w = dq_w; l.dq_const = dq_const;
+  l.dq = dq; l.dq_w = dq_w; l.dq_const = dq_const; l.dq_w_gstride = dq_w_gstride;
   RC(ln_tanh_bwd(l, D, st));
   if (G) {
     RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, st));
@@ -545,7 +569,7 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
   const Offs& o = a->o;
   const int Hd = c.hidden, N = c.ensemble;
   float* G = pg ? a->Gc : nullptr;
-  if (pg) {  // shared head kernel: dw[j] = sum_{e,b} dq*h2
+  if (pg && !a->state_only) {  // shared head kernel: dw[j] = sum_{e,b} dq*h2
     GemmDesc g{};
     g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = 0;
     g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = 0;
@@ -553,10 +577,19 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
     g.M = 1; g.N = Hd; g.K = N * cnt; g.nbatch = 1; g.splitk = 8;
     RC(gemm_f32(g, st));
     RC(reduce_slabs(a->slabs, 8, Hd, 1, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, 0, false, st));
+  } else if (pg) {  // one head per member: dw[e][j] = sum_b dq[e][b]*h2[e][b][j]
+    GemmDesc g{};
+    g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = cnt;
+    g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = (long)cnt * Hd;
+    g.C = a->slabs; g.ldc = Hd; g.sCz = Hd;
+    g.M = 1; g.N = Hd; g.K = cnt; g.nbatch = N; g.splitk = 4;
+    RC(gemm_f32(g, st));
+    RC(reduce_slabs(a->slabs, 4, Hd, N, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, Hd, false, st));
   }
   // gradient through the shared head dh2 = dq (x) w is formed inside the LN backward kernel (rank-1 mode)
   RC(dense_ln_tanh_bwd(a, nullptr, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
-                       N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st, dq, P + o.c_hw, dq_const));
+                       N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st, dq, P + o.c_hw, dq_const,
+                       a->state_only ? Hd : 0));
   if (pg)
     RC(wgrad(cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
              cnt, st));
@@ -623,7 +656,7 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
                                cnt_total, a->shard_global, a->shard_off, c.act_dim};
     *eps = a->eps_buf[slot];
   }
-  if (given_mask) *mask = given_mask;
+  if (given_mask || a->state_only) *mask = given_mask;  // (no encoder, no dropout in the state-only agent)
   else {
     nb.jobs[nb.n++] = NoiseJob{a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D,
                                c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)), 1, 1.0f - c.dropout,
@@ -632,8 +665,9 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
   }
 }
 
-float lr_at(const serl_agent_cfg& c, int64_t count) {  // optimizers.py:23-30
-  if (count < c.warmup_steps) return c.lr * (float)count / (float)c.warmup_steps;
+float lr_at(const serl_agent_cfg& c, int64_t count, bool temperature = false) {  // optimizers.py:23-30
+  const int warm = (temperature && c.temp_warmup_steps >= 0) ? c.temp_warmup_steps : c.warmup_steps;
+  if (count < warm) return c.lr * (float)count / (float)warm;
   return c.lr;
 }
 
@@ -643,8 +677,9 @@ extern "C" {
 
 int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   SERL_REQUIRE(cfg && out, "NULL argument");
-  SERL_REQUIRE(cfg->n_cam >= 1 && cfg->n_cam <= SERL_MAX_CAMS, "n_cam %d not in [1,%d]", cfg->n_cam, SERL_MAX_CAMS);
-  SERL_REQUIRE(cfg->H >= 32 && cfg->W >= 32, "images must be at least 32x32");
+  SERL_REQUIRE(cfg->n_cam >= 0 && cfg->n_cam <= SERL_MAX_CAMS, "n_cam %d not in [0,%d]", cfg->n_cam, SERL_MAX_CAMS);
+  SERL_REQUIRE(cfg->n_cam == 0 || (cfg->H >= 32 && cfg->W >= 32), "images must be at least 32x32");
+  SERL_REQUIRE(cfg->n_cam > 0 || cfg->ensemble <= 16, "state-only SAC supports ensembles of at most 16");
   SERL_REQUIRE(cfg->hidden == 256 && cfg->bottleneck == 256, "hidden/bottleneck must be 256 (got %d/%d)", cfg->hidden, cfg->bottleneck);
   SERL_REQUIRE(cfg->proprio_dim == 64, "proprio_dim must be 64");
   SERL_REQUIRE(cfg->sle_features == 8, "sle_features must be 8");
@@ -662,7 +697,7 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   }
   carve(a, a->arena);
   SERL_HIP(hipMemset(a->arena, 0, bytes));
-  bind_trunk_weights(a);
+  if (!a->state_only) bind_trunk_weights(a);
   *out = a;
   return SERL_OK;
 }
@@ -766,16 +801,17 @@ int64_t serl_agent_get_step(serl_agent* a) { return a ? a->step : -1; }
 
 int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream) {
   SERL_REQUIRE(a && dev_frames && dev_feats_out, "NULL argument");
+  SERL_REQUIRE(!a->state_only, "a state-only agent has no trunk");
   SERL_HIP(hipSetDevice(a->cfg.device));
   return trunk_forward(a->tw, a->tws, dev_frames, n, dev_feats_out, (hipStream_t)stream, a->trunk_mode ? &a->tpk : nullptr);
 }
 
 static int check_batch(serl_agent* a, const serl_batch* b) {
   const serl_agent_cfg& c = a->cfg;
-  SERL_REQUIRE(b && b->frames && b->state && b->action && b->reward && b->mask, "serl_batch has NULL members");
+  SERL_REQUIRE(b && (b->frames || c.n_cam == 0) && b->state && b->action && b->reward && b->mask, "serl_batch has NULL members");
   SERL_REQUIRE(b->batch >= 1 && b->batch <= c.batch, "batch %d not in [1,%d]", b->batch, c.batch);
-  SERL_REQUIRE(b->n_cam == c.n_cam && b->H == c.H && b->W == c.W && b->C == 3 && b->state_dim == c.state_dim &&
-                   b->act_dim == c.act_dim, "serl_batch shape does not match the agent");
+  SERL_REQUIRE(b->n_cam == c.n_cam && (c.n_cam == 0 || (b->H == c.H && b->W == c.W && b->C == 3)) &&
+                   b->state_dim == c.state_dim && b->act_dim == c.act_dim, "serl_batch shape does not match the agent");
   return SERL_OK;
 }
 
@@ -792,6 +828,7 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
   const serl_agent_cfg& c = a->cfg;
   const int B = batch->batch;
   const size_t fbytes = (size_t)c.H * c.W * 3;
+  if (a->state_only) return SERL_OK;  // no encoder: nothing to precompute
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
     // (sub-batching the run to keep activations in the Infinity Cache was measured: slower -- DESIGN.md)
     return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr);
@@ -871,11 +908,13 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
   RC(critic_fwd_multi(a, cj, 2, cnt, st));
   const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
   RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
-                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st));
+                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st, a->state_only));
   RC(critic_bwd(a, a->theta, a->crit, cnt, true, st, a->dq, 0.f));
-  RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
-                 a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
-  RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
+  if (!a->state_only) {
+    RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
+                   a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
+    RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
+  }
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -925,9 +964,11 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
                        a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, s0));
   RC(wgrad(a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, s0));
   // image codes are stop-gradiented (encoding.py:48-49); only the proprio slice of d_enc is needed
-  const long pc = (long)c.n_cam * c.bottleneck;
-  RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, s0));
-  RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, s0));
+  if (!a->state_only) {
+    const long pc = (long)c.n_cam * c.bottleneck;
+    RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, s0));
+    RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, s0));
+  }
   a->last_global = global_count;
   return SERL_OK;
 }
@@ -948,7 +989,8 @@ int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) 
   ad.sum_logp_next = a->SC + S_LOGP_NEXT; ad.temp_grad_out = a->aux + X_TGRAD;
   ad.critic_on = crit ? 1 : 0; ad.actor_on = crit ? 0 : 1; ad.temp_on = crit ? 0 : 1;
   const float lr = lr_at(c, a->step);  // all three txs share count == step and the same schedule
-  ad.lr_c = ad.lr_a = ad.lr_t = lr;
+  ad.lr_c = ad.lr_a = lr;
+  ad.lr_t = lr_at(c, a->step, true);
   const int64_t t = a->step + 1;
   ad.bc1 = 1.0f - powf(0.9f, (float)t);
   ad.bc2 = 1.0f - powf(0.999f, (float)t);
@@ -964,6 +1006,7 @@ int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) 
   RC(adam_ema(ad, st));
   a->step += 1;
   a->lr_last = lr;
+  a->lr_t_last = ad.lr_t;
   return SERL_OK;
 }
 
@@ -1008,14 +1051,16 @@ int serl_agent_read_info(serl_agent* a, serl_info* out, void* stream) {
   out->critic_loss = acc[I_CL]; out->predicted_qs = acc[I_PQ]; out->target_qs = acc[I_TQ];
   out->actor_loss = acc[I_AL]; out->temperature = acc[I_TEMP]; out->entropy = acc[I_ENT];
   out->temperature_loss = acc[I_TL];
-  out->actor_lr = out->critic_lr = out->temperature_lr = a->lr_last;
+  out->actor_lr = out->critic_lr = a->lr_last;
+  out->temperature_lr = a->lr_t_last;
   return SERL_OK;
 }
 
 int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const float* dev_state, int n,
                               const float* dev_eps, float* dev_out_actions, void* stream) {
-  SERL_REQUIRE(a && dev_frames && dev_state && dev_out_actions, "NULL argument");
+  SERL_REQUIRE(a && dev_state && dev_out_actions, "NULL argument");
   const serl_agent_cfg& c = a->cfg;
+  SERL_REQUIRE(dev_frames || c.n_cam == 0, "NULL frames");
   SERL_REQUIRE(n >= 1 && n <= c.batch, "n %d not in [1,%d]", n, c.batch);
   hipStream_t st = (hipStream_t)stream;
   SERL_HIP(hipSetDevice(c.device));

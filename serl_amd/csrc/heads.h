@@ -28,6 +28,7 @@ struct LnFwdArgs {
   float* rstd;           // [rows] or nullptr
   // optional fused row-dot (critic head, actor_critic_nets.py:65-73): dot_out[row] = sum_col y*dot_w + dot_b[0]
   const float* dot_w; const float* dot_b; float* dot_out;
+  long dot_gstride, dot_b_gstride;  // 0: one head shared by all groups (DrQ critic); else per-group heads (ensemblized Critic)
 };
 int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream);
 int ln_tanh_fwd_multi(const LnFwdArgs* a, int n, int D, hipStream_t stream);
@@ -36,6 +37,7 @@ struct LnBwdArgs {
   const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y (ignored in rank-1 mode)
   // rank-1 mode (gradient through the critic head): dy[row][col] = (dq ? dq[row] : dq_const) * dq_w[col]
   const float* dq; const float* dq_w; float dq_const;
+  long dq_w_gstride;  // 0: shared head vector; else per-group head vectors
   const float* y; long ld_y; long y_goff;
   const float* xhat; const float* rstd;
   const float* gamma; long pstride;
@@ -58,9 +60,10 @@ int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int 
             long x_gs, long df_gs, long part_gs, hipStream_t stream);
 int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);
 int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream);
+// dbias: gradient of the head bias -- one scalar (shared head) or, with per_member_bias, one per ensemble member
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
-                hipStream_t stream);
+                hipStream_t stream, bool per_member_bias = false);
 // slabs: [2][B][A] raw head GEMM outputs (mean, log_std); biases added here and the result kept in `pre`
 int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
                     int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
@@ -84,6 +87,8 @@ int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, 
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
                     float std_min, float std_max, float* dpre, hipStream_t stream);
 int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream);
+struct CopyJob { const float* src; long ld_src; float* dst; long ld_dst; int cols; };
+int copy_cols_multi(const CopyJob* jobs, int n, int rows, hipStream_t stream);
 int fill(float* p, float v, long n, hipStream_t stream);
 int temperature_alpha(const float* lam, float* out, hipStream_t stream);
 int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream);

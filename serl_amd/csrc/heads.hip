@@ -322,11 +322,12 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
     for (int j = 0; j < VPL; ++j) {
       const int col = lane * VPL + j;
       const float xh = (v[j] - mean) * rstd;
-      d += tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]) * a.dot_w[col];
+      d += tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]) *
+           a.dot_w[(long)grp * a.dot_gstride + col];
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off);
-    if (lane == 0) a.dot_out[row] = d + a.dot_b[0];
+    if (lane == 0) a.dot_out[row] = d + a.dot_b[(long)grp * a.dot_b_gstride];
   }
 }
 
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(LnBwdArgs a) {
     const int col = lane * VPL + j;
     const long lr = row - grp * a.rows_per_group;
     const float y = a.y[lr * a.ld_y + (long)grp * a.y_goff + col];
-    const float dy = a.dq_w ? (a.dq ? a.dq[row] : a.dq_const) * a.dq_w[col]
+    const float dy = a.dq_w ? (a.dq ? a.dq[row] : a.dq_const) * a.dq_w[(long)grp * a.dq_w_gstride + col]
                             : a.dy[lr * a.ld_dy + (long)grp * a.dy_goff + col];
     dg[j] = dy * (1.f - y * y);
     xh[j] = a.xhat[(long)row * D + col];
@@ -578,9 +579,12 @@ int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, 
 __global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const float* q, const float* reward,
                                                          const float* mask, int i0, int i1, int E, int B,
                                                          float discount, float inv_norm, float* y_out,
-                                                         float* dq, float* scalars, float* dbias) {
+                                                         float* dq, float* scalars, float* dbias, int per_member) {
   __shared__ float red[4][256];
   float s_d2 = 0.f, s_q = 0.f, s_y = 0.f, s_dq = 0.f;
+  float s_e[16];  // per-member sums of dQ (per_member: E <= 16)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s_e[e] = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
     const float y = reward[b] + discount * mask[b] * fminf(qt[(long)i0 * B + b], qt[(long)i1 * B + b]);
     y_out[b] = y;
@@ -593,6 +597,11 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const
       s_d2 += d * d;
       s_q += qv;
       s_dq += g;
+      if (per_member) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k == e) s_e[k] += g;
+      }
     }
   }
   red[0][threadIdx.x] = s_d2; red[1][threadIdx.x] = s_q; red[2][threadIdx.x] = s_y; red[3][threadIdx.x] = s_dq;
@@ -604,15 +613,31 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const
   }
   if (threadIdx.x == 0) {
     scalars[0] = red[0][0]; scalars[1] = red[1][0]; scalars[2] = red[2][0];
-    *dbias = red[3][0];
+    if (!per_member) *dbias = red[3][0];
+  }
+  if (per_member) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < E) {  // (uniform)
+        __syncthreads();
+        red[0][threadIdx.x] = s_e[k];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
+          __syncthreads();
+        }
+        if (threadIdx.x == 0) dbias[k] = red[0][0];
+      }
+    }
   }
 }
 
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
-                hipStream_t stream) {
+                hipStream_t stream, bool per_member_bias) {
+  SERL_REQUIRE(!per_member_bias || E <= 16, "per-member head bias supports ensembles of at most 16 (got %d)", E);
   hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, stream, qt, q, reward, mask, i0, i1, E, B,
-                     discount, inv_norm, y_out, dq, scalars, dbias);
+                     discount, inv_norm, y_out, dq, scalars, dbias, per_member_bias ? 1 : 0);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -751,6 +776,23 @@ __global__ void copy_cols_kernel(const float* src, long ld_src, float* dst, long
 int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream) {
   hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, stream, src, ld_src, dst,
                      ld_dst, rows, cols);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+__global__ void copy_cols_multi_kernel(Multi<CopyJob> mv, int rows) {
+  const CopyJob& j = mv.v[blockIdx.y];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * j.cols) return;
+  const int r = e / j.cols, c = e - r * j.cols;
+  j.dst[(long)r * j.ld_dst + c] = j.src[(long)r * j.ld_src + c];
+}
+int copy_cols_multi(const CopyJob* jobs, int n, int rows, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad job count %d", n);
+  Multi<CopyJob> mv{};
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) { mv.v[i] = jobs[i]; cmax = std::max(cmax, jobs[i].cols); }
+  hipLaunchKernelGGL(copy_cols_multi_kernel, dim3(cdiv((long)rows * cmax, 256), n), dim3(256), 0, stream, mv, rows);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -20,7 +20,8 @@ def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0, trun
     core = AgentCore(n_cam=cfg.n_cam, H=cfg.H, W=cfg.W, state_dim=cfg.S, act_dim=cfg.A, batch=B,
                      ensemble=cfg.ensemble, discount=cfg.discount, tau=cfg.tau, lr=cfg.lr,
                      warmup_steps=cfg.warmup, dropout=cfg.dropout, std_min=cfg.std_min, std_max=cfg.std_max,
-                     target_entropy=cfg.target_entropy, seed=agent_seed)
+                     target_entropy=cfg.target_entropy, seed=agent_seed,
+                     temp_warmup_steps=-1 if cfg.temp_warmup is None else cfg.temp_warmup)
     if trunk_mode is not None:
         core.set_trunk_mode(trunk_mode)
     for sec in ("params", "target_params"):
@@ -72,7 +73,8 @@ def noise_to_device(cfg, noise):
         if k.startswith("eps"):
             out[k] = torch.tensor(v, device="cuda")
         elif k.startswith("mask"):
-            out[k] = torch.tensor(np.stack([v[c] for c in cfg.image_keys]), device="cuda")
+            if cfg.image_keys:
+                out[k] = torch.tensor(np.stack([v[c] for c in cfg.image_keys]), device="cuda")
         elif k == "redq_idx":
             out[k] = np.asarray(v, np.int32)
     return out
