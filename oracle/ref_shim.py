@@ -123,3 +123,14 @@ def make_spaces(image_keys, H, W, C, T, S, A):
     for k in image_keys:
         obs[k] = Box(0, 255, (T, H, W, C), np.uint8)
     return Dict(obs), Box(-1.0, 1.0, (A,), np.float32)
+
+
+def load_reference_plain_buffer_cls():
+    """Returns the reference's plain ReplayBuffer class (replay_buffer.py:40-75, unmodified)."""
+    if not reference_available():
+        raise RuntimeError("/root/reference not present (GPU box?) -- use the golden fixtures")
+    install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from serl_launcher.data.replay_buffer import ReplayBuffer
+    return ReplayBuffer

@@ -193,3 +193,37 @@ class PCG64Py:
                 m = self.next32() * n
                 l = m & 0xFFFFFFFF
         return m >> 32
+
+
+class PlainReplayOracle:
+    """ReplayBuffer of flat observations (replay_buffer.py:40-75) + Dataset.sample (dataset.py:79-102):
+    insert writes at the head and advances; sample draws `integers(len, size=B)` -- no validity mask."""
+
+    def __init__(self, S, A, capacity):
+        self.obs = np.zeros((capacity, S), np.float32)
+        self.next_obs = np.zeros((capacity, S), np.float32)
+        self.actions = np.zeros((capacity, A), np.float32)
+        self.rewards = np.zeros((capacity,), np.float32)
+        self.masks = np.zeros((capacity,), np.float32)
+        self.dones = np.zeros((capacity,), bool)
+        self.cap, self.size, self.insert_index, self.rng = capacity, 0, 0, None
+
+    def __len__(self):
+        return self.size
+
+    def seed(self, seed):
+        self.rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+
+    def insert(self, d):  # replay_buffer.py:71-75
+        i = self.insert_index
+        self.obs[i], self.next_obs[i] = d["observations"], d["next_observations"]
+        self.actions[i], self.rewards[i], self.masks[i], self.dones[i] = d["actions"], d["rewards"], d["masks"], d["dones"]
+        self.insert_index = (i + 1) % self.cap
+        self.size = min(self.size + 1, self.cap)
+
+    def sample_indices(self, batch_size):  # dataset.py:85-89
+        return self.rng.integers(len(self), size=batch_size)
+
+    def gather(self, idx):
+        return {"observations": self.obs[idx], "next_observations": self.next_obs[idx], "actions": self.actions[idx],
+                "rewards": self.rewards[idx], "masks": self.masks[idx], "dones": self.dones[idx]}

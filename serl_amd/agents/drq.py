@@ -241,7 +241,11 @@ class DrQAgent:
         {"actor","temperature"} (the two the reference's learners use)."""
         loss_keys = {"actor", "critic", "temperature"}
         assert set(networks_to_update).issubset(loss_keys), f"Invalid gradient steps: {networks_to_update}"
-        db = self.prepare(batch, crops=(np.full((batch.batch, 2), 4, np.int32),) * 2) if isinstance(batch, LazyBatch) else batch
+        if isinstance(batch, DeviceBatch):
+            db = batch
+        else:  # identity crop (offset 4 = centre of the 9 shifts): the batch is taken as already augmented
+            n = batch.batch_size if isinstance(batch, LazyBatch) else int(batch["rewards"].shape[0])
+            db = self.prepare(batch, crops=(np.full((n, 2), 4, np.int32),) * 2)
         self.core.begin_update()
         self.core.encode(db)
         if set(networks_to_update) == {"critic"}:

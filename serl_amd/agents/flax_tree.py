@@ -48,6 +48,10 @@ def theta_paths(image_keys, critic_mlp_name="critic_ensemble"):
     """flat trainable leaf -> list of flax paths (aliases)."""
     enc = ("modules_actor", "encoder")
     m = {}
+    if len(image_keys) == 0:
+        # SACAgent.create_states: Policy(encoder=None, network=MLP) and ensemblize(Critic(encoder=None, network=MLP))
+        # -- the vmapped Critic keeps its module names, every leaf gains a leading ensemble axis (sac.py:516-524)
+        return _state_paths()
     for i, k in enumerate(image_keys):
         e = enc + (f"encoder_{k}",)
         m[f"enc/{i}/sle"] = [e + ("SpatialLearnedEmbeddings_0", "kernel")]
@@ -81,6 +85,24 @@ def theta_paths(image_keys, critic_mlp_name="critic_ensemble"):
     return m
 
 
+def _state_paths():
+    m = {}
+    for mod, pre in (("modules_critic", "critic"), ("modules_actor", "actor")):
+        for j, n in ((1, 0), (2, 1)):
+            m[f"{pre}/w{j}"] = [(mod, "network", f"Dense_{n}", "kernel")]
+            m[f"{pre}/b{j}"] = [(mod, "network", f"Dense_{n}", "bias")]
+            m[f"{pre}/ln{j}/scale"] = [(mod, "network", f"LayerNorm_{n}", "scale")]
+            m[f"{pre}/ln{j}/bias"] = [(mod, "network", f"LayerNorm_{n}", "bias")]
+    m["critic/head/kernel"] = [("modules_critic", "Dense_0", "kernel")]
+    m["critic/head/bias"] = [("modules_critic", "Dense_0", "bias")]
+    m["actor/mean/kernel"] = [("modules_actor", "Dense_0", "kernel")]
+    m["actor/mean/bias"] = [("modules_actor", "Dense_0", "bias")]
+    m["actor/logstd/kernel"] = [("modules_actor", "Dense_1", "kernel")]
+    m["actor/logstd/bias"] = [("modules_actor", "Dense_1", "bias")]
+    m["temp/lagrange"] = [("modules_temperature", "lagrange")]
+    return m
+
+
 def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: bool = False,
                 critic_mlp_name: str = "critic_ensemble") -> Dict:
     """Nested dict of np.float32 arrays in flax layout (HWIO convs, (in,out) dense, ensemble axis 0)."""
@@ -94,7 +116,7 @@ def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: 
             if duplicate_encoder_under_critic and p[:2] == ("modules_actor", "encoder"):
                 _put(tree, ("modules_critic",) + p[1:], v)
     tshapes = trunk_shapes()
-    for leaf, sub in _trunk_paths().items():
+    for leaf, sub in (_trunk_paths() if cfg.n_cam else {}).items():
         v = core.get(section, leaf).reshape(tshapes[leaf])
         for k in image_keys:  # every camera subtree carries the (identical) frozen trunk
             _put(tree, ("modules_actor", "encoder", f"encoder_{k}", "pretrained_encoder") + sub, v)

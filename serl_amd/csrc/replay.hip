@@ -363,10 +363,12 @@ int serl_rb_create(int device, int64_t capacity, int n_cam, int H, int W, int C,
                    int state_dim, int act_dim, serl_rb** out) {
   SERL_REQUIRE(out != nullptr, "out is NULL");
   SERL_REQUIRE(capacity > 1 && capacity < 0x7FFFFFFF, "capacity %lld out of range", (long long)capacity);
-  SERL_REQUIRE(n_cam >= 1 && n_cam <= SERL_MAX_CAMS, "n_cam %d not in [1,%d]", n_cam, SERL_MAX_CAMS);
+  // n_cam == 0: plain ReplayBuffer of flat observations (replay_buffer.py:41-75): every inserted slot is valid
+  SERL_REQUIRE(n_cam >= 0 && n_cam <= SERL_MAX_CAMS, "n_cam %d not in [0,%d]", n_cam, SERL_MAX_CAMS);
   SERL_REQUIRE(num_stack >= 1, "num_stack must be >= 1");
-  SERL_REQUIRE(((size_t)W * C) % 16 == 0, "W*C (%d) must be a multiple of 16 bytes", W * C);
-  SERL_REQUIRE(H >= 1 && state_dim >= 1 && act_dim >= 1, "bad dims");
+  if (n_cam == 0) { H = W = C = 0; }
+  SERL_REQUIRE(n_cam == 0 || ((size_t)W * C) % 16 == 0, "W*C (%d) must be a multiple of 16 bytes", W * C);
+  SERL_REQUIRE((n_cam == 0 || H >= 1) && state_dim >= 1 && act_dim >= 1, "bad dims");
   SERL_HIP(hipSetDevice(device));
   serl_rb* rb = new serl_rb();
   rb->device = device;
@@ -442,12 +444,24 @@ int serl_rb_rng_state(serl_rb* rb, uint64_t out[4], int* has_uint32, uint32_t* u
 int serl_rb_insert(serl_rb* rb, const uint8_t* const* obs_frames, const uint8_t* const* next_frames,
                    const float* state, const float* next_state, const float* action, float reward,
                    float mask, int done) {
-  SERL_REQUIRE(rb && obs_frames && next_frames && state && next_state && action, "NULL argument");
+  SERL_REQUIRE(rb && state && next_state && action, "NULL argument");
+  SERL_REQUIRE(rb->n_cam == 0 || (obs_frames && next_frames), "NULL frames");
   std::lock_guard<std::mutex> g(rb->mu);
   SERL_HIP(hipSetDevice(rb->device));
   int rc = wait_gathers(rb);  // never overwrite a slot an in-flight gather may still read
   if (rc) return rc;
   const int T = rb->T, TS = rb->T * rb->S;
+  if (rb->n_cam == 0) {  // ReplayBuffer.insert (replay_buffer.py:71-75): write at the head, advance, no bookkeeping
+    std::vector<float> r0(rb->rec_len);
+    std::memcpy(r0.data(), state, sizeof(float) * TS);
+    std::memcpy(r0.data() + TS, next_state, sizeof(float) * TS);
+    std::memcpy(r0.data() + 2 * TS, action, sizeof(float) * rb->A);
+    r0[2 * TS + rb->A] = reward;
+    r0[2 * TS + rb->A + 1] = mask;
+    r0[2 * TS + rb->A + 2] = done ? 1.0f : 0.0f;
+    rb->valid[rb->insert_index] = 1;
+    return write_slot(rb, rb->insert_index, nullptr, r0.data());
+  }
   // wrap: re-insert the last T slots at the head as invalid (py:54-59)
   if (rb->insert_index == 0 && rb->cap == rb->size && !rb->first) {
     for (int64_t src = rb->size - T; src < rb->size; ++src) {
@@ -536,7 +550,7 @@ int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
                           uint8_t* const* dev_frames_out, float* dev_state_out,
                           float* dev_next_state_out, float* dev_action_out, float* dev_reward_out,
                           float* dev_mask_out, uint8_t* dev_done_out, void* stream_) {
-  SERL_REQUIRE(rb && host_idx && dev_frames_out, "NULL argument");
+  SERL_REQUIRE(rb && host_idx && (dev_frames_out || rb->n_cam == 0), "NULL argument");
   SERL_REQUIRE(batch > 0, "batch must be positive");
   hipStream_t stream = (hipStream_t)stream_;
   std::lock_guard<std::mutex> g(rb->mu);
@@ -603,9 +617,9 @@ int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* hos
     total += counts[b];
   }
   SERL_REQUIRE(total == out->batch && total > 0, "counts sum %d != batch %d", total, out->batch);
-  SERL_REQUIRE(out->n_cam == r0->n_cam && out->H == r0->H && out->W == r0->W && out->C == r0->C &&
+  SERL_REQUIRE(out->n_cam == r0->n_cam && (r0->n_cam == 0 || (out->H == r0->H && out->W == r0->W && out->C == r0->C)) &&
                    out->state_dim == r0->S && out->act_dim == r0->A, "serl_batch shape mismatch");
-  SERL_REQUIRE(out->frames && out->state && out->action && out->reward && out->mask && out->done,
+  SERL_REQUIRE((out->frames || r0->n_cam == 0) && out->state && out->action && out->reward && out->mask && out->done,
                "serl_batch has NULL outputs");
   for (int k = 0; k < 2; ++k) {
     const int32_t* cr = k ? host_crop_next : host_crop_obs;

@@ -225,6 +225,62 @@ class MemoryEfficientReplayBufferDataStore:
         return self._h
 
 
+class ReplayBufferDataStore(MemoryEfficientReplayBufferDataStore):
+    """Drop-in for the reference's plain `ReplayBufferDataStore` (data_store.py:27-80) of flat observations
+    (ReplayBuffer, replay_buffer.py:41-75: every inserted slot is valid, `Dataset.sample` draws
+    `integers(len, size=B)` with no rejection) -- the store of BASELINE.json configs[0] `async_sac_state_sim`."""
+
+    def __init__(self, observation_space, action_space, capacity: int, rlds_logger=None, device: int = 0):
+        if rlds_logger is not None:
+            raise NotImplementedError("RLDS logging is outside the MI355X hot path")
+        if hasattr(observation_space, "spaces"):
+            raise TypeError("ReplayBufferDataStore holds flat (Box) observations; use the memory-efficient store for pixels")
+        self.pixel_keys = ()
+        self._num_stack = 1
+        self._img_shape = (0, 0, 0)
+        self._S = int(np.prod(_space_shape(observation_space)))
+        self._A = _space_shape(action_space)[0]
+        self._capacity = int(capacity)
+        self.device = device
+        self._torch_device = torch.device("cuda", device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().serl_rb_create(device, self._capacity, 0, 0, 0, 0, 1, self._S, self._A, C.byref(self._h)))
+        self._np_random = None
+        self._seed = None
+
+    def insert(self, data_dict):  # replay_buffer.py:71-75 under the data store's lock (data_store.py:44-46)
+        st = np.ascontiguousarray(data_dict["observations"], dtype=np.float32).reshape(-1)
+        nst = np.ascontiguousarray(data_dict["next_observations"], dtype=np.float32).reshape(-1)
+        act = np.ascontiguousarray(data_dict["actions"], dtype=np.float32).reshape(-1)
+        assert st.size == self._S and nst.size == self._S and act.size == self._A
+        _lib.check(_lib.lib().serl_rb_insert(
+            self._h, None, None, st.ctypes.data, nst.ctypes.data, act.ctypes.data,
+            float(data_dict["rewards"]), float(data_dict["masks"]), int(bool(data_dict["dones"]))))
+
+    def gather(self, indx: np.ndarray, stream=None):
+        indx = np.ascontiguousarray(indx, dtype=np.int64)
+        B, dev = len(indx), self._torch_device
+        st = torch.empty((B, self._S), dtype=torch.float32, device=dev)
+        nst = torch.empty_like(st)
+        act = torch.empty((B, self._A), dtype=torch.float32, device=dev)
+        rew = torch.empty((B,), dtype=torch.float32, device=dev)
+        msk = torch.empty((B,), dtype=torch.float32, device=dev)
+        done = torch.empty((B,), dtype=torch.uint8, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().serl_rb_gather_packed(
+            self._h, indx.ctypes.data, B, None, st.data_ptr(), nst.data_ptr(), act.data_ptr(),
+            rew.data_ptr(), msk.data_ptr(), done.data_ptr(), C.c_void_p(s)))
+        return {"observations": st, "next_observations": nst, "actions": act, "rewards": rew, "masks": msk,
+                "dones": done.bool()}
+
+    def sample(self, batch_size: int, keys=None, indx=None, lazy: bool = False, **kwargs):
+        """Dataset.sample (dataset.py:79-102): `indx` may be given (used by `download`)."""
+        if keys is not None:
+            raise NotImplementedError("key sub-selection is not used on the hot path")
+        idx = self.sample_indices(batch_size) if indx is None else np.asarray(indx, np.int64)
+        return LazyBatch([(self, idx)]) if lazy else self.gather(idx)
+
+
 def gather_crop(parts, crop_obs: Optional[np.ndarray], crop_next: Optional[np.ndarray], out, stream=None):
     """Fused K2+K3+K4 into a DeviceBatch `out` (serl_amd.agents.batch.DeviceBatch)."""
     n = len(parts)

@@ -85,7 +85,7 @@ def restore_checkpoint(ckpt_dir_or_file: str, agent, step: Optional[int] = None,
         sd = msgpack.unpackb(f.read(), ext_hook=_unpack_ext, raw=False, strict_map_key=False)
     core, keys = agent.core, agent.image_keys
     tp = theta_paths(keys)
-    trunk = _trunk_paths()
+    trunk = _trunk_paths() if keys else {}   # the state-only agent has no encoder
     for section, tree in (("params", sd["params"]), ("target_params", sd["target_params"])):
         for leaf, paths in tp.items():
             core.set(section, leaf, _walk(tree, paths[0]))

@@ -42,6 +42,18 @@ def feat_hw(H, W):
 
 
 def theta_shapes(n_cam, H, W, S, A, ensemble=10, hidden=256, bottleneck=256, sle_features=8, proprio_dim=64):
+    if n_cam == 0:   # state-only SAC (SACAgent.create_states, sac.py:486-542): no encoder, per-member Q heads
+        N, Hd = ensemble, hidden
+        return {
+            "critic/w1": (N, S + A, Hd), "critic/b1": (N, Hd), "critic/ln1/scale": (N, Hd), "critic/ln1/bias": (N, Hd),
+            "critic/w2": (N, Hd, Hd), "critic/b2": (N, Hd), "critic/ln2/scale": (N, Hd), "critic/ln2/bias": (N, Hd),
+            "critic/head/kernel": (N, Hd, 1), "critic/head/bias": (N,),
+            "actor/w1": (S, Hd), "actor/b1": (Hd,), "actor/ln1/scale": (Hd,), "actor/ln1/bias": (Hd,),
+            "actor/w2": (Hd, Hd), "actor/b2": (Hd,), "actor/ln2/scale": (Hd,), "actor/ln2/bias": (Hd,),
+            "actor/mean/kernel": (Hd, A), "actor/mean/bias": (A,),
+            "actor/logstd/kernel": (Hd, A), "actor/logstd/bias": (A,),
+            "temp/lagrange": (),
+        }
     fh, fw = feat_hw(H, W)
     E = bottleneck * n_cam + proprio_dim
     sh = {}
@@ -88,7 +100,8 @@ def init_theta(n_cam, H, W, S, A, seed=42, temperature_init=1e-2, **kw):
             out[name] = (rng.standard_normal(shp) / math.sqrt(shp[0] * shp[1] * shp[2])).astype(np.float32)
         elif name.startswith("enc/") and name.endswith("dense/kernel") and "proprio" not in name:
             out[name] = (rng.standard_normal(shp) / math.sqrt(shp[0])).astype(np.float32)  # nn.Dense default
-        elif name in ("critic/w1", "critic/w2"):  # default_init = xavier_uniform, vmapped per member
+        elif name in ("critic/w1", "critic/w2") or (name == "critic/head/kernel" and len(shp) == 3):
+            # default_init = xavier_uniform, vmapped per member
             a = math.sqrt(6.0 / (shp[1] + shp[2]))
             out[name] = rng.uniform(-a, a, shp).astype(np.float32)
         elif name.endswith("kernel") or name in ("actor/w1", "actor/w2"):

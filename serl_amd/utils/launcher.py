@@ -4,7 +4,8 @@ from __future__ import annotations
 from typing import Optional
 
 from ..agents.drq import DrQAgent
-from ..data.data_store import MemoryEfficientReplayBufferDataStore
+from ..agents.sac import SACAgent
+from ..data.data_store import MemoryEfficientReplayBufferDataStore, ReplayBufferDataStore
 
 
 def make_drq_agent(seed, sample_obs, sample_action, image_keys=("image",), encoder_type="small",
@@ -19,12 +20,25 @@ def make_drq_agent(seed, sample_obs, sample_action, image_keys=("image",), encod
         critic_subsample_size=2, batch_size=batch_size, device=device)
 
 
+def make_sac_agent(seed, sample_obs, sample_action, discount=0.99, batch_size=256, device=0):
+    """launcher.py:50-76 (hyper-parameters copied from there; optimizer defaults from sac.py:333-343)."""
+    return SACAgent.create_states(
+        seed, sample_obs, sample_action,
+        policy_kwargs={"tanh_squash_distribution": True, "std_parameterization": "exp", "std_min": 1e-5, "std_max": 5},
+        critic_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
+        policy_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
+        temperature_init=1e-2, discount=discount, backup_entropy=False, critic_ensemble_size=10,
+        critic_subsample_size=2, batch_size=batch_size, device=device)
+
+
 def make_replay_buffer(env, capacity: int = 1000000, rlds_logger_path: Optional[str] = None,
                        type: str = "replay_buffer", image_keys: list = [], preload_rlds_path: Optional[str] = None,
                        preload_data_transform: Optional[callable] = None, device: int = 0):
     """launcher.py:201-271.  Only the memory-efficient pixel buffer lives in HBM."""
     if rlds_logger_path or preload_rlds_path:
         raise NotImplementedError("RLDS logging / preload are outside the MI355X hot path")
+    if type == "replay_buffer":   # launcher.py:236-243
+        return ReplayBufferDataStore(env.observation_space, env.action_space, capacity=capacity, device=device)
     if type != "memory_efficient_replay_buffer":
         raise ValueError(f"Unsupported replay_buffer_type: {type}")
     return MemoryEfficientReplayBufferDataStore(env.observation_space, env.action_space, capacity=capacity,

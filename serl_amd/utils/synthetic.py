@@ -38,3 +38,18 @@ def transition_stream(image_keys, H=128, W=128, C=3, T=1, S=24, A=6, episode_len
         }
         t += 1
         obs = new_obs() if done else nobs
+
+
+def flat_stream(S, A, episode_len, seed):
+    """Flat-observation transitions (async_sac_state_sim: PandaPickCube state obs)."""
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    t = 0
+    obs = rng.standard_normal(S).astype(np.float32)
+    while True:
+        nobs = rng.standard_normal(S).astype(np.float32)
+        done = (t % episode_len) == episode_len - 1
+        yield {"observations": obs, "next_observations": nobs, "actions": rng.uniform(-1, 1, A).astype(np.float32),
+               "rewards": np.float32(1.0 if (done and rng.random() < 0.5) else 0.0), "masks": np.float32(1.0 - done),
+               "dones": bool(done)}
+        obs = rng.standard_normal(S).astype(np.float32) if done else nobs
+        t += 1

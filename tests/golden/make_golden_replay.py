@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import ref_shim  # noqa: E402
-from serl_amd.utils.synthetic import transition_stream  # noqa: E402
+from serl_amd.utils.synthetic import flat_stream, transition_stream  # noqa: E402
 
 CASES = {
     # name: (keys, H, W, C, T, S, A, capacity, n_insert, episode_len, stream_seed, rb_seed, batch, n_samples)
@@ -57,5 +57,33 @@ def main():
         print(name, "ok", {k: v.shape for k, v in rec.items() if k.endswith("_0")})
 
 
+PLAIN_CASES = {  # name: (S, A, capacity, n_insert, episode_len, stream_seed, rb_seed, batch, n_samples)
+    "plain_wrap": (10, 4, 50, 130, 9, 21, 4, 32, 4),
+    "plain_nowrap": (24, 6, 400, 123, 30, 22, 0, 64, 3),
+}
+
+
+def main_plain():
+    Ref = ref_shim.load_reference_plain_buffer_cls()
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, (S, A, cap, n_ins, ep, sseed, rseed, B, ns) in PLAIN_CASES.items():
+        ref = Ref(ref_shim.Box(-np.inf, np.inf, (S,), np.float32), ref_shim.Box(-1, 1, (A,), np.float32), cap)
+        ref.seed(rseed)
+        for tr in itertools.islice(flat_stream(S, A, ep, sseed), n_ins):
+            ref.insert(tr)
+        rec = {"meta": np.array([S, A, cap, n_ins, ep, sseed, rseed, B, ns], np.int64), "size": np.int64(len(ref)),
+               "insert_index": np.int64(ref._insert_index)}
+        for s_ in range(ns):
+            st = ref.np_random.bit_generator.state
+            b = ref.sample(B)
+            ref.np_random.bit_generator.state = st
+            rec[f"idx_{s_}"] = ref.np_random.integers(len(ref), size=B)     # dataset.py:85-89, same stream
+            for f in ("observations", "next_observations", "actions", "rewards", "masks", "dones"):
+                rec[f"{f}_{s_}"] = np.asarray(b[f])
+        np.savez_compressed(os.path.join(out_dir, f"replay_{name}.npz"), **rec)
+        print(name, "ok", {k: v.shape for k, v in rec.items() if k.endswith("_0")})
+
+
 if __name__ == "__main__":
     main()
+    main_plain()

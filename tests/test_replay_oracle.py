@@ -1,6 +1,7 @@
 """CPU: pins oracle/replay_oracle.py against the reference-generated golden fixtures and, when
 /root/reference is present, against the reference class itself."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -91,3 +92,52 @@ def test_concat_and_unpack():
     u = unpack(c, ("im",))
     assert u["observations"]["im"].shape == (5, 1, 4, 4, 3)
     assert u["next_observations"]["im"].shape == (5, 1, 4, 4, 3)
+
+
+# ---- plain ReplayBuffer of flat observations (BASELINE.json configs[0], async_sac_state_sim) -------------------
+PLAIN = ["plain_wrap", "plain_nowrap"]
+
+
+def _plain_oracle(g):
+    import itertools
+    from oracle.replay_oracle import PlainReplayOracle
+    from serl_amd.utils.synthetic import flat_stream
+    S, A, cap, n_ins, ep, sseed, rseed, B, ns = [int(x) for x in g["meta"]]
+    o = PlainReplayOracle(S, A, cap)
+    o.seed(rseed)
+    for tr in itertools.islice(flat_stream(S, A, ep, sseed), n_ins):
+        o.insert(tr)
+    return o, B, ns
+
+
+@pytest.mark.parametrize("name", PLAIN)
+def test_plain_oracle_matches_reference_golden(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"replay_{name}.npz"))
+    o, B, ns = _plain_oracle(g)
+    assert len(o) == int(g["size"]) and o.insert_index == int(g["insert_index"])
+    for s in range(ns):
+        idx = o.sample_indices(B)
+        assert np.array_equal(idx, g[f"idx_{s}"])
+        b = o.gather(idx)
+        for f in ("observations", "next_observations", "actions", "rewards", "masks", "dones"):
+            assert np.array_equal(b[f], g[f"{f}_{s}"]), (s, f)
+
+
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+def test_plain_oracle_matches_live_reference():
+    import itertools
+    from oracle.replay_oracle import PlainReplayOracle
+    from serl_amd.utils.synthetic import flat_stream
+    Ref = ref_shim.load_reference_plain_buffer_cls()
+    S, A, cap = 7, 3, 41
+    ref = Ref(ref_shim.Box(-np.inf, np.inf, (S,), np.float32), ref_shim.Box(-1, 1, (A,), np.float32), cap)
+    o = PlainReplayOracle(S, A, cap)
+    ref.seed(5); o.seed(5)
+    for i, tr in enumerate(itertools.islice(flat_stream(S, A, 6, 99), 100)):
+        ref.insert(tr); o.insert(tr)
+        if i % 17 == 16:
+            b = ref.sample(13)
+            idx = o.sample_indices(13)
+            ob = o.gather(idx)
+            for f in ("observations", "next_observations", "actions", "rewards", "masks", "dones"):
+                assert np.array_equal(np.asarray(b[f]), ob[f]), (i, f)
