@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/t.log 2>&1; echo rc=$? >> gpurun_out/t.log; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" gpurun_out/t.log | tail -6
+timeout 300 python scripts/bench_sac_state.py 200 > gpurun_out/sac_state.json 2> gpurun_out/sac_state.err; tail -1 gpurun_out/sac_state.json; tail -3 gpurun_out/sac_state.err
