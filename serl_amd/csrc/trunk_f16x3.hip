@@ -432,205 +432,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-specialised variant for the large tiles: 4 consumer waves (64x64 MFMA tiles each) + 2 producer
-// waves per workgroup.  Producers stream split16 activation records and fp16 weight slots
-// global -> registers -> a 3-stage LDS ring: two chunks ahead of the consumers in LDS plus one more
-// chunk in flight in registers;
-// consumers only do ds_read_b128 + MFMA.  One workgroup barrier per K chunk.
-// ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int PMODE>
-__global__ __launch_bounds__(384) void conv_igemm_f16x3_ws_kernel(ConvArgsB ab) {
-  static_assert(WM * WN == 4, "4 consumer waves");
-  const ConvArgs& a = ab.c;
-  constexpr int TM = 2, TN = 2, WROWS = 64, WCOLS = 64;
-  constexpr int BM = WROWS * WM, BN = WCOLS * WN, NS = 3;
-  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = 2 * A_PLANE + 2 * B_PLANE;
-  constexpr int ARECS = BM * 8 / 128, BVECS = BN * 8 / 128;  // per producer lane per chunk
-  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
-  const int niter = nchunks;  // both roles run the same number of barrier rounds
-  // producer staging registers (declared at function scope: block-scope arrays were left in scratch)
-  // (native vector type, not HIP's uint4 struct: struct copies lower to memcpy and block register promotion)
-  u32x4 ra0[ARECS], rb0[BVECS];  // one chunk in flight in registers, two more already in the LDS ring
-  unsigned ok0 = 0;
-
-  if (wave >= 4) {
-    // ------------------------------- producers -------------------------------
-    const int pt = tid - 256;  // 0..127
-    const int ntaps = a.KH * a.KW;
-    long rbase[ARECS];
-    unsigned rmask[ARECS];
-    int aoff[ARECS];  // LDS byte offset of the record inside a stage (hi plane)
-#pragma unroll
-    for (int j = 0; j < ARECS; ++j) {
-      const int idx = pt + 128 * j, row = idx >> 3, kq = idx & 7;
-      const int m = m0 + row;
-      rbase[j] = 0; rmask[j] = 0;
-      aoff[j] = swz(row, kq >> 1) + (kq & 1) * 8;
-      if (m < a.M) {
-        const int n = m / a.P, rem = m - n * a.P;
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        rbase[j] = ((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin + 4 * kq;
-        for (int t = 0; t < ntaps; ++t) {
-          const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
-          if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) rmask[j] |= 1u << t;
-        }
-      }
-    }
-    int woff[BVECS], boff[BVECS];  // weight element offset (lo plane flagged in bit 30) / LDS byte offset
-#pragma unroll
-    for (int j = 0; j < BVECS; ++j) {
-      const int idx = pt + 128 * j, plane = idx / (BN * 4), r = (idx / 4) % BN, sl = idx & 3;
-      woff[j] = ((n0 + r) * ab.K + sl * 8) | (plane << 30);
-      boff[j] = 2 * A_PLANE + plane * B_PLANE + swz(r, sl);
-    }
-    int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_c = 0;  // counters of the NEXT chunk to load
-#define SERL_P_LOAD(RA, RB, OK)                                                                            \
-  {                                                                                                        \
-    const int toff_ = ((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + l_ci0;                           \
-    OK = 0;                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < ARECS; ++j) {                                                    \
-      const bool ok = (rmask[j] >> l_tap) & 1u;                                                            \
-      OK |= (ok ? 1u : 0u) << j;                                                                           \
-      RA[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[j] + (ok ? toff_ : l_ci0));                     \
-    }                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < BVECS; ++j)                                                      \
-        RB[j] = *reinterpret_cast<const u32x4*>(((woff[j] >> 30) ? ab.wlo : ab.whi) + (woff[j] & 0x3FFFFFFF) + (l_c << 5)); \
-    if (l_c + 1 < nchunks) {                                                                               \
-      ++l_c;                                                                                               \
-      l_ci0 += 32;                                                                                         \
-      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                \
-    }                                                                                                      \
-  }
-#define SERL_P_STORE(RA, RB, OK, STG)                                                                      \
-  {                                                                                                        \
-    uint8_t* st_ = smemb + (STG) * STAGE;                                                                  \
-    _Pragma("unroll") for (int j = 0; j < ARECS; ++j) {                                                    \
-      u32x4 v = RA[j];                                                                                     \
-      if (!((OK >> j) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                                  \
-      *reinterpret_cast<u32x2*>(st_ + aoff[j]) = (u32x2){v[0], v[1]};                                      \
-      *reinterpret_cast<u32x2*>(st_ + A_PLANE + aoff[j]) = (u32x2){v[2], v[3]};                            \
-    }                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < BVECS; ++j) *reinterpret_cast<u32x4*>(st_ + boff[j]) = RB[j];    \
-  }
-    // prologue: chunks 0 and 1 into LDS stages 0 and 1, chunk 2 in flight in registers
-    SERL_P_LOAD(ra0, rb0, ok0);
-    SERL_P_STORE(ra0, rb0, ok0, 0);
-    SERL_P_LOAD(ra0, rb0, ok0);
-    SERL_P_STORE(ra0, rb0, ok0, 1);
-    SERL_P_LOAD(ra0, rb0, ok0);
-    __syncthreads();
-    int stg = 2;  // stage that receives chunk c+2
-    for (int c = 0; c < niter; ++c) {
-      SERL_P_STORE(ra0, rb0, ok0, stg);  // chunk c+2 (consumers read chunk c meanwhile)
-      SERL_P_LOAD(ra0, rb0, ok0);        // chunk c+3, lands during the next round
-      stg = stg == NS - 1 ? 0 : stg + 1;
-      __syncthreads();
-    }
-#undef SERL_P_LOAD
-#undef SERL_P_STORE
-    return;
-  }
-
-  // ------------------------------- consumers -------------------------------
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  f32x16 acc[TM][TN], accx[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
-  int aro[TM], bro[TN];  // swizzle-free parts of the fragment addresses
-  __syncthreads();       // prologue stages are ready
-  int stg = 0;
-  for (int c = 0; c < niter; ++c) {
-    if (c < nchunks) {
-      const uint8_t* st = smemb + stg * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);
-          ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);
-          alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + off);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int off = 2 * A_PLANE + swz(wn * WCOLS + tn * 32 + li, 2 * ks + lh);
-          bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);
-          blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-            accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-          }
-      }
-    }
-    stg = stg == NS - 1 ? 0 : stg + 1;
-    __syncthreads();
-  }
-  (void)aro; (void)bro;
-
-  const int wrow0 = m0 + wm * WROWS;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < a.M) {
-        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
-      }
-    }
-  if (PMODE != 3) {
-    const int gsize = a.Cout / kGnGroups;
-    constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
-    constexpr int NSLOT = WROWS / ROWS;
-#pragma unroll
-    for (int slot = 0; slot < NSLOT; ++slot) {
-      const int mrow = wrow0 + slot * ROWS;
-      const bool valid = mrow < a.M;
-      const int n = valid ? mrow / a.P : 0;
-      double* stp = a.stats + (size_t)n * kGnGroups * 2;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = tm * 32 + 8 * (r >> 2);
-            if (row / ROWS == slot) {
-              const float v = acc[tm][tn][r];
-              s += v;
-              q += v * v;
-            }
-          }
-        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // conv_init in split-fp16: u8 image -> normalise -> conv 7x7 stride 2 pad 3, 3 -> 64.
 // K is re-indexed as k' = ky*24 + (kx*3 + c) (21 real taps per kernel row + 3 zero-weight pads, 7 rows
 // -> 168, padded to 176 = 11 MFMA k-steps) so that every 8-wide MFMA k-block is a contiguous run of
@@ -991,9 +792,6 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 2>), grid, block, lds, stream, ab); \
     else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3>), grid, block, lds, stream, ab);                 \
   } while (0)
-    // wave-specialised variant: measured slower than two co-resident 4-wave workgroups (the convs are bound
-    // by L2->LDS operand bandwidth, not latency); kept for experiments behind SERL_CONV_WS=1
-    static const bool use_ws = []() { const char* e = getenv("SERL_CONV_WS"); return e && e[0] == '1'; }();
     static const bool use_rp = []() { const char* e = getenv("SERL_CONV_ROWPATCH"); return !(e && e[0] == '0'); }();
     const bool rp_ok = use_rp && ksz == 3 && stride == 1 && Cout == 64 && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
                        (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 &&
@@ -1001,19 +799,6 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     if (rp_ok) {
       hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),
                          stream, ab);
-    } else if (use_ws && cfg != 2) {
-      const size_t lds_ws = (size_t)3 * (2 * BM * 64 + 2 * BN * 64);
-      dim3 block_ws(384);
-#define SERL_LAUNCH_WS(WM, WN)                                                                                            \
-  do {                                                                                                                    \
-    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_ws_kernel<WM, WN, 0>), grid, block_ws, lds_ws, stream, ab);        \
-    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_ws_kernel<WM, WN, 1>), grid, block_ws, lds_ws, stream, ab);   \
-    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_ws_kernel<WM, WN, 2>), grid, block_ws, lds_ws, stream, ab);   \
-    else hipLaunchKernelGGL((conv_igemm_f16x3_ws_kernel<WM, WN, 3>), grid, block_ws, lds_ws, stream, ab);                   \
-  } while (0)
-      if (cfg == 0) SERL_LAUNCH_WS(2, 2);
-      else SERL_LAUNCH_WS(4, 1);
-#undef SERL_LAUNCH_WS
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
     else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
