@@ -74,6 +74,9 @@ def main():
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
+    ap.add_argument("--prio", choices=["auto", "update", "trunk", "none"], default="auto",
+                    help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
+                         "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -129,7 +132,9 @@ def main():
         return dbs[slot]
 
     from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
-    sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank))
+    prio = args.prio if args.prio != "auto" else ("trunk" if Bl >= 128 else "update")
+    sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank), prioritise_update=prio == "update",
+                                                                            prioritise_trunk=prio == "trunk")
     learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world,
                                   all_reduce=(lambda t: dist.all_reduce(t)) if dist is not None else (lambda t: None),
                                   seed=7, schedule=sched)

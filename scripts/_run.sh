@@ -1,2 +1,7 @@
-timeout 600 python -m pytest tests/test_agent_gpu.py -x -q -k "trunk_forward or full_size or pipelined" 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" | tail -2
-timeout 200 python bench.py --no-cpu-baseline --steps 40 | tail -1 | cut -c1-200
+mkdir -p gpurun_out/ab
+run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
+import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ab/$tag.err; }
+for p in update trunk none; do
+run n1_$p timeout 200 python bench.py --no-cpu-baseline --steps 60 --prio $p
+run e8_$p timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8 --prio $p
+done

@@ -72,13 +72,13 @@ class TorchPipelineSchedule:
     """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream."""
     slots = 2
 
-    def __init__(self, device, prioritise_update=True):
+    def __init__(self, device, prioritise_update=True, prioritise_trunk=False):
         import torch
         self.torch = torch
         self.device = device
         # the update's long chain of small dependent kernels gets the high-priority queue so that it is
         # not starved by the (throughput-bound) trunk kernels of the next batch
-        self.side_stream = torch.cuda.Stream(device=device, priority=0)
+        self.side_stream = torch.cuda.Stream(device=device, priority=-1 if prioritise_trunk else 0)
         self.main_stream = torch.cuda.Stream(device=device, priority=-1) if prioritise_update else None
         self.ev_prod = [torch.cuda.Event() for _ in range(2)]
         self.ev_cons = [None, None]
