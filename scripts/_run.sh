@@ -1,7 +1,2 @@
-mkdir -p gpurun_out/ab
-run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
-import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ab/$tag.err; }
-for p in update trunk none; do
-run n1_$p timeout 200 python bench.py --no-cpu-baseline --steps 60 --prio $p
-run e8_$p timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8 --prio $p
-done
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/t.log 2>&1; echo rc=$? >> gpurun_out/t.log; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" gpurun_out/t.log | tail -4
+SERL_POOL_FUSE=0 timeout 300 python -m pytest tests/test_agent_gpu.py -x -q -k "trunk_forward" 2>&1 | tail -2

@@ -83,7 +83,8 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
 
 // conv_init in split-fp16 (weights re-indexed and padded to [64][176])
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream);
+// pool_gamma != nullptr: fused 3x3/2 max-pool (trunk_f16x3.hip); `out` then receives the three compact outputs
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream);
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr);
 
 }  // namespace serl

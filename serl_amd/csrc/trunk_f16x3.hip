@@ -442,9 +442,14 @@ struct ConvInitArgsB {
   const uint8_t* img;   // [N][H][W][3]
   const uint16_t* whi;  // [64][176] fp16
   const uint16_t* wlo;  // [64][176] fp16 residual (unscaled)
-  float* out;           // [N][Ho][Wo][64]
+  float* out;           // [N][Ho][Wo][64]   (POOL: unused)
   double* stats;        // [N][4][2]
   int N, H, W, Ho, Wo, tiles_y, tiles_x, total_tiles;
+  // POOL (fused 3x3/2 max-pool, see conv_init_f16x3_kernel): sign source and the three compact outputs
+  const float* gamma;   // [64] GroupNorm scale of norm_init
+  float* pooled;        // [N][Ho/2][Wo/2][64] extreme of the in-tile part of every pooling window
+  float* first_rows;    // [N][tiles_y][Wo][64] raw conv outputs of rows 0 mod 16
+  float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
 };
 
 constexpr int kCbKP = 176;       // padded K
@@ -455,6 +460,13 @@ constexpr int kCbWBytes = 64 * kCbWP * 2;         // one weight plane
 constexpr int kCbPBytes = kCbPatch * kCbPWH * 2;  // one patch plane
 constexpr int kCbLds = 2 * kCbWBytes + 2 * kCbPBytes + 768 * 4;
 
+// POOL: relu(GN(.)) is monotone in the raw conv output with the sign of the channel's GroupNorm scale gamma (a frozen
+// parameter), so max_pool(relu(GN(x))) = relu(GN(extreme(x))) with extreme = max where gamma >= 0 and min where
+// gamma < 0 -- bit for bit (rounding is monotone).  The pooling can therefore run HERE, before the image's
+// statistics exist: the tile writes, per channel, the extreme over the in-tile part of each 3x3/2 window (1/4 of the
+// raw tensor) plus its first row and first column raw (the missing row/column of the windows of the tile above /
+// to the left), instead of 1 MiB of raw fp32 per image that the pool kernel re-read 1.5x.
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   uint8_t* w_hi = smemb;
@@ -566,22 +578,91 @@ __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a
         }
     }
     float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+    if (!POOL) {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-        const bool ok = oy < a.Ho && ox < a.Wo;
-        float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
+        for (int r = 0; r < 16; ++r) {
+          const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+          const bool ok = oy < a.Ho && ox < a.Wo;
+          float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          const float v = ok ? acc[tm][tn][r] : 0.f;
-          if (ok) o[tn * 32 + li] = v;
-          s[tn] += v;
-          q[tn] += v * v;
+          for (int tn = 0; tn < 2; ++tn) {
+            const float v = ok ? acc[tm][tn][r] : 0.f;
+            if (ok) o[tn * 32 + li] = v;
+            s[tn] += v;
+            q[tn] += v * v;
+          }
         }
+    } else {  // (the launcher guarantees Ho, Wo multiples of 16: every tile is full)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const float v = acc[tm][tn][r];
+            s[tn] += v;
+            q[tn] += v * v;
+          }
+      // pixel p = wave*64 + tm*32 + 8*(r>>2) + 4*lh + (r&3) -> (row p>>4, col p&15) of the tile
+      if (wave == 0) {  // tile row 0: tm = 0, r < 8, col = 8*(r>>2) + 4*lh + (r&3)
+        float* fr = a.first_rows + (((size_t)n * a.tiles_y + (oy0 >> 4)) * a.Wo + ox0 + 4 * lh) * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) fr[(8 * (r >> 2) + (r & 3)) * 64 + tn * 32] = acc[0][tn][r];
       }
+      if (lh == 0) {    // tile column 0: r in {0, 8}, row = wave*4 + tm*2 + (r>>3)
+        float* fc = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + (ox0 >> 4)) * 64 + li;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              fc[(size_t)(tm * 2 + rr) * a.tiles_x * 64 + tn * 32] = acc[tm][tn][8 * rr];
+      }
+      __syncthreads();  // every wave is done reading the patch planes: reuse them as the pooling stage
+      float* stage = reinterpret_cast<float*>(p_hi);  // [16x16 pixels][16 channels] fp32 = 16 KB <= 2 patch planes
+      static_assert(2 * kCbPBytes >= 16 * 16 * 16 * 4, "pooling stage does not fit the patch planes");
+      const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // 16 channels at a time (fully unrolled: acc[..][g >> 1] stays in registers)
+        if ((li >> 4) == (g & 1)) {
+          const float sgn = a.gamma[(g >> 1) * 32 + li] < 0.f ? -1.f : 1.f;
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              stage[p * 16 + (li & 15)] = sgn * acc[tm][g >> 1][r];  // sign-folded: always a max below
+            }
+        }
+        __syncthreads();
+        {
+          const int cell = tid >> 2, c4 = tid & 3, py = cell >> 3, px = cell & 7;
+          float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int y = 2 * py + dy, x = 2 * px + dx;
+              if (y < 16 && x < 16) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + (y * 16 + x) * 16 + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+              }
+            }
+          const float4 gm = *reinterpret_cast<const float4*>(a.gamma + g * 16 + c4 * 4);
+          m.x = gm.x < 0.f ? -m.x : m.x; m.y = gm.y < 0.f ? -m.y : m.y;
+          m.z = gm.z < 0.f ? -m.z : m.z; m.w = gm.w < 0.f ? -m.w : m.w;
+          *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + (oy0 >> 1) + py) * Wp + (ox0 >> 1) + px) * 64 +
+                                     g * 16 + c4 * 4) = m;
+        }
+        __syncthreads();
+      }
+    }
     double* st = a.stats + (size_t)n * kGnGroups * 2;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
@@ -609,7 +690,7 @@ int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t
 }
 
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream) {
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma) {
   ConvInitArgsB a{};
   a.img = img; a.whi = w.hi; a.wlo = w.lo; a.out = out; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
@@ -617,7 +698,16 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   const int grid = std::min(a.total_tiles, 512);  // 2 persistent workgroups per CU
   ProfScope prof("conv_init", stream);
-  hipLaunchKernelGGL(conv_init_f16x3_kernel, dim3(grid), dim3(256), kCbLds, stream, a);
+  if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
+    SERL_REQUIRE(Ho % 16 == 0 && Wo % 16 == 0, "fused conv_init pooling needs full 16x16 tiles");
+    a.gamma = pool_gamma;
+    a.pooled = out;
+    a.first_rows = a.pooled + (size_t)N * (Ho / 2) * (Wo / 2) * 64;
+    a.first_cols = a.first_rows + (size_t)N * a.tiles_y * Wo * 64;
+    hipLaunchKernelGGL(conv_init_f16x3_kernel<true>, dim3(grid), dim3(256), kCbLds, stream, a);
+  } else {
+    hipLaunchKernelGGL(conv_init_f16x3_kernel<false>, dim3(grid), dim3(256), kCbLds, stream, a);
+  }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -714,6 +804,62 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_split_kernel(const float*
     }
   }
   out[e] = to_split16(m);
+}
+
+// Second half of the fused pool: completes the windows that cross a tile edge from the neighbours' first row / column,
+// then GroupNorm + ReLU on the extreme and conversion to split16.
+__global__ __launch_bounds__(256) void pool_finish_split_kernel(const float* pooled, const float* first_rows,
+                                                               const float* first_cols, GnRef gn, uint4* out, int N,
+                                                               int Ho, int Wo, int tiles_y, int tiles_x) {
+  // one thread = 4 channels x 4 consecutive pooled pixels of a row (the GroupNorm coefficients, derived from the
+  // fp64 statistics, are computed once per thread)
+  const int Hp = Ho >> 1, Wp = Wo >> 1, Wq = Wp >> 2;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * Hp * Wq * 16) return;
+  const int c4 = (int)(e & 15);
+  long t = e >> 4;
+  const int pq = (int)(t % Wq);
+  t /= Wq;
+  const int py = (int)(t % Hp);
+  const int n = (int)(t / Hp);
+  float4 s, h;
+  gn_coef4(gn, n, c4 * 4, s, h);
+  const float4 gm = *reinterpret_cast<const float4*>(gn.gamma + c4 * 4);
+  const float4 sg = make_float4(gm.x < 0.f ? -1.f : 1.f, gm.y < 0.f ? -1.f : 1.f, gm.z < 0.f ? -1.f : 1.f, gm.w < 0.f ? -1.f : 1.f);
+  const bool edge_row = (py & 7) == 7 && 2 * py + 2 < Ho;  // window row 2py+2 is the first row of the tile below
+  const float* rr = first_rows + (((size_t)n * tiles_y + (edge_row ? (2 * py + 2) / 16 : 0)) * Wo) * 64 + c4 * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int px = 4 * pq + j;
+    const size_t o = (((size_t)n * Hp + py) * Wp + px) * 16 + c4;
+    float4 m = *reinterpret_cast<const float4*>(pooled + o * 4);
+    m.x *= sg.x; m.y *= sg.y; m.z *= sg.z; m.w *= sg.w;  // sign-folded domain: extreme == max
+    if (edge_row) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * px + dx;
+        if (x < Wo) {
+          const float4 v = *reinterpret_cast<const float4*>(rr + (size_t)x * 64);
+          m.x = fmaxf(m.x, sg.x * v.x); m.y = fmaxf(m.y, sg.y * v.y); m.z = fmaxf(m.z, sg.z * v.z); m.w = fmaxf(m.w, sg.w * v.w);
+        }
+      }
+    }
+    if (j == 3 && (px & 7) == 7 && 2 * px + 2 < Wo) {  // window column 2px+2 is the first column of the tile to the right
+      const int tcol = (2 * px + 2) / 16;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int y = 2 * py + dy;
+        if (y < Ho) {
+          const float4 v = *reinterpret_cast<const float4*>(first_cols + (((size_t)n * Ho + y) * tiles_x + tcol) * 64 + c4 * 4);
+          m.x = fmaxf(m.x, sg.x * v.x); m.y = fmaxf(m.y, sg.y * v.y); m.z = fmaxf(m.z, sg.z * v.z); m.w = fmaxf(m.w, sg.w * v.w);
+        }
+      }
+    }
+    m.x *= sg.x; m.y *= sg.y; m.z *= sg.z; m.w *= sg.w;  // back to the raw extreme
+    m.x = fmaxf(m.x * s.x + h.x, 0.f); m.y = fmaxf(m.y * s.y + h.y, 0.f);
+    m.z = fmaxf(m.z * s.z + h.z, 0.f); m.w = fmaxf(m.w * s.w + h.w, 0.f);
+    out[o] = to_split16(m);
+  }
 }
 
 // relu(GN(raw)) -> split16: the input of a block's second conv
@@ -842,9 +988,22 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
   SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
   int rc;
+  static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
+  const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
   if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo}, ws.raw_init, stats_of(0), N, d.H,
-                                   d.W, d.h[0], d.w[0], stream))) return rc;
-  {
+                                   d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr))) return rc;
+  if (fuse_pool) {
+    const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
+    const int ty = d.h[0] / 16, tx = d.w[0] / 16;
+    const float* pooled = ws.raw_init;
+    const float* frows = pooled + (size_t)N * d.h[1] * d.w[1] * 64;
+    const float* fcols = frows + (size_t)N * ty * d.w[0] * 64;
+    ProfScope prof("gn_relu_maxpool", stream);
+    hipLaunchKernelGGL(pool_finish_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, pooled, frows, fcols,
+                       gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+                       reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], ty, tx);
+    SERL_HIP(hipGetLastError());
+  } else {
     const long tot = (long)N * d.h[1] * d.w[1] * 16;
     ProfScope prof("gn_relu_maxpool", stream);
     hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init,
