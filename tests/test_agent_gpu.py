@@ -425,3 +425,26 @@ def test_baseline_config_shapes_match_oracle(gpu, name, keys, S, A, car):
             assert abs(got[k] - info[k]) < 2 * TOL * max(1.0, abs(info[k])), (name, it, k, got[k], info[k])
     _compare_state(cfg, st, core, tol=5e-4 if car > 2 else TOL, steps=car + 1)
     assert core.step == st.step == car + 1
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_trunk_with_negative_and_zero_groupnorm_scales(gpu, mode):
+    """The fused conv_init max-pool picks max or min of the raw conv output by the sign of the channel's GroupNorm
+    scale (max_pool(relu(GN(x))) = relu(GN(extreme(x)))): exercise negative, zero and positive scales."""
+    cfg = O.Config(image_keys=("a",), H=64, W=128, S=4, A=2)
+    trunk, theta = O.init_params(cfg, 42)
+    rng = np.random.default_rng(7)
+    g = trunk["trunk/norm_init/scale"].copy()
+    g[rng.random(64) < 0.4] *= -1.0
+    g[:3] = 0.0
+    trunk["trunk/norm_init/scale"] = g
+    from serl_amd.agents.core import AgentCore
+    core = AgentCore(n_cam=1, H=cfg.H, W=cfg.W, state_dim=cfg.S, act_dim=cfg.A, batch=8)
+    core.set_trunk_mode(mode)
+    for sec in ("params", "target_params"):
+        core.load_flat(sec, trunk)
+    st = O.TrainState(cfg, trunk, theta)
+    img = rng.integers(0, 256, (6, cfg.H, cfg.W, 3), dtype=np.uint8)
+    ref = O.trunk_forward(st.trunk, torch.tensor(img), torch.float64).numpy()
+    got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+    assert (g < 0).sum() > 10 and AH.rel_err(got, ref) < (TOL if mode == "f16x3" else 2e-5)
