@@ -74,6 +74,8 @@ def main():
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
+    ap.add_argument("--workload", choices=["drq", "sac_state"], default="drq",
+                    help="drq: the official bench line; sac_state: side measurement of configs[0] (state-only SAC)")
     ap.add_argument("--prio", choices=["auto", "update", "trunk", "none"], default="auto",
                     help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
@@ -82,6 +84,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
+    if args.workload == "sac_state":
+        return sac_state_main(max(args.steps, 50))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +268,70 @@ def main():
         pass
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def sac_state_main(iters):
+    """Side measurement (NOT the official bench line): BASELINE.json configs[0] `async_sac_state_sim` -- state-only SAC,
+    batch 256 x UTD 8 = 2048 sampled per iteration, `update_high_utd(utd_ratio=8)`
+    (examples/async_sac_state_sim/async_sac_state_sim.py:231,296), plain replay buffer in HBM -- next to the CPU port
+    (oracle, PyTorch-CPU fp32) on the box's host cores."""
+    S, A, B, UTD = 10, 4, 2048, 8
+
+    class _Box:
+        def __init__(self, shape):
+            self.shape = shape
+
+    class _Env:
+        observation_space, action_space = _Box((S,)), _Box((A,))
+
+    from serl_amd.utils.launcher import make_replay_buffer, make_sac_agent
+    from serl_amd.utils.synthetic import flat_stream
+    rb = make_replay_buffer(_Env(), capacity=1_000_000, type="replay_buffer")
+    rb.seed(0)
+    for tr in itertools.islice(flat_stream(S, A, 100, 1234), 20000):
+        rb.insert(tr)
+    agent = make_sac_agent(42, np.zeros((S,), np.float32), np.zeros((A,), np.float32), batch_size=B)
+    it = rb.get_iterator(sample_args={"batch_size": B, "lazy": True})
+    for _ in range(20):
+        agent.update_high_utd(next(it), utd_ratio=UTD)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        agent.update_high_utd(next(it), utd_ratio=UTD)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "async_sac_state_sim (state-only SAC, 2048 = 256 x UTD 8 per iteration)", "iterations": iters,
+           "ms_per_iteration": round(1e3 * dt / iters, 4), "critic_grad_steps_per_s": round(UTD * iters / dt, 2),
+           "kernels": "same HIP kernels as the DrQ update chain (latency-bound: ~75 dependent launches per grad-step pair)"}
+    # CPU port: the oracle in fp32 on the host cores
+    from oracle import drq_oracle as O
+    ncpu = _effective_cpus()
+    torch.set_num_threads(ncpu)
+    cfg = O.Config(image_keys=(), S=S, A=A, discount=0.99, warmup=2000, temp_warmup=0)
+    _, theta = O.init_params(cfg, 42)
+    st = O.TrainState(cfg, {}, theta, torch.float32)
+    rng = np.random.default_rng(0)
+
+    def cpu_iter():
+        b = {"obs": {}, "next": {}, "state": torch.tensor(rng.standard_normal((B, S)), dtype=torch.float32),
+             "next_state": torch.tensor(rng.standard_normal((B, S)), dtype=torch.float32),
+             "action": torch.tensor(rng.uniform(-1, 1, (B, A)), dtype=torch.float32),
+             "reward": torch.tensor(rng.random(B), dtype=torch.float32), "mask": torch.ones(B)}
+        n = O.noise_to_torch(O.make_noise(cfg, B, seed=int(rng.integers(1 << 30)), utd_ratio=UTD), torch.float32)
+        O.update_high_utd(st, b, n, UTD)
+    cpu_iter()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 8.0:
+        cpu_iter()
+        n += 1
+    cdt = time.perf_counter() - t0
+    out["cpu_port"] = {"critic_grad_steps_per_s": round(UTD * n / cdt, 2), "cores": ncpu, "iterations": n,
+                       "kind": "port (oracle, PyTorch-CPU fp32)"}
+    out["speedup"] = round(out["critic_grad_steps_per_s"] / out["cpu_port"]["critic_grad_steps_per_s"], 1)
+    print(json.dumps(out))
+
+
 
 
 def cpu_baseline(budget_s):

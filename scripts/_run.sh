@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_agent_gpu.py -x -q -k "negative_and_zero" 2>&1 | grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" | tail -8
+timeout 300 python bench.py --workload sac_state --steps 200 2>/dev/null | tail -1 | cut -c1-300
