@@ -30,7 +30,6 @@ struct LnFwdArgs {
   const float* dot_w; const float* dot_b; float* dot_out;
   long dot_gstride, dot_b_gstride;  // 0: one head shared by all groups (DrQ critic); else per-group heads (ensemblized Critic)
 };
-int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream);
 int ln_tanh_fwd_multi(const LnFwdArgs* a, int n, int D, hipStream_t stream);
 
 struct LnBwdArgs {
@@ -51,46 +50,35 @@ int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D
            long out_gstride, bool accumulate, hipStream_t stream);
 int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
-int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
-            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream);
 struct SleFwdArgs { const float* x; const float* K; const uint8_t* mask; float* f; };
 int sle_fwd_multi(const SleFwdArgs* v, int n, float keep_scale, int N, int HW, int Cc, int groups, long x_gs, long k_gs,
                   long mask_gs, long f_gs, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
             long x_gs, long df_gs, long part_gs, hipStream_t stream);
-int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream);
-int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream);
 // dbias: gradient of the head bias -- one scalar (shared head) or, with per_member_bias, one per ensemble member
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
                 hipStream_t stream, bool per_member_bias = false);
-// slabs: [2][B][A] raw head GEMM outputs (mean, log_std); biases added here and the result kept in `pre`
-int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
-                    int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
-                    float* sum_logp, hipStream_t stream);
+// tanh-Gaussian policy head: slabs = raw head GEMM outputs (mean, log_std); biases added here, result kept in `pre`
 struct PolicyDistArgs {
   const float* slabs; const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
   float* act; long ld_act; float* logp; float* std_out; float* sum_logp;
   const float* lam; float* alpha_out;  // optional rider: alpha_out[0] = softplus(lam[0])
 };
 int policy_dist_fwd_multi(const PolicyDistArgs* v, int n, int B, int A, float std_min, float std_max, hipStream_t stream);
+// proprio branch: y = tanh(LN(state W + b)) with W [S][64] (encoding.py:55-70), one wave per row
 struct ProprioArgs {
   const float* state; const float *W, *b, *gamma, *beta;
   float* y; long ld_y; float* xhat; float* rstd;
   const float* copy_src; long ld_copy_src; float* copy_dst; long ld_copy_dst; int copy_cols;  // optional rider
 };
 int proprio_fwd_multi(const ProprioArgs* v, int n, int S, int rows, hipStream_t stream);
-// proprio branch: y = tanh(LN(state W + b)) with W [S][64] (encoding.py:55-70), one wave per row
-int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
-                int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream);
 int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
                     float std_min, float std_max, float* dpre, hipStream_t stream);
-int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream);
 struct CopyJob { const float* src; long ld_src; float* dst; long ld_dst; int cols; };
 int copy_cols_multi(const CopyJob* jobs, int n, int rows, hipStream_t stream);
 int fill(float* p, float v, long n, hipStream_t stream);
-int temperature_alpha(const float* lam, float* out, hipStream_t stream);
 int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream);
 
 struct AdamArgs {
@@ -111,13 +99,10 @@ struct AdamArgs {
   float info_w, inv_eb;
 };
 int adam_ema(const AdamArgs& a, hipStream_t stream);
-int ema(const float* p, float* tp, float tau, long n, hipStream_t stream);
 // kind 0: N(0,1) f32, 1: keep-mask u8.  The tensor is [planes][rows_local][row_elems]; the value of an element is a
 // hash of its position in the GLOBAL tensor [planes][rows_global][row_elems] (rows row_offset.. of it), so that a
 // batch-sharded job draws the same noise for a sample whichever rank owns it (rows_global == 0: local == global)
 struct NoiseJob { void* out; long n; uint64_t seed; int kind; float keep; long rows_local, rows_global, row_offset, row_elems; };
 int gen_noise_multi(const NoiseJob* v, int n, hipStream_t stream);
-int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream);
-int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream);
 
 }  // namespace serl

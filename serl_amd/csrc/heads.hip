@@ -343,7 +343,6 @@ int ln_tanh_fwd_multi(const LnFwdArgs* as, int n, int D, hipStream_t stream) {
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
-int ln_tanh_fwd(const LnFwdArgs& a, int D, hipStream_t stream) { return ln_tanh_fwd_multi(&a, 1, D, stream); }
 
 // backward of y = tanh(gamma*xhat + beta), xhat = (x-mean)*rstd:
 //   dg = dy*(1-y^2);  dxhat = dg*gamma;  dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat))
@@ -501,11 +500,6 @@ int sle_fwd_multi(const SleFwdArgs* vs, int n, float keep_scale, int N, int HW, 
   return SERL_OK;
 }
 
-int sle_fwd(const float* x, const float* K, const uint8_t* mask, float keep_scale, float* f, int N, int HW,
-            int Cc, int groups, long x_gs, long k_gs, long mask_gs, long f_gs, hipStream_t stream) {
-  const SleFwdArgs v{x, K, mask, f};
-  return sle_fwd_multi(&v, 1, keep_scale, N, HW, Cc, groups, x_gs, k_gs, mask_gs, f_gs, stream);
-}
 
 // dK partial[split][hw][c][j] = sum_{n in split} x[n][hw][c] * df[n][c*8+j]
 __global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const float* df, float* partial, int N,
@@ -532,40 +526,6 @@ int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int 
             long x_gs, long df_gs, long part_gs, hipStream_t stream) {
   hipLaunchKernelGGL(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit * groups), dim3(256), 0, stream, x, df, partial, N,
                      HW, Cc, nsplit, x_gs, df_gs, part_gs);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
-// =============================================================================================
-// critic head (actor_critic_nets.py:65-73; shared Dense(1) over the ensemble, drq.py:201-207)
-// =============================================================================================
-__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float* w, const float* b, float* q,
-                                                    int rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float4 hv = *reinterpret_cast<const float4*>(h + (long)row * 256 + lane * 4);
-  const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
-  float s = hv.x * wv.x + hv.y * wv.y + hv.z * wv.z + hv.w * wv.w;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
-  if (lane == 0) q[row] = s + b[0];
-}
-
-int critic_head_fwd(const float* h, const float* w, const float* b, float* q, int rows, hipStream_t stream) {
-  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, h, w, b, q, rows);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
-// dh[r][j] = dq[r]*w[j]
-__global__ void outer_kernel(const float* dq, const float* w, float* dh, int rows) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long)rows * 256) return;
-  dh[e] = dq[e >> 8] * w[e & 255];
-}
-
-int critic_head_bwd_input(const float* dq, const float* w, float* dh, int rows, hipStream_t stream) {
-  hipLaunchKernelGGL(outer_kernel, dim3(cdiv((long)rows * 256, 256)), dim3(256), 0, stream, dq, w, dh, rows);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -690,12 +650,6 @@ int policy_dist_fwd_multi(const PolicyDistArgs* vs, int n, int B, int A, float s
   return SERL_OK;
 }
 
-int policy_dist_fwd(const float* slabs, const float* bias_mean, const float* bias_ls, float* pre, const float* eps,
-                    int B, int A, float std_min, float std_max, float* act, long ld_act, float* logp, float* std_out,
-                    float* sum_logp, hipStream_t stream) {
-  const PolicyDistArgs v{slabs, bias_mean, bias_ls, pre, eps, act, ld_act, logp, std_out, sum_logp, nullptr, nullptr};
-  return policy_dist_fwd_multi(&v, 1, B, A, std_min, std_max, stream);
-}
 
 // proprio branch (encoding.py:55-70): y = tanh(LayerNorm_1e-6(state W + b)), W [S][64]; one wave per row,
 // lane = output feature.  Replaces a GEMM + LN launch pair for this tiny layer.
@@ -729,12 +683,6 @@ int proprio_fwd_multi(const ProprioArgs* vs, int n, int S, int rows, hipStream_t
   return SERL_OK;
 }
 
-int proprio_fwd(const float* state, int S, const float* W, const float* b, const float* gamma, const float* beta,
-                int rows, float* y, long ld_y, float* xhat, float* rstd, hipStream_t stream) {
-  ProprioArgs v{};
-  v.state = state; v.W = W; v.b = b; v.gamma = gamma; v.beta = beta; v.y = y; v.ld_y = ld_y; v.xhat = xhat; v.rstd = rstd;
-  return proprio_fwd_multi(&v, 1, S, rows, stream);
-}
 
 // backward of the actor loss through the distribution:
 //   G_u = dL/da*(1-a^2) + c_lp*2a   (d logp/du = 2 tanh u);  dmean = G_u;
@@ -767,19 +715,6 @@ int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, 
 }
 
 // small helpers ---------------------------------------------------------------------------------
-__global__ void copy_cols_kernel(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= rows * cols) return;
-  const int r = e / cols, c = e - r * cols;
-  dst[(long)r * ld_dst + c] = src[(long)r * ld_src + c];
-}
-int copy_cols(const float* src, long ld_src, float* dst, long ld_dst, int rows, int cols, hipStream_t stream) {
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, stream, src, ld_src, dst,
-                     ld_dst, rows, cols);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
 __global__ void copy_cols_multi_kernel(Multi<CopyJob> mv, int rows) {
   const CopyJob& j = mv.v[blockIdx.y];
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -803,14 +738,6 @@ __global__ void fill_kernel(float* p, float v, long n) {
 }
 int fill(float* p, float v, long n, hipStream_t stream) {
   hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, v, n);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
-// alpha = softplus(lambda) (lagrange.py:49-50);  scalars[slot] = alpha
-__global__ void alpha_kernel(const float* lam, float* out) { out[0] = softplusf(lam[0]); }
-int temperature_alpha(const float* lam, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(1), 0, stream, lam, out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -910,16 +837,6 @@ int adam_ema(const AdamArgs& a, hipStream_t stream) {
   return SERL_OK;
 }
 
-__global__ void ema_kernel(const float* p, float* tp, float tau, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) tp[i] = p[i] * tau + tp[i] * (1.f - tau);
-}
-int ema(const float* p, float* tp, float tau, long n, hipStream_t stream) {
-  hipLaunchKernelGGL(ema_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, tp, tau, n);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
 // =============================================================================================
 // device noise (production mode): counter-based hash -> N(0,1) and Bernoulli(keep) masks
 // =============================================================================================
@@ -959,13 +876,4 @@ int gen_noise_multi(const NoiseJob* vs, int n, hipStream_t stream) {
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
-int gen_normal(float* out, long n, uint64_t seed, hipStream_t stream) {
-  const NoiseJob j{out, n, seed, 0, 0.f, 0, 0, 0, 1};
-  return gen_noise_multi(&j, 1, stream);
-}
-int gen_mask(uint8_t* out, long n, uint64_t seed, float keep, hipStream_t stream) {
-  const NoiseJob j{out, n, seed, 1, keep, 0, 0, 0, 1};
-  return gen_noise_multi(&j, 1, stream);
-}
-
 }  // namespace serl
