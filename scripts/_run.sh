@@ -1,2 +1,8 @@
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/t.log 2>&1; echo rc=$? >> gpurun_out/t.log; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" gpurun_out/t.log | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+mkdir -p gpurun_out/ab
+run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
+import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ab/$tag.err; }
+for b in 256 512 1024 4096; do
+export SERL_GEMM_BLOCKS=$b
+run e8_b$b timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8
+run n1_b$b timeout 200 python bench.py --no-cpu-baseline --steps 60
+done

@@ -339,7 +339,7 @@ size_t carve(serl_agent* a, void* base) {
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
 int split_for(int M, int N, int groups, int smax) {
-  static const int budget = []() { const char* e = getenv("SERL_GEMM_BLOCKS"); return e ? std::max(atoi(e), 1) : 256; }();
+  static const int budget = []() { const char* e = getenv("SERL_GEMM_BLOCKS"); return e ? std::max(atoi(e), 1) : 512; }();
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
