@@ -484,8 +484,8 @@ int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStrea
     g.A = pb.m.h2; g.sAm = Hd; g.sAk = 1; g.sAb = 0;
     g.B = P + o.a_Wm; g.sBk = A; g.sBn = 1; g.sBb = o.a_Ws - o.a_Wm;
     g.C = a->slabs_lane[i]; g.ldc = A; g.sCz = (long)cnt * A;
-    g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 1;
-    pv[i] = PolicyDistArgs{a->slabs_lane[i], P + o.a_bm, P + o.a_bs, pb.pre, j.eps, j.act_out, j.ld_act, pb.logp, pb.std,
+    g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 4;
+    pv[i] = PolicyDistArgs{a->slabs_lane[i], 4, P + o.a_bm, P + o.a_bs, pb.pre, j.eps, j.act_out, j.ld_act, pb.logp, pb.std,
                            j.sum_logp, P + o.lam, j.alpha_out};
   }
   RC(dense_ln_tanh_multi(a, d1, n, 1, cnt, a->E, 8, st));

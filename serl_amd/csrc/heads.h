@@ -61,7 +61,8 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
                 hipStream_t stream, bool per_member_bias = false);
 // tanh-Gaussian policy head: slabs = raw head GEMM outputs (mean, log_std); biases added here, result kept in `pre`
 struct PolicyDistArgs {
-  const float* slabs; const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
+  const float* slabs; int S;  // head GEMM output [mean | log_std][S K-splits][B][A]
+  const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
   float* act; long ld_act; float* logp; float* std_out; float* sum_logp;
   const float* lam; float* alpha_out;  // optional rider: alpha_out[0] = softplus(lam[0])
 };

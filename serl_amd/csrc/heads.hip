@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void sle_fwd_kernel(Multi<SleFwdArgs> mv, floa
   const uint8_t* mask = v.mask ? v.mask + blockIdx.y * ms : nullptr;
   const int n = (int)(e / Cc), c = (int)(e - (long)n * Cc);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
   for (int hw = 0; hw < HW; ++hw) {
     const float xv = x[((long)n * HW + hw) * Cc + c];
     const float4 k0 = *reinterpret_cast<const float4*>(K + ((long)hw * Cc + c) * 8);
@@ -617,7 +618,11 @@ __global__ void policy_dist_fwd_kernel(Multi<PolicyDistArgs> mv, int B, int A, f
   for (int b = threadIdx.x; b < B; b += 256) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) {
-      const float mean = v.slabs[(long)b * A + j] + v.bias_mean[j], ls = v.slabs[((long)B + b) * A + j] + v.bias_ls[j];
+      float mean = v.bias_mean[j], ls = v.bias_ls[j];
+      for (int sp = 0; sp < v.S; ++sp) {  // K-split slabs of the head GEMM: [mean | log_std][split][B][A]
+        mean += v.slabs[((long)sp * B + b) * A + j];
+        ls += v.slabs[(((long)v.S + sp) * B + b) * A + j];
+      }
       const float e = v.eps[(long)b * A + j];
       v.pre[(long)b * A + j] = mean;
       v.pre[((long)B + b) * A + j] = ls;
@@ -658,7 +663,19 @@ __global__ __launch_bounds__(256) void proprio_fwd_kernel(Multi<ProprioArgs> mv,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   float v = a.b[lane];
-  for (int s = 0; s < S; ++s) v += a.state[(long)row * S + s] * a.W[s * 64 + lane];
+  for (int s0 = 0; s0 < S; s0 += 64) {  // the state row travels once, coalesced, and is broadcast lane by lane
+    const float mine = (s0 + lane < S) ? a.state[(long)row * S + s0 + lane] : 0.f;
+    const int cnt = min(64, S - s0);
+    int s = 0;
+    for (; s + 8 <= cnt; s += 8) {
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = a.W[(s0 + s + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += __shfl(mine, s + j) * w[j];
+    }
+    for (; s < cnt; ++s) v += __shfl(mine, s) * a.W[(s0 + s) * 64 + lane];
+  }
   float s1 = v, s2 = v * v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
