@@ -35,6 +35,9 @@ class FakeCore:
     def phi(ids, dim):
         return np.stack([np.sin(ids * (k + 1) * 0.37) for k in range(dim)], axis=1)
 
+    def set_shard(self, global_offset, global_batch):   # device noise is indexed by the global sample id
+        self.shard = (global_offset, global_batch)
+
     def begin_update(self):
         pass
 
@@ -128,3 +131,17 @@ def test_two_rank_dp_matches_single_process():
     for x, y, z in zip(log0, log1, core.log):
         assert np.array_equal(x, y)
         assert np.allclose(x, z.numpy(), rtol=0, atol=1e-9)  # all-reduced sums == full-batch values
+
+
+def test_learner_declares_its_shard():
+    """A rank of a batch-sharded job tells the agent which global rows its batches hold (serl_agent_set_shard), so
+    that device-generated noise is a function of the global sample id; a single rank does not shard."""
+    from serl_amd.parallel import DataParallelLearner
+
+    class Buf:
+        def sample_indices(self, n):
+            return np.arange(n)
+    for world, rank in ((1, 0), (4, 2)):
+        core = FakeCore()
+        DataParallelLearner(core, lambda parts, co, cn, slot: None, [Buf()], [16], rank, world, all_reduce=lambda t: None)
+        assert getattr(core, "shard", None) == ((rank * 4, 16) if world > 1 else None)
