@@ -48,6 +48,11 @@ int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream);
 
 int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
            long out_gstride, bool accumulate, hipStream_t stream);
+struct Colsum3Args {
+  const float *dg, *xhat, *dpre; int groups, rows_per_group, D;
+  float *o_gamma, *o_beta, *o_bias; long gstride;
+};
+int colsum3_multi(const Colsum3Args* layers, int n, hipStream_t stream);
 int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
 struct SleFwdArgs { const float* x; const float* K; const uint8_t* mask; float* f; };

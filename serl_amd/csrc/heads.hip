@@ -419,42 +419,54 @@ int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D
 
 // fused parameter gradients of one Dense->LN->tanh layer (one pass over dg, xhat, dpre):
 //   dgamma[g][j] = sum_r dg*xhat,  dbeta[g][j] = sum_r dg,  dbias[g][j] = sum_r dpre
-__global__ __launch_bounds__(512) void colsum3_kernel(const float* dg, const float* xhat, const float* dpre,
-                                                     int rows_per_group, int D, float* o_gamma, float* o_beta,
-                                                     float* o_bias, long gstride) {
+__global__ __launch_bounds__(512) void colsum3_kernel(Multi<Colsum3Args> mv) {
+  const Colsum3Args& a = mv.v[blockIdx.z];  // blockIdx.z = layer
   __shared__ float red[3][8][64];
   const int grp = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  if (grp >= a.groups || (int)blockIdx.x * 64 >= a.D) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  if (col < D) {
-    const long base = (long)grp * rows_per_group;
-    for (int r = part; r < rows_per_group; r += 8) {
-      const long e = (base + r) * D + col;
-      const float g = dg[e];
-      s0 += g * xhat[e];
+  if (col < a.D) {
+    const long base = (long)grp * a.rows_per_group;
+    for (int r = part; r < a.rows_per_group; r += 8) {
+      const long e = (base + r) * a.D + col;
+      const float g = a.dg[e];
+      s0 += g * a.xhat[e];
       s1 += g;
-      s2 += dpre[e];
+      s2 += a.dpre[e];
     }
   }
   red[0][part][threadIdx.x & 63] = s0;
   red[1][part][threadIdx.x & 63] = s1;
   red[2][part][threadIdx.x & 63] = s2;
   __syncthreads();
-  if (part < 3 && col < D) {
+  if (part < 3 && col < a.D) {
     const int c = threadIdx.x & 63;
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[part][k][c];
-    float* o = (part == 0 ? o_gamma : (part == 1 ? o_beta : o_bias)) + (long)grp * gstride + col;
+    float* o = (part == 0 ? a.o_gamma : (part == 1 ? a.o_beta : a.o_bias)) + (long)grp * a.gstride + col;
     *o = t;
   }
 }
 
-int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
-            float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream) {
-  hipLaunchKernelGGL(colsum3_kernel, dim3(cdiv(D, 64), groups), dim3(512), 0, stream, dg, xhat, dpre,
-                     rows_per_group, D, o_gamma, o_beta, o_bias, gstride);
+int colsum3_multi(const Colsum3Args* vs, int n, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad layer count %d", n);
+  Multi<Colsum3Args> mv{};
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    mv.v[i] = vs[i];
+    gx = std::max(gx, cdiv(vs[i].D, 64));
+    gy = std::max(gy, vs[i].groups);
+  }
+  hipLaunchKernelGGL(colsum3_kernel, dim3(gx, gy, n), dim3(512), 0, stream, mv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
+}
+
+int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
+            float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream) {
+  const Colsum3Args v{dg, xhat, dpre, groups, rows_per_group, D, o_gamma, o_beta, o_bias, gstride};
+  return colsum3_multi(&v, 1, stream);
 }
 
 // =============================================================================================
