@@ -597,18 +597,20 @@ int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hip
     GemmDesc g{};
     g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = 0;
     g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = 0;
-    g.C = a->slabs; g.ldc = Hd; g.sCz = Hd;
-    g.M = 1; g.N = Hd; g.K = N * cnt; g.nbatch = 1; g.splitk = 8;
+    const bool direct = N * cnt <= 1024;  // short K: written in place, no K-split slabs to reduce
+    g.C = direct ? a->Gc + o.c_hw : a->slabs; g.ldc = Hd; g.sCz = Hd;
+    g.M = 1; g.N = Hd; g.K = N * cnt; g.nbatch = 1; g.splitk = direct ? 1 : 8;
     RC(gemm_f32(g, st));
-    RC(reduce_slabs(a->slabs, 8, Hd, 1, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, 0, false, st));
+    if (!direct) RC(reduce_slabs(a->slabs, 8, Hd, 1, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, 0, false, st));
   } else if (pg) {  // one head per member: dw[e][j] = sum_b dq[e][b]*h2[e][b][j]
     GemmDesc g{};
     g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = cnt;
     g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = (long)cnt * Hd;
-    g.C = a->slabs; g.ldc = Hd; g.sCz = Hd;
-    g.M = 1; g.N = Hd; g.K = cnt; g.nbatch = N; g.splitk = 4;
+    const bool direct = cnt <= 1024;
+    g.C = direct ? a->Gc + o.c_hw : a->slabs; g.ldc = Hd; g.sCz = Hd;
+    g.M = 1; g.N = Hd; g.K = cnt; g.nbatch = N; g.splitk = direct ? 1 : 4;
     RC(gemm_f32(g, st));
-    RC(reduce_slabs(a->slabs, 4, Hd, N, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, Hd, false, st));
+    if (!direct) RC(reduce_slabs(a->slabs, 4, Hd, N, 1, Hd, nullptr, 0, a->Gc + o.c_hw, Hd, Hd, false, st));
   }
   // gradient through the shared head dh2 = dq (x) w is formed inside the LN backward kernel (rank-1 mode)
   RC(dense_ln_tanh_bwd(a, nullptr, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
@@ -973,10 +975,10 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   RC(policy_fwd_multi(a, pj, 2, cnt, s0));
   const CritJob cj{a->theta, &a->crit};
   RC(critic_fwd_multi(a, &cj, 1, cnt, s0));
-  RC(qmean_sum(a->crit.q, c.ensemble, cnt, a->SC + S_QPI, s0));
   RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0, nullptr, -1.0f / ((float)c.ensemble * (float)global_count)));
   RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
-                     1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, s0));
+                     1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, a->crit.q, c.ensemble,
+                     a->SC + S_QPI, s0));
   // policy heads (mean, log_std): nbatch = 2 with uniform stride; parameter gradients off the critical chain
   const long hs = o.a_Ws - o.a_Wm;
   float* Ga = a->Ga;

@@ -81,11 +81,11 @@ struct ProprioArgs {
 int proprio_fwd_multi(const ProprioArgs* v, int n, int S, int rows, hipStream_t stream);
 int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
-                    float std_min, float std_max, float* dpre, hipStream_t stream);
+                    float std_min, float std_max, float* dpre, const float* q, int E, float* qmean_out,
+                    hipStream_t stream);  // rider: qmean_out[0] = sum_b mean_e q[e][b]
 struct CopyJob { const float* src; long ld_src; float* dst; long ld_dst; int cols; };
 int copy_cols_multi(const CopyJob* jobs, int n, int rows, hipStream_t stream);
 int fill(float* p, float v, long n, hipStream_t stream);
-int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream);
 
 struct AdamArgs {
   float *theta, *theta_target;

@@ -720,7 +720,24 @@ int proprio_fwd_multi(const ProprioArgs* vs, int n, int S, int rows, hipStream_t
 __global__ void policy_dist_bwd_kernel(const float* da, long ld_da, const float* act, long ld_act,
                                        const float* pre, const float* stdv, const float* eps,
                                        const float* alpha, float coef, int B, int A, float std_min,
-                                       float std_max, float* dpre) {
+                                       float std_max, float* dpre, const float* q, int E, float* qmean_out) {
+  if (blockIdx.x == gridDim.x - 1) {  // rider (one extra workgroup): sum_b mean_e Q[e][b], the actor-loss info scalar
+    __shared__ float red[256];
+    float sacc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      float m = 0.f;
+      for (int e = 0; e < E; ++e) m += q[(long)e * B + b];
+      sacc += m / (float)E;
+    }
+    red[threadIdx.x] = sacc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) qmean_out[0] = red[0];
+    return;
+  }
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= B * A) return;
   const int b = e / A, j = e - b * A;
@@ -736,9 +753,10 @@ __global__ void policy_dist_bwd_kernel(const float* da, long ld_da, const float*
 
 int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, const float* pre,
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
-                    float std_min, float std_max, float* dpre, hipStream_t stream) {
-  hipLaunchKernelGGL(policy_dist_bwd_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, stream, da, ld_da, act,
-                     ld_act, pre, stdv, eps, alpha, coef, B, A, std_min, std_max, dpre);
+                    float std_min, float std_max, float* dpre, const float* q, int E, float* qmean_out,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(policy_dist_bwd_kernel, dim3(cdiv(B * A, 256) + 1), dim3(256), 0, stream, da, ld_da, act,
+                     ld_act, pre, stdv, eps, alpha, coef, B, A, std_min, std_max, dpre, q, E, qmean_out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -767,29 +785,6 @@ __global__ void fill_kernel(float* p, float v, long n) {
 }
 int fill(float* p, float v, long n, hipStream_t stream) {
   hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, v, n);
-  SERL_HIP(hipGetLastError());
-  return SERL_OK;
-}
-
-// sum over rows of the ensemble-mean Q (actor loss info): scalars[out] = sum_b mean_e q[e][b]
-__global__ __launch_bounds__(256) void qmean_sum_kernel(const float* q, int E, int B, float* out) {
-  __shared__ float red[256];
-  float s = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    float m = 0.f;
-    for (int e = 0; e < E; ++e) m += q[(long)e * B + b];
-    s += m / (float)E;
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = red[0];
-}
-int qmean_sum(const float* q, int E, int B, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(qmean_sum_kernel, dim3(1), dim3(256), 0, stream, q, E, B, out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
