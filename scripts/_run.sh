@@ -1,9 +1,5 @@
-mkdir -p gpurun_out/ab
-timeout 900 python -m pytest tests/test_agent_gpu.py tests/test_sac_state_gpu.py -x -q > gpurun_out/t.log 2>&1; echo rc=$? >> gpurun_out/t.log; grep -v "^RCCL\|^HIP \|^ROCm\|^Hostname\|^Librccl" gpurun_out/t.log | tail -3
-run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
-import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ab/$tag.err; }
-P=$GRAFT_REPO_ROOT/serl_amd/lib/libserl_prev.so
-for rep in 1 2; do
-run e8_new$rep timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8
-SERL_MI355_LIB=$P run e8_prev$rep timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world 8
-done
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/tl8
+cd /tmp && export TMPDIR=/tmp
+SERL_BENCH_NOPROF=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl8 -o t -- python $R/bench.py --no-cpu-baseline --fill 3000 --steps 12 --warmup 4 --emulate-world 8 > $R/gpurun_out/tl8.log 2>&1
+cd $R; python scripts/timeline_streams.py gpurun_out/tl8 > gpurun_out/tl8.txt 2>&1
+find gpurun_out/tl8 -name "*.csv" -size +20M -delete

@@ -31,7 +31,7 @@ if sac:
     rows += f"| `r01_sac_state.json` | side measurement of BASELINE.json configs[0] `async_sac_state_sim` (state-only SAC, 2048 = 256 x UTD 8 per iteration, plain replay buffer in HBM): {sac['critic_grad_steps_per_s']} critic grad-steps/s ({sac['ms_per_iteration']} ms per iteration of 8 critic + 1 actor/temperature updates) vs {sac['cpu_port']['critic_grad_steps_per_s']} on {sac['cpu_port']['cores']} CPU cores (oracle port) -> {sac['speedup']}x; latency-bound (small MLPs: ~8 us per dependent kernel) | `python bench.py --workload sac_state --steps 200` |\n"
 rows += f"""| `r01_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` per-kernel summary of the bench workload (pipelined, so the update chain's small kernels co-run with trunk kernels and are stretched; `__amd_rocclr_copyBuffer` = replay inserts of the fill phase); agrees with the live HIP events of `r01_bench.json` within the profiler's overhead | `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --fill 3000 --steps 30 --warmup 5` + `scripts/rocprof_summary.py` |
 | `pmc_traffic.json` | HBM traffic per launch from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, serial schedule, `scripts/pmc_to_json.py`; FETCH doubled per the gfx950 note). conv family: {pm['conv_igemm_f16x3_bytes_per_launch']/1e6:.0f} MB per launch (fetch {pm['conv_igemm_f16x3_fetch_bytes_per_launch']/1e6:.0f} MB, write {pm['conv_igemm_f16x3_write_bytes_per_launch']/1e6:.0f} MB); gather_crop {pm['gather_crop_bytes_per_launch']/1e6:.1f} MB measured vs 100.72 MB algorithmic (no wasted re-reads); conv_init {pm['conv_init_f16x3_bytes_per_launch']/1e6:.0f} MB and pool stage {pm['gn_relu_maxpool_bytes_per_launch']/1e6:.0f} MB per pass with the fused pool (1199 MB and 1888 MB before it) | `scripts/collect_evidence.sh` |
-| `r01_timeline_emulate_world8.txt` | per-stream kernel timeline of one step at B/8 (`scripts/timeline_streams.py` on a kernel trace): trunk stream 0.60 ms busy in 26 kernels, update stream 0.62 ms busy in 75 kernels | |
+| `r01_timeline_emulate_world8.txt` | per-stream kernel timeline of one step at B/8 (`scripts/timeline_streams.py` on a kernel trace): trunk stream 0.62 ms busy in 24 kernels, update stream 0.56 ms busy in 62 kernels (the trace itself makes the host the bottleneck: 1.02 ms per step under rocprofv3 vs 0.75 ms without) | |
 """
 p = os.path.join(P, "README.md")
 s = open(p).read()
