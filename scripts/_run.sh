@@ -1,5 +1,8 @@
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/tl8
-cd /tmp && export TMPDIR=/tmp
-SERL_BENCH_NOPROF=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl8 -o t -- python $R/bench.py --no-cpu-baseline --fill 3000 --steps 12 --warmup 4 --emulate-world 8 > $R/gpurun_out/tl8.log 2>&1
-cd $R; python scripts/timeline_streams.py gpurun_out/tl8 > gpurun_out/tl8.txt 2>&1
-find gpurun_out/tl8 -name "*.csv" -size +20M -delete
+mkdir -p gpurun_out/ab
+run() { tag=$1; shift; "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err; python -c "
+import json;d=json.loads(open('gpurun_out/ab/$tag.json').read().strip().splitlines()[-1]);print('$tag', d['value'], d['ms_per_step'])" || tail -3 gpurun_out/ab/$tag.err; }
+for w in 8 4 2; do
+run mid${w}_512 timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world $w
+SERL_CONV_MID_MIN=0 run mid${w}_off timeout 200 python bench.py --no-cpu-baseline --steps 100 --emulate-world $w
+done
+timeout 300 python -m pytest tests/test_agent_gpu.py -x -q -k "trunk_forward or full_size or dp_split" 2>&1 | tail -2

@@ -922,6 +922,10 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   ab.whi = w.hi; ab.wlo = w.lo; ab.K = ksz * ksz * Cin;
   int cfg = Cout >= 128 ? 0 : 1;
   if (cfg == 0 && (long)cdiv(a.M, 128) * (Cout / 128) < 512) cfg = 2;
+  // in between: 128x64 tiles (waves of 64x32) with three chunks in flight when there are enough of them
+  // (measured per layer at B/2, B/4, B/8: faster than 64x64 from 512 such workgroups up, slower below)
+  static const long mid_min = []() { const char* e = getenv("SERL_CONV_MID_MIN"); return e ? atol(e) : 512L; }();
+  if (cfg == 2 && mid_min > 0 && (long)cdiv(a.M, 128) * (Cout / 64) >= mid_min) cfg = 4;
   const int BM = cfg == 2 ? 64 : (cfg == 1 ? 256 : 128), BN = cfg == 0 ? 128 : 64;
   const int wrows = cfg == 2 ? 32 : 64;
   a.tiles_m = cdiv(a.M, BM); a.tiles_n = Cout / BN;
@@ -947,7 +951,12 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
                          stream, ab);
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
-    else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
+    else if (cfg == 4) {
+      if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 0, 3>), grid, block, lds, stream, ab);
+      else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 1, 3>), grid, block, lds, stream, ab);
+      else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 2, 3>), grid, block, lds, stream, ab);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 3, 3>), grid, block, lds, stream, ab);
+    } else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
       static const int deep = []() { const char* e = getenv("SERL_CONV_DEEP"); return e ? atoi(e) : 3; }();
 #define SERL_LAUNCH_DEEP(D)                                                                                                      \
   do {                                                                                                                           \
