@@ -255,17 +255,18 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     # the JSON line must be the last thing on stdout: librccl prints its version banner through C stdio, which is
-    # block-buffered when stdout is a pipe/file and would otherwise surface after this line at exit
+    # block-buffered when stdout is a pipe/file and would otherwise surface after this line at exit -- every rank
+    # flushes before the final barrier, rank 0 prints after it
     sys.stdout.flush()
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
 
