@@ -101,6 +101,12 @@ class DrQAgent:
         self._batch: Optional[DeviceBatch] = None
         self._update_serial = 0
         self.state = TrainStateView(self)
+        # transparent software pipelining for batches that come from `get_iterator(..., lazy=True)`: the iterator has
+        # already sampled the NEXT batch, so its gather + crop + frozen trunk run on a second stream under this update
+        self.prefetch = True
+        self._sched = None
+        self._slot_batches = [None, None]
+        self._prefetched = None   # (key of the lazy batch, slot)
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -218,20 +224,97 @@ class DrQAgent:
         out._keep = keep
         return out
 
+    # ------------------------------------------------------------------ pipelined acquisition of lazy batches
+    @staticmethod
+    def _lazy_key(batch: LazyBatch):
+        return tuple((id(b), id(ix)) for b, ix in batch.parts)
+
+    def _can_prefetch(self, batch, crops):
+        return (self.prefetch and crops is None and isinstance(batch, LazyBatch) and self.core.cfg.n_cam > 0
+                and batch.batch_size <= self.core.cfg.batch)
+
+    def _slot_batch(self, slot, B):
+        c = self.core.cfg
+        if self._slot_batches[slot] is None or self._slot_batches[slot].batch != B:
+            self._slot_batches[slot] = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
+        return self._slot_batches[slot]
+
+    def _produce(self, batch: LazyBatch, slot, db):
+        """gather + crop on the caller's stream (tens of microseconds: an actor-side insert never waits long for an
+        in-flight gather), frozen trunk on the side stream."""
+        sch, torch_ = self._sched, torch
+        co, cn = self._draw_crops(db.batch)
+        gather_crop(batch.parts, co, cn, db)
+        ev = torch_.cuda.Event()
+        ev.record(torch_.cuda.current_stream(self.core.device))
+        sch.side_stream.wait_event(ev)
+        sch.wait_consumed(slot)
+        with sch.side():
+            self.core.encode_slot(db, slot)
+        sch.produced(slot)
+
+    def _acquire(self, batch: LazyBatch):
+        """-> (slot, DeviceBatch) with the frozen-trunk features of `batch` ready in `slot` (prefetched during the
+        previous update, or encoded now), and starts the same work for the iterator's next batch on the side stream."""
+        from ..parallel import TorchPipelineSchedule
+        if self._sched is None:
+            self._sched = TorchPipelineSchedule(self.core.device, prioritise_update=False)
+        sch, B = self._sched, batch.batch_size
+        key = self._lazy_key(batch)
+        if self._prefetched is not None and self._prefetched[0] == key:
+            slot = self._prefetched[1]
+            sch.wait_produced(slot)
+            db = self._slot_batches[slot]
+        else:
+            # not prefetched (first call, or the caller skipped a batch).  All trunk work goes through the side stream,
+            # in order: the two feature slots share one trunk workspace.
+            slot = 0 if self._prefetched is None else 1 - self._prefetched[1]
+            db = self._slot_batch(slot, B)
+            self._produce(batch, slot, db)
+            sch.wait_produced(slot)
+        self._prefetched = None
+        nxt = batch.peek_next() if batch.peek_next is not None else None
+        if nxt is not None and nxt.batch_size == B:
+            s2 = 1 - slot
+            self._produce(nxt, s2, self._slot_batch(s2, B))
+            self._prefetched = (self._lazy_key(nxt), s2)
+        self.core.select_slot(slot)
+        return slot, db
+
     # ------------------------------------------------------------------ updates
     def update_critics(self, batch, *, pmap_axis: Optional[str] = None, noise=None, crops=None):
         """drq.py:296-328."""
-        db = self.prepare(batch, crops)
-        self.core.update_critics(db, noise)
+        if self._can_prefetch(batch, crops):
+            slot, db = self._acquire(batch)
+            self.core.begin_update()
+            self.core.critic_grads(0, db.batch, db.batch, noise)
+            self.core.apply(APPLY_CRITIC)
+            self._sched.consumed(slot)
+        else:
+            db = self.prepare(batch, crops)
+            self.core.update_critics(db, noise)
         self._update_serial += 1
         return self, PendingInfo(self, "critics", self._update_serial)
 
     def update_high_utd(self, batch, *, utd_ratio: int, pmap_axis: Optional[str] = None, noise=None, crops=None):
         """drq.py:255-294 -> sac.py:544-596."""
-        db = self.prepare(batch, crops)
-        assert db.batch % utd_ratio == 0, \
-            f"Batch size {db.batch} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
-        self.core.update_high_utd(db, utd_ratio, noise)
+        if self._can_prefetch(batch, crops):
+            B = batch.batch_size
+            assert B % utd_ratio == 0, f"Batch size {B} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
+            slot, db = self._acquire(batch)
+            mb = B // utd_ratio
+            self.core.begin_update()
+            for i in range(utd_ratio):
+                self.core.critic_grads(i * mb, mb, mb, noise, i)
+                self.core.apply(APPLY_CRITIC, 1.0 / utd_ratio)
+            self.core.actor_grads(B, noise)
+            self.core.apply(APPLY_ACTOR_TEMP)
+            self._sched.consumed(slot)
+        else:
+            db = self.prepare(batch, crops)
+            assert db.batch % utd_ratio == 0, \
+                f"Batch size {db.batch} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
+            self.core.update_high_utd(db, utd_ratio, noise)
         self._update_serial += 1
         return self, PendingInfo(self, "high_utd", self._update_serial)
 

@@ -33,8 +33,12 @@ class LazyBatch:
     kernel (serl_rb_gather_crop).  `materialize()` gives the reference's packed dict instead.
     """
 
-    def __init__(self, parts):
+    def __init__(self, parts, peek_next=None):
         self.parts = list(parts)  # [(buffer, np.int64[n])]
+        # peek_next() -> the LazyBatch the iterator will yield next (already sampled by its prefetch queue), or None.
+        # The agent uses it to run gather + crop + frozen trunk of the NEXT batch on a second stream under the update
+        # of this one (the reference's iterator prefetches two batches to the device for the same reason).
+        self.peek_next = peek_next
 
     @property
     def batch_size(self):
@@ -48,13 +52,29 @@ class LazyBatch:
         return out
 
 
+def _after(queue, me):
+    """The batch the iterator yields after `me` if it is already in the prefetch queue."""
+    return queue[0] if queue and queue[0] is not me else (queue[1] if len(queue) > 1 and queue[0] is me else None)
+
+
 def concat_batches(offline_batch, online_batch, axis=1):
     """train_utils.py:16-31 (first argument first).  Works on dict batches of torch tensors and
     on LazyBatch (axis must be 0 there)."""
     if isinstance(offline_batch, LazyBatch) or isinstance(online_batch, LazyBatch):
         assert isinstance(offline_batch, LazyBatch) and isinstance(online_batch, LazyBatch)
         assert axis == 0, "lazy batches concatenate along the batch axis only"
-        return LazyBatch(offline_batch.parts + online_batch.parts)
+        a, b = offline_batch, online_batch
+
+        def peek():
+            if a.peek_next is None or b.peek_next is None:
+                return None
+            na, nb = a.peek_next(), b.peek_next()
+            if na is None or nb is None:
+                return None
+            if getattr(peek, "_cache", (None, None, None))[:2] != (id(na), id(nb)):
+                peek._cache = (id(na), id(nb), concat_batches(na, nb, axis=0))
+            return peek._cache[2]
+        return LazyBatch(a.parts + b.parts, peek)
     batch = {}
     for k, v in offline_batch.items():
         if isinstance(v, dict):
@@ -213,7 +233,10 @@ class MemoryEfficientReplayBufferDataStore:
 
         def enqueue(n):
             for _ in range(n):
-                queue.append(self.sample(**sample_args))
+                b = self.sample(**sample_args)
+                if isinstance(b, LazyBatch):
+                    b.peek_next = lambda me=b: _after(queue, me)
+                queue.append(b)
 
         enqueue(queue_size)
         while queue:

@@ -133,3 +133,42 @@ def test_checkpoint_roundtrip(gpu, tmp_path):
     for sec, leaf in (("opt/critic/mu", "critic/w2"), ("opt/actor/nu", "actor/w1"), ("opt/temperature/mu", "temp/lagrange"),
                       ("opt/critic/nu", "enc/proprio/dense/kernel"), ("opt/actor/mu", "enc/proprio/dense/kernel")):
         assert np.array_equal(fresh.core.get(sec, leaf), agent.core.get(sec, leaf)), (sec, leaf)
+
+
+def test_iterator_prefetch_is_transparent(gpu):
+    """Lazy batches from get_iterator let the agent run gather + crop + trunk of the NEXT batch on a second stream
+    under the current update; the results are bit-identical to the unpipelined agent (same crop / noise streams)."""
+    from serl_amd.utils.launcher import make_replay_buffer
+    from serl_amd.utils.synthetic import transition_stream
+    from serl_amd.utils.train_utils import concat_batches
+
+    def run(prefetch):
+        env, rb, agent = _setup(B=16)
+        demo = make_replay_buffer(env, capacity=100, type="memory_efficient_replay_buffer", image_keys=KEYS)
+        demo.seed(1)
+        for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 10, 9), 40):
+            demo.insert(tr)
+        agent.prefetch = prefetch
+        args = {"batch_size": 8, "pack_obs_and_next_obs": True, "lazy": True}
+        it, dit = rb.get_iterator(sample_args=args), demo.get_iterator(sample_args=args)
+        infos = []
+        for step in range(4):
+            agent, _ = agent.update_critics(concat_batches(next(it), next(dit), axis=0))
+            agent, info = agent.update_high_utd(concat_batches(next(it), next(dit), axis=0), utd_ratio=2)
+            infos.append(info.resolve())
+        used = agent._prefetched is not None
+        return agent, infos, used
+
+    a0, i0, used0 = run(False)
+    a1, i1, used1 = run(True)
+    assert used1 and not used0
+    for leaf in ("critic/w1", "critic/head/kernel", "actor/w2", "enc/0/dense/kernel", "enc/proprio/dense/kernel", "temp/lagrange"):
+        assert np.array_equal(a0.core.get("params", leaf), a1.core.get("params", leaf)), leaf
+    assert i0[-1]["critic"] == i1[-1]["critic"] and i0[-1]["actor"] == i1[-1]["actor"]
+    # a caller that skips a batch just loses the prefetch (the crop stream then differs from the unpipelined agent's)
+    env, rb, agent = _setup(B=16)
+    it = rb.get_iterator(sample_args={"batch_size": 16, "pack_obs_and_next_obs": True, "lazy": True})
+    agent.update_critics(next(it))
+    next(it)
+    _, info = agent.update_high_utd(next(it), utd_ratio=1)
+    assert all(np.isfinite(v) for v in info.resolve()["critic"].values()) and agent.state.step == 3
