@@ -77,3 +77,28 @@ def test_checkpoint_file_format(tmp_path):
     k = raw["params"]["modules_actor"]["Dense_1"]["kernel"]
     assert k.dtype == np.float32 and k.shape == (2, 3) and np.array_equal(k, tree["modules_actor"]["Dense_1"]["kernel"])
     assert raw["rng"].dtype == np.uint32 and int(raw["step"]) == 7
+
+
+def test_lazy_batches_know_the_next_batch():
+    """get_iterator's prefetch queue already holds the next sample: lazy batches expose it (peek_next) through
+    concat_batches, which is what lets the agent run the next batch's trunk under the current update."""
+    from serl_amd.data.data_store import MemoryEfficientReplayBufferDataStore as Store
+
+    class Fake:
+        def __init__(self, base):
+            self.n = base
+        def sample(self, **kw):
+            self.n += 1
+            return LazyBatch([(self, np.array([self.n]))])
+        get_iterator = Store.get_iterator
+
+    a, b = Fake(0), Fake(100)
+    ia, ib = a.get_iterator(sample_args={}), b.get_iterator(sample_args={})
+    cur = concat_batches(next(ia), next(ib), axis=0)
+    assert [int(ix[0]) for _, ix in cur.parts] == [1, 101]
+    nxt = cur.peek_next()
+    assert [int(ix[0]) for _, ix in nxt.parts] == [2, 102] and cur.peek_next() is nxt
+    cur2 = concat_batches(next(ia), next(ib), axis=0)
+    assert all(p1[1] is p2[1] for p1, p2 in zip(cur2.parts, nxt.parts))      # the very same index arrays
+    assert [int(ix[0]) for _, ix in cur2.peek_next().parts] == [3, 103]
+    assert LazyBatch([(a, np.array([1]))]).peek_next is None                 # plain sample(): nothing to peek
