@@ -25,7 +25,7 @@ threefry / flax rng folding is not reproduced.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch

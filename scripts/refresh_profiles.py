@@ -1,6 +1,6 @@
 """Copies gpurun_out/evidence (scripts/collect_evidence.sh) into profiles/ and rewrites the 'final state' table of
 profiles/README.md from the JSON files (the history / rejected-experiments sections are kept as they are)."""
-import json, os, shutil, sys
+import json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(R, "gpurun_out", "evidence")
 P = os.path.join(R, "profiles")

@@ -11,7 +11,7 @@ All numerics run in HIP kernels; there is no CPU fallback.
 """
 from __future__ import annotations
 
-from typing import Dict, FrozenSet, Iterable, Optional, Tuple
+from typing import Dict, FrozenSet, Iterable, Optional
 
 import numpy as np
 import torch

@@ -116,7 +116,6 @@ def test_plain_store_matches_reference_golden(gpu, name):
 
 def test_sac_learner_loop(gpu, tmp_path):
     """examples/async_sac_state_sim/async_sac_state_sim.py:280-300: iterator -> update_high_utd(utd_ratio=8)."""
-    from serl_amd.agents.batch import DeviceBatch
     from serl_amd.utils.checkpoint import restore_checkpoint, save_checkpoint
     from serl_amd.utils.launcher import make_replay_buffer, make_sac_agent
     from serl_amd.utils.synthetic import flat_stream
