@@ -2,6 +2,8 @@
 import ctypes
 import os
 
+import pytest
+
 
 def test_library_exports_header_symbols():
     import __graft_entry__ as ge
@@ -26,3 +28,19 @@ def test_product_path_has_no_oracle_import():
                 if "import oracle" in txt or "from oracle" in txt:
                     bad.append(f)
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_plain_c_client_of_the_abi(gpu, tmp_path):
+    """tests/c_abi_smoke.c is C99 and includes nothing but the HIP runtime API and include/serl_mi355.h: it builds a
+    state-only SAC learner (replay buffer in HBM -> fused gather -> update_high_utd) through the C ABI alone."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(root, "serl_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", os.path.join(root, "tests", "c_abi_smoke.c"), "-I" + os.path.join(root, "include"),
+                           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + libdir, "-lserl_mi355", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "C ABI OK" in out.stdout, (out.stdout, out.stderr)
