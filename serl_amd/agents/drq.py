@@ -90,6 +90,18 @@ class TrainStateView:
     def rng(self):
         return self._a._rng_key.copy()
 
+    def replace(self, **kw):
+        """JaxRLTrainState.replace(params=..., target_params=..., opt_states=..., step=...): loads the given trees
+        into HBM (in place) and returns the view."""
+        bad = set(kw) - {"params", "target_params", "opt_states", "step", "rng"}
+        if bad:
+            raise TypeError(f"unknown TrainState fields: {sorted(bad)}")
+        from ..utils.checkpoint import load_state_dict
+        load_state_dict(self._a, {k: v for k, v in kw.items() if k != "rng"})
+        if kw.get("rng") is not None:
+            self._a._rng_key = np.asarray(kw["rng"], np.uint32).copy()
+        return self
+
 
 class DrQAgent:
     def __init__(self, core: AgentCore, image_keys, config: dict, seed: int):
@@ -168,9 +180,17 @@ class DrQAgent:
             self.core.load_flat(sec, flat)
         return self
 
-    def replace(self, **kw):  # agent.replace(state=...) in the reference; state is device-resident here
+    def replace(self, **kw):
+        """agent.replace(state=...) of the reference (e.g. `agent.replace(state=restored_ckpt)`).  The state is
+        device-resident here: a flax-layout dict (or this agent's own state view) is loaded into HBM in place."""
         if kw and set(kw) - {"state"}:
             raise NotImplementedError(list(kw))
+        st = kw.get("state")
+        if isinstance(st, dict):
+            from ..utils.checkpoint import load_state_dict
+            load_state_dict(self, st)
+        elif st is not None and st is not self.state:
+            raise TypeError("state must be a flax-layout dict (params / target_params / opt_states / step) or agent.state")
         return self
 
     # ------------------------------------------------------------------ batches

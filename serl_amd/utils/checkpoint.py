@@ -83,19 +83,30 @@ def restore_checkpoint(ckpt_dir_or_file: str, agent, step: Optional[int] = None,
             return agent  # flax returns the target unchanged when there is nothing to restore
     with open(path, "rb") as f:
         sd = msgpack.unpackb(f.read(), ext_hook=_unpack_ext, raw=False, strict_map_key=False)
+    return load_state_dict(agent, sd)
+
+
+def load_state_dict(agent, sd: dict):
+    """Loads any of {params, target_params, opt_states, step} (flax-layout trees, e.g. a restored checkpoint or
+    `agent.state.replace(...)` arguments) into the agent's HBM arena."""
     core, keys = agent.core, agent.image_keys
     tp = theta_paths(keys)
     trunk = _trunk_paths() if keys else {}   # the state-only agent has no encoder
-    for section, tree in (("params", sd["params"]), ("target_params", sd["target_params"])):
+    for section in ("params", "target_params"):
+        tree = sd.get(section)
+        if tree is None:
+            continue
         for leaf, paths in tp.items():
             core.set(section, leaf, _walk(tree, paths[0]))
         for leaf, sub in trunk.items():
             core.set(section, leaf, _walk(tree, ("modules_actor", "encoder", f"encoder_{keys[0]}", "pretrained_encoder") + sub))
-    for tx in TX_NAMES:
-        for mom in ("mu", "nu"):
-            tree = sd["opt_states"][tx][mom]
-            for leaf, paths in tp.items():
-                # leaves outside the optimizer's support are exact zeros; the C ABI accepts (and checks) them
-                core.set(f"opt/{tx}/{mom}", leaf, np.asarray(_walk(tree, paths[0]), np.float32))
-    core.step = int(sd["step"])
+    if sd.get("opt_states") is not None:
+        for tx in TX_NAMES:
+            for mom in ("mu", "nu"):
+                tree = sd["opt_states"][tx][mom]
+                for leaf, paths in tp.items():
+                    # leaves outside the optimizer's support are exact zeros; the C ABI accepts (and checks) them
+                    core.set(f"opt/{tx}/{mom}", leaf, np.asarray(_walk(tree, paths[0]), np.float32))
+    if sd.get("step") is not None:
+        core.step = int(np.asarray(sd["step"]))
     return agent

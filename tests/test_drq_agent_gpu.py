@@ -172,3 +172,19 @@ def test_iterator_prefetch_is_transparent(gpu):
     next(it)
     _, info = agent.update_high_utd(next(it), utd_ratio=1)
     assert all(np.isfinite(v) for v in info.resolve()["critic"].values()) and agent.state.step == 3
+
+
+def test_state_replace_loads_trees_into_hbm(gpu):
+    """agent.state.replace(params=...) / agent.replace(state=<restored dict>) of the reference: the trees land in HBM."""
+    env, rb, src = _setup(B=8)
+    src.update_high_utd(rb.sample(8, pack_obs_and_next_obs=True, lazy=True), utd_ratio=1)
+    env2, rb2, dst = _setup(B=8)
+    dst.state.replace(params=src.state.params, step=src.state.step)
+    assert dst.state.step == src.state.step
+    assert np.array_equal(dst.core.get("params", "actor/w1"), src.core.get("params", "actor/w1"))
+    assert not np.array_equal(dst.core.get("target_params", "critic/w1"), src.core.get("target_params", "critic/w1"))
+    dst = dst.replace(state={"target_params": src.state.target_params, "opt_states": src.state.opt_states})
+    for sec, leaf in (("target_params", "critic/w1"), ("opt/critic/mu", "critic/w2"), ("opt/actor/nu", "actor/w1")):
+        assert np.array_equal(dst.core.get(sec, leaf), src.core.get(sec, leaf)), (sec, leaf)
+    with pytest.raises(TypeError):
+        dst.state.replace(parms={})
