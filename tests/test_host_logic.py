@@ -102,3 +102,14 @@ def test_lazy_batches_know_the_next_batch():
     assert all(p1[1] is p2[1] for p1, p2 in zip(cur2.parts, nxt.parts))      # the very same index arrays
     assert [int(ix[0]) for _, ix in cur2.peek_next().parts] == [3, 103]
     assert LazyBatch([(a, np.array([1]))]).peek_next is None                 # plain sample(): nothing to peek
+
+
+def test_bench_flop_model_matches_the_survey():
+    """bench.py's roofline uses 2*M*K*Cout per conv launch: the trunk totals must equal SURVEY.md appendix D
+    (580,386,816 FLOP per 128x128 image = 77.07 M for conv_init + 503.32 M for the 11 block convs)."""
+    import bench
+    m = bench.conv_macs_per_image()
+    blocks = 2 * sum(v for k, v in m.items() if k.startswith("conv_igemm"))
+    assert 2 * m["conv_init"] == 77_070_336 and blocks == 503_316_480
+    assert 2 * m["conv_init"] + blocks == 580_386_816
+    assert sum(1 for k in m if k.startswith("conv_igemm")) == 11
