@@ -81,25 +81,40 @@ def main():
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
+    ap.add_argument("--force-launcher", action="store_true",
+                    help="go through torch.distributed.run (one rank per GPU, RCCL group) even with --gpus 1")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
     if args.workload == "sac_state":
         return sac_state_main(max(args.steps, 50))
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.force_launcher):
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU over
+        # RCCL), exactly as the driver's `python -m torch.distributed.run ... bench.py --gpus N` would
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world != args.gpus:  # never silently measure a different job than the one asked for
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or args.force_collective:
+    if launched or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world and dist.get_backend() == "nccl", "RCCL group does not span the job"
+        # prove RCCL sees every rank: sum of (rank + 1) over the group
+        probe = torch.tensor([float(rank + 1)], device="cuda")
+        dist.all_reduce(probe)
+        assert int(probe.item()) == world * (world + 1) // 2, f"RCCL all-reduce saw {probe.item()}, expected {world} ranks"
     assert B % world == 0
     Bl = B // world
     emu = args.emulate_world
@@ -139,11 +154,31 @@ def main():
     prio = args.prio if args.prio != "auto" else ("trunk" if Bl >= 128 else "update")
     sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank), prioritise_update=prio == "update",
                                                                             prioritise_trunk=prio == "trunk")
-    learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world,
-                                  all_reduce=(lambda t: dist.all_reduce(t)) if dist is not None else (lambda t: None),
+    # gradient all-reduce (common.py:213-214 pmean made real), HIP events around every 4th call on the stream it runs on
+    coll = {"calls": 0, "bytes": 0, "timed": [], "on": False}
+
+    def all_reduce(t):
+        if dist is None:
+            return
+        nb = t.numel() * t.element_size()
+        timed = coll["on"] and coll.setdefault(nb, 0) % PROFILE_EVERY == 0   # every 4th call of each payload size
+        if coll["on"]:
+            coll[nb] += 1
+            coll["calls"] += 1
+            coll["bytes"] += nb
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(t)
+            e1.record()
+            coll["timed"].append((t.numel() * t.element_size(), e0, e1))
+        else:
+            dist.all_reduce(t)
+
+    learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world, all_reduce=all_reduce,
                                   seed=7, schedule=sched)
 
-    learner.force_reduce = args.force_collective
+    learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
 
     def iteration():
         learner.iteration(args.car)
@@ -161,11 +196,13 @@ def main():
     _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else PROFILE_EVERY))
     _lib.check(_lib.lib().serl_profile_reset())
     barrier()
+    coll["on"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
     barrier()
     dt = time.perf_counter() - t0
+    coll["on"] = False
     prof = _lib.profile_read()
     _lib.check(_lib.lib().serl_profile_enable(0))
     torch.cuda.synchronize()
@@ -253,6 +290,16 @@ def main():
         "last_info": {k: round(float(v), 6) for k, v in info.items()},
         "host_enqueue_ms_per_iteration": round(min(host_ms), 4), "setup": {"replay_fill_s": round(fill_s, 2)},
     }
+    if dist is not None:
+        by_size = {}
+        for nbytes, e0, e1 in coll["timed"]:
+            by_size.setdefault(nbytes, []).append(e0.elapsed_time(e1) * 1e3)
+        out["collective"] = {
+            "backend": "nccl (RCCL)", "world_size": dist.get_world_size(), "launcher": "torch.distributed.run",
+            "all_reduces_per_step": coll["calls"] / max(args.steps, 1), "bytes_per_step": coll["bytes"] / max(args.steps, 1),
+            "avg_us_by_bytes": {str(k): round(float(np.mean(v)), 2) for k, v in sorted(by_size.items())},
+            "note": "one all-reduce(SUM) of [critic grads | loss scalars] per critic update and one of [scalars | actor grads] "
+                    "per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     # the JSON line must be the last thing on stdout: librccl prints its version banner through C stdio, which is
@@ -269,6 +316,25 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def self_launch(n):
+    """Re-exec this script under torch.distributed.run with one rank per GPU (RCCL over xGMI).  Refuses, non-zero,
+    when the node has fewer than `n` GPUs -- never falls back to a smaller world."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--force-launcher"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def sac_state_main(iters):
@@ -402,4 +468,4 @@ def _cpu_name():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -98,3 +98,12 @@ def leaf_slices(cfg):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def elem_rel_err(a, b, floor=1e-3):
+    """worst |a-b|/|b| over the elements with |b| >= floor * max|b| (errors in small elements are not normalised away)."""
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    m = np.abs(b) >= floor * (np.max(np.abs(b)) + 1e-300)
+    if not m.any():
+        return 0.0
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m])))

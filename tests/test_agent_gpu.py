@@ -10,6 +10,8 @@ import agent_helpers as AH
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+import os
+SEQ_TOL = float(os.environ.get("SERL_TEST_SEQ_TOL", "1e-4"))   # multi-step sequences: the same 1e-4 (measured on MI355X: passes)
 
 
 MODES = ["f16x3", "f32"]   # split-fp16 trunk convs (default) and exact fp32 MFMA
@@ -27,7 +29,8 @@ def test_trunk_forward(gpu, H, W, n, mode):
     assert got.shape == ref.shape
     err = AH.rel_err(got, ref)
     print(f"trunk {mode} {H}x{W} n={n}: rel err vs fp64 = {err:.2e}")
-    assert err < (TOL if mode == "f16x3" else 2e-5), err
+    # both modes are fp32-class (measured: f16x3 0.6-1.0e-6, exact-fp32 MFMA 1.2-1.7e-6 of the fp64 oracle)
+    assert err < 5e-6, err
 
 
 def _compare_state(cfg, st, core, tol=TOL, steps=1):
@@ -161,7 +164,7 @@ def test_multi_step_sequence(gpu):
         else:
             O.update_critics(st, tb, tn)
             core.update_critics(db, dn)
-    worst = _compare_state(cfg, st, core, tol=5e-4, steps=10)
+    worst = _compare_state(cfg, st, core, tol=SEQ_TOL, steps=10)
     assert core.step == st.step == 10
     print("worst rel err after 10 steps:", worst)
 
@@ -423,7 +426,7 @@ def test_baseline_config_shapes_match_oracle(gpu, name, keys, S, A, car):
         got = core.read_info()
         for k in keys_:
             assert abs(got[k] - info[k]) < 2 * TOL * max(1.0, abs(info[k])), (name, it, k, got[k], info[k])
-    _compare_state(cfg, st, core, tol=5e-4 if car > 2 else TOL, steps=car + 1)
+    _compare_state(cfg, st, core, tol=SEQ_TOL if car > 2 else TOL, steps=car + 1)
     assert core.step == st.step == car + 1
 
 

@@ -56,7 +56,7 @@ def test_state_update_high_utd_matches_oracle(gpu, utd):
         for k in ("critic_loss", "predicted_qs", "target_qs", "actor_loss", "temperature", "entropy", "temperature_loss"):
             assert abs(got[k] - info[k]) < TOL * max(1.0, abs(info[k])), (it, k, got[k], info[k])
         _check_grads(cfg, core, aux["g_actor"], "g_actor", sl["actor/w1"][0])
-    _compare_state(cfg, st, core, tol=5e-4 if utd > 2 else TOL, steps=2 * (utd + 1))
+    _compare_state(cfg, st, core, tol=TOL, steps=2 * (utd + 1))
     assert core.step == st.step == 2 * (utd + 1)
     # the temperature optimizer has no warm-up, the others do (sac.py:333-343)
     got = core.read_info()
