@@ -367,7 +367,9 @@ def apply_gradients(st: TrainState, grads):
     updates = {}
     for tx in TX_NAMES:
         o = st.opt[tx]
-        lr = st.lr_at(o["count"], tx)
+        # optax.inject_hyperparams keeps the scheduled learning rate as a float32 array (the value the reference logs as
+        # `<tx>_lr`): 3e-4 enters the update as float32(3e-4) = 0.00030000001425, also in an fp64 run
+        lr = float(np.float32(st.lr_at(o["count"], tx)))
         o["count"] += 1
         t = o["count"]
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t

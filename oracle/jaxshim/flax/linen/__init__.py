@@ -27,7 +27,7 @@ import jax
 from jax import numpy as jnp
 from jax import random as jrandom
 from jax._core import Array, asarray, raw
-from jax.nn import gelu, initializers, log_softmax, relu, sigmoid, silu, softmax, softplus, swish, tanh  # noqa: F401
+from jax.nn import elu, gelu, initializers, leaky_relu, log_softmax, relu, sigmoid, silu, softmax, softplus, swish, tanh  # noqa: F401
 
 from . import module  # noqa: F401  (the reference annotates a field with `nn.module`)
 

@@ -110,6 +110,9 @@ class Array(torch.Tensor):
     def __hash__(self):
         return id(self)
 
+    def __deepcopy__(self, memo):
+        return self.detach().clone().as_subclass(Array)
+
 
 def asarray(x, dtype=None):
     """anything array-like -> Array (floats in the configured float dtype unless a dtype is given)."""

@@ -45,3 +45,11 @@ def softmax(x, axis=-1):
 
 def log_softmax(x, axis=-1):
     return _w(torch.log_softmax(raw(x), dim=axis))
+
+
+def leaky_relu(x, negative_slope=0.01):
+    return _w(F.leaky_relu(raw(x), negative_slope))
+
+
+def elu(x, alpha=1.0):
+    return _w(F.elu(raw(x), alpha))

@@ -2,10 +2,13 @@
 and flax checkpoints expect; examples/async_drq_sim/async_drq_sim.py:104-108,229,295-307).
 
 Tree derived from flax naming rules at the reference's construction sites
-(agents/continuous/drq.py:165-222, common/common.py:58-78, vision/resnet_v1.py) -- UNVERIFIED against
-a real flax install (none available).  The alias switches below cover
-the open points: whether the shared EncodingWrapper also appears under modules_critic and the name
-of the vmapped critic MLP.
+(agents/continuous/drq.py:165-222, common/common.py:58-78, vision/resnet_v1.py): modules passed as attributes are
+named by attachment (`modules_actor`, `network`, `encoder_<key>`), a module instance shared by several owners
+(the EncodingWrapper of actor and critic, the frozen `pretrained_encoder` of all cameras) is adopted once -- the
+evidence is the reference's own loader, which patches `modules_actor` only and guards
+`if "pretrained_encoder" in new_encoder_params` (utils/train_utils.py:118-127).  tests/test_reference_update.py checks
+these paths against the tree the reference's own code builds under the flax stand-in (oracle/jaxshim); no real flax
+install is available, so the alias switches below remain for the alternative readings.
 """
 from __future__ import annotations
 
@@ -44,7 +47,7 @@ def _trunk_paths():
     return m
 
 
-def theta_paths(image_keys, critic_mlp_name="critic_ensemble"):
+def theta_paths(image_keys, critic_mlp_name="network"):
     """flat trainable leaf -> list of flax paths (aliases)."""
     enc = ("modules_actor", "encoder")
     m = {}
@@ -103,8 +106,13 @@ def _state_paths():
     return m
 
 
+def trunk_owner(image_keys):
+    """camera whose subtree holds the shared frozen trunk (first key in sorted order)."""
+    return sorted(image_keys)[0]
+
+
 def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: bool = False,
-                critic_mlp_name: str = "critic_ensemble") -> Dict:
+                critic_mlp_name: str = "network", trunk_under_every_camera: bool = False) -> Dict:
     """Nested dict of np.float32 arrays in flax layout (HWIO convs, (in,out) dense, ensemble axis 0)."""
     cfg = core.cfg
     shapes = theta_shapes(cfg.n_cam, cfg.H, cfg.W, cfg.state_dim, cfg.act_dim, ensemble=cfg.ensemble)
@@ -118,7 +126,11 @@ def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: 
     tshapes = trunk_shapes()
     for leaf, sub in (_trunk_paths() if cfg.n_cam else {}).items():
         v = core.get(section, leaf).reshape(tshapes[leaf])
-        for k in image_keys:  # every camera subtree carries the (identical) frozen trunk
+        # ONE frozen trunk: drq.py:165-176 passes the same `pretrained_encoder` module to every camera's
+        # PreTrainedResNetEncoder, flax adopts a shared module once -- under the first camera in sorted-key order --
+        # which is why train_utils.py:118-123 guards with `if "pretrained_encoder" in new_encoder_params`
+        owners = image_keys if trunk_under_every_camera else (trunk_owner(image_keys),)
+        for k in owners:
             _put(tree, ("modules_actor", "encoder", f"encoder_{k}", "pretrained_encoder") + sub, v)
             if duplicate_encoder_under_critic:
                 _put(tree, ("modules_critic", "encoder", f"encoder_{k}", "pretrained_encoder") + sub, v)

@@ -1,0 +1,42 @@
+"""Generates tests/golden/update_*.npz by running the REFERENCE's own DrQAgent update code unmodified
+(serl_launcher/agents/continuous/{drq,sac}.py, common/common.py, ... imported from /root/reference) under the
+third-party stand-ins of oracle/jaxshim, in fp64.  Run in the build container (needs /root/reference):
+    python tests/golden/make_golden_update.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import drq_oracle as O  # noqa: E402
+from oracle import golden_update as G  # noqa: E402
+from oracle import ref_update_runner as RR  # noqa: E402
+
+PARAM_SEED, BATCH_SEED = 42, 100
+CASES = {
+    # CAR-style sequence: critic-only steps (zero-gradient Adam steps of actor/temperature), an actor+temperature
+    # step, a UTD=2 scan -- 2x2 SpatialLearnedEmbeddings
+    "drq_64_seq": (O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3), 8,
+                   [("critics",), ("critics",), ("high_utd", 1), ("critics",), ("high_utd", 2)]),
+    # the benchmark's image size (4x4 SLE) and dims, small batch
+    "drq_128": (O.Config(image_keys=("front", "wrist"), H=128, W=128, S=24, A=6), 4, [("critics",), ("high_utd", 1)]),
+    # one camera (the literal BASELINE.json configs[1] wording), non-square
+    "drq_one_cam": (O.Config(image_keys=("image",), H=128, W=64, S=7, A=4), 6, [("high_utd", 1), ("critics",)]),
+}
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, (cfg, B, sched) in CASES.items():
+        res = RR.run_reference(cfg, B, sched, PARAM_SEED, BATCH_SEED)
+        rec = G.pack(res, PARAM_SEED, BATCH_SEED)
+        path = os.path.join(out_dir, f"update_{name}.npz")
+        np.savez_compressed(path, **rec)
+        print(name, "->", path, f"{os.path.getsize(path) / 1e6:.2f} MB", "final step", res["final"]["step"],
+              {k: round(v, 6) for k, v in res["steps"][-1]["info"].items()})
+
+
+if __name__ == "__main__":
+    main()
