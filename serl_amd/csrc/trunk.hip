@@ -551,7 +551,7 @@ size_t trunk_packed_bytes() {
       conv_dims(i, k, K, Cout);
       off += 2 * al256((size_t)K * Cout * 2);
     }
-  off += 2 * al256((size_t)64 * 176 * 2);
+  off += 2 * al256((size_t)64 * 224 * 2);   // conv_init planes (u8 variant: [64][224]; the 3-product variant uses [64][176] of it)
   return off;
 }
 
@@ -567,8 +567,8 @@ int trunk_packed_bind(TrunkPacked& p, void* mem) {
       p.blk[i][k].hi = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
       p.blk[i][k].lo = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
     }
-  p.init.hi = (uint16_t*)(b + off); off += al256((size_t)64 * 176 * 2);
-  p.init.lo = (uint16_t*)(b + off); off += al256((size_t)64 * 176 * 2);
+  p.init.hi = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
+  p.init.lo = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
   p.dirty = true;
   return SERL_OK;
 }

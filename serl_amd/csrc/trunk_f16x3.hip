@@ -450,6 +450,7 @@ struct ConvInitArgsB {
   float* pooled;        // [N][Ho/2][Wo/2][64] extreme of the in-tile part of every pooling window
   float* first_rows;    // [N][tiles_y][Wo][64] raw conv outputs of rows 0 mod 16
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
+  int dbg;              // timing experiments only (SERL_CI_DBG): 1 no stats atomics, 2 no pool epilogue, 4 no MFMA loop, 8 no patch fill
 };
 
 constexpr int kCbKP = 176;       // padded K
@@ -669,6 +670,289 @@ __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_init on RAW pixels ("u8" variant, default): the ImageNet normalisation is folded into the weights,
+//     out = sum_taps_inside ((px/255 - mean_c)/std_c) w  =  sum px * w/(255 std_c)  -  sum_taps_inside (mean_c/std_c) w ,
+// so the activation operand is the pixel value itself -- an integer 0..255, EXACT in fp16: it needs no lo' plane and an
+// fp32 product costs TWO fp16 MFMA products (px*w_hi + px*w_lo) instead of three.  The second term depends on which
+// taps fall inside the image (the reference zero-pads the NORMALISED image, resnet_v1.py:221-223,249-255); it rides in
+// the padding lane of the pixel record: a pixel is 4 halfs {c0, c1, c2, 1} (all 0 outside the image) and the weight of
+// the 4th lane is -sum_c (mean_c/std_c) w[ky,kx,c,:], so the border-dependent bias comes out of the same MFMAs.
+// 8-byte pixels make every 8-wide k-block (two pixels) a 16-byte aligned run of one patch row: K = 7 rows x 8 pixels x 4
+// = 224, A fragments are single ds_read_b128 (patch pitch 384 B: the two output rows of a lane group land on
+// complementary bank halves -> conflict-free), half the patch bytes of the 3-product kernel.  Weights are scaled by
+// 2^12 (keeps w_lo in fp16's normal range); the accumulator is rescaled (exactly) in the epilogue.
+// ---------------------------------------------------------------------------------------------
+constexpr int kC8K = 224;                    // 7 kernel rows x 8 pixel slots x 4 lanes
+constexpr int kC8WP = 232;                   // LDS pitch of a weight row (halfs): 464 B -> conflict-free ds_read_b128
+constexpr int kC8Pitch = 384;                // LDS pitch of a patch row (bytes) = 48 pixel slots
+constexpr int kC8WBytes = 64 * kC8WP * 2;    // one weight plane
+constexpr int kC8PBytes = 16384;             // patch (37 x 384 = 14208 B) / pooling stage (16 KB)
+constexpr int kC8Lds = 2 * kC8WBytes + kC8PBytes;
+constexpr float kC8Scale = 4096.0f, kC8Inv = 1.0f / 4096.0f;
+static_assert(kCbPatch * kC8Pitch <= kC8PBytes, "patch does not fit");
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  uint8_t* w_hi = smemb;
+  uint8_t* w_lo = smemb + kC8WBytes;
+  uint8_t* patch = smemb + 2 * kC8WBytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  for (int v = tid; v < 2 * 64 * (kC8K / 8); v += 256) {   // resident weights: 64 rows x 28 16-byte slots per plane
+    const int plane = v / (64 * 28), r = (v / 28) % 64, sl = v % 28;
+    const uint4 val = *reinterpret_cast<const uint4*>((plane ? a.wlo : a.whi) + (size_t)r * kC8K + sl * 8);
+    *reinterpret_cast<uint4*>((plane ? w_lo : w_hi) + r * (kC8WP * 2) + sl * 16) = val;
+  }
+  // patch staging: task = (patch row r, group g of 4 image pixels aligned to 4): 12 contiguous image bytes
+  constexpr int kGroups = 10, kTasks = kCbPatch * kGroups;   // 370 tasks, 2 rounds of 256 threads
+  const long img_bytes = (long)a.N * a.H * a.W * 3;
+  const bool aligned = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.img) & 3) == 0;
+  uint32_t pre[2][3];
+  unsigned pmask[2];   // bit j: pixel j of the group is inside the image
+#define SERL_C8_FETCH(TILE)                                                                             \
+  {                                                                                                     \
+    int b_ = (TILE);                                                                                    \
+    const int tx_ = b_ % a.tiles_x;                                                                     \
+    b_ /= a.tiles_x;                                                                                    \
+    const int ty_ = b_ % a.tiles_y;                                                                     \
+    const int n_ = b_ / a.tiles_y;                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
+      const int t_ = tid + 256 * q;                                                                     \
+      const int r_ = t_ / kGroups, g_ = t_ - r_ * kGroups;                                              \
+      const int iy = ty_ * 32 - 3 + r_, ixg = tx_ * 32 - 4 + 4 * g_;                                    \
+      const bool rowok = t_ < kTasks && (unsigned)iy < (unsigned)a.H;                                   \
+      unsigned m_ = 0;                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+        if (rowok && (unsigned)(ixg + j) < (unsigned)a.W) m_ |= 1u << j;                                \
+      pmask[q] = m_;                                                                                    \
+      long off_ = (((long)n_ * a.H + min(max(iy, 0), a.H - 1)) * a.W + ixg) * 3;                        \
+      if (aligned) {                                                                                    \
+        _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                 \
+          const long o_ = min(max(off_ + 4 * d, 0L), img_bytes - 4);                                    \
+          pre[q][d] = m_ ? *reinterpret_cast<const uint32_t*>(a.img + o_) : 0u;                         \
+        }                                                                                               \
+      } else {                                                                                          \
+        _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                 \
+          uint32_t w_ = 0;                                                                              \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+            const long o_ = min(max(off_ + 4 * d + e, 0L), img_bytes - 1);                              \
+            w_ |= (m_ ? (uint32_t)a.img[o_] : 0u) << (8 * e);                                           \
+          }                                                                                             \
+          pre[q][d] = w_;                                                                               \
+        }                                                                                               \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+  // every workgroup walks a CONTIGUOUS range of tiles (whole images where the counts divide): the GroupNorm partial
+  // sums stay in registers across the tiles of an image and are flushed once per image (the per-tile fp64 atomics of
+  // 16 workgroups on the same 8 words cost 40 us per pass), and neighbouring tiles share their halo in L2
+  const int per_wg = (a.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per_wg, t_end = min(t_begin + per_wg, a.total_tiles);
+  const int tiles_per_img = a.tiles_y * a.tiles_x;
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+  if (t_begin < t_end) SERL_C8_FETCH(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int b = tile;
+    const int tx = b % a.tiles_x;
+    b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    __syncthreads();  // previous tile's reads of the patch / pooling stage are done (weights are in place)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = tid + 256 * q;
+      if (t < kTasks && !(a.dbg & 8)) {
+        const int r = t / kGroups, g = t - r * kGroups;
+        // bytes 0..11 = pixels 0..3 x (c0,c1,c2); patch column of pixel j = 4g - 1 + j (column -1 is not stored)
+        const uint32_t d0 = pre[q][0], d1 = pre[q][1], d2 = pre[q][2];
+        const uint32_t by[12] = {d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, d0 >> 24, d1 & 255u, (d1 >> 8) & 255u,
+                                 (d1 >> 16) & 255u, d1 >> 24, d2 & 255u, (d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24};
+        uint8_t* rowp = patch + r * kC8Pitch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = 4 * g - 1 + j;
+          if (col < 0) continue;
+          const bool in = (pmask[q] >> j) & 1u;
+          const f16x2 c01 = {(_Float16)(float)by[3 * j], (_Float16)(float)by[3 * j + 1]};
+          const f16x2 c2b = {(_Float16)(float)by[3 * j + 2], (_Float16)1.0f};
+          u32x2 rec = {__builtin_bit_cast(unsigned, c01), __builtin_bit_cast(unsigned, c2b)};
+          if (!in) rec = (u32x2){0u, 0u};
+          *reinterpret_cast<u32x2*>(rowp + col * 8) = rec;
+        }
+      }
+    }
+    __syncthreads();
+    SERL_C8_FETCH(min(tile + 1, a.total_tiles - 1));  // next tile's bytes, in flight under the MFMAs
+    int abase[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int p = wave * 64 + tm * 32 + li;
+      abase[tm] = (2 * (p >> 4)) * kC8Pitch + (p & 15) * 16 + lh * 16;
+    }
+    const int bbase = li * (kC8WP * 2) + lh * 16;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    if (!(a.dbg & 4))
+#pragma unroll
+    for (int ks = 0; ks < kC8K / 16; ++ks) {
+      const int aoff = (ks >> 1) * kC8Pitch + (ks & 1) * 32;   // kernel row ky = ks/2, k-blocks 2(ks&1) + lh
+      f16x8 apx[2], bhi[2], blo[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) apx[tm] = *reinterpret_cast<const f16x8*>(patch + abase[tm] + aoff);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int off = bbase + tn * 32 * (kC8WP * 2) + ks * 32;
+        bhi[tn] = *reinterpret_cast<const f16x8*>(w_hi + off);
+        blo[tn] = *reinterpret_cast<const f16x8*>(w_lo + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(apx[tm], blo[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(apx[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= kC8Inv;   // exact (power of two)
+    if (!POOL) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+          const bool ok = oy < a.Ho && ox < a.Wo;
+          float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const float v = ok ? acc[tm][tn][r] : 0.f;
+            if (ok) o[tn * 32 + li] = v;
+            s[tn] += v;
+            q[tn] += v * v;
+          }
+        }
+    } else if (!(a.dbg & 2)) {  // fused 3x3/2 max-pool, identical to conv_init_f16x3_kernel<true> (every tile is full)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const float v = acc[tm][tn][r];
+            s[tn] += v;
+            q[tn] += v * v;
+          }
+      if (wave == 0) {
+        float* fr = a.first_rows + (((size_t)n * a.tiles_y + (oy0 >> 4)) * a.Wo + ox0 + 4 * lh) * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) fr[(8 * (r >> 2) + (r & 3)) * 64 + tn * 32] = acc[0][tn][r];
+      }
+      if (lh == 0) {
+        float* fc = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + (ox0 >> 4)) * 64 + li;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+              fc[(size_t)(tm * 2 + rr) * a.tiles_x * 64 + tn * 32] = acc[tm][tn][8 * rr];
+      }
+      // 3x3/2 max-pool of the in-tile part of every window, in registers.  A lane holds, for channel tn*32 + li, the
+      // tile rows 4*wave + i (i = 0..3) and the column quads Q = 2q + lh (q = 0, 1): r = 8*(i&1) + 4q + j, tm = i>>1.
+      // Horizontal: px = 2Q needs cols 4Q..4Q+2 (local), px = 2Q+1 needs cols 4Q+2, 4Q+3 and col 0 of quad Q+1, which
+      // the partner lane (lane ^ 32) holds.  Vertical: py = 2*wave needs rows 0..2 (local), py = 2*wave+1 rows 2, 3 and
+      // row 0 of the next wave, exchanged through LDS.  Values are sign-folded (x * sign(gamma)), so it is always a max.
+      float hrow[2][4][4];   // [tn][row i][px slot = 2q + parity]
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const float sg = a.gamma[tn * 32 + li] < 0.f ? -1.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float part[2], v0[2];
+#pragma unroll
+          for (int qd = 0; qd < 2; ++qd) {
+            const int rb = 8 * (i & 1) + 4 * qd;
+            const float c0 = sg * acc[i >> 1][tn][rb], c1 = sg * acc[i >> 1][tn][rb + 1];
+            const float c2 = sg * acc[i >> 1][tn][rb + 2], c3 = sg * acc[i >> 1][tn][rb + 3];
+            hrow[tn][i][2 * qd] = fmaxf(fmaxf(c0, c1), c2);
+            part[qd] = fmaxf(c2, c3);
+            v0[qd] = c0;
+          }
+          const float r0 = __shfl_xor(v0[0], 32), r1 = __shfl_xor(v0[1], 32);
+          hrow[tn][i][1] = fmaxf(part[0], lh ? r1 : r0);
+          hrow[tn][i][3] = lh ? part[1] : fmaxf(part[1], r1);   // lh = 1, q = 1: column 16 belongs to the next tile
+        }
+      }
+      __syncthreads();  // every wave is done reading the patch: its first 8 KB become the row-exchange buffer
+      float* ex = reinterpret_cast<float*>(patch);   // [wave][tn][px slot][lane]
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) ex[((wave * 2 + tn) * 4 + sl) * 64 + lane] = hrow[tn][0][sl];
+      __syncthreads();
+      const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const float sg = a.gamma[tn * 32 + li] < 0.f ? -1.f : 1.f;
+        float* orow = a.pooled + (((size_t)n * Hp + (oy0 >> 1) + 2 * wave) * Wp + (ox0 >> 1)) * 64 + tn * 32 + li;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          const int px = 2 * (2 * (sl >> 1) + lh) + (sl & 1);
+          const float even = fmaxf(fmaxf(hrow[tn][0][sl], hrow[tn][1][sl]), hrow[tn][2][sl]);
+          float odd = fmaxf(hrow[tn][2][sl], hrow[tn][3][sl]);
+          if (wave < 3) odd = fmaxf(odd, ex[(((wave + 1) * 2 + tn) * 4 + sl) * 64 + lane]);
+          orow[(size_t)px * 64] = sg * even;
+          orow[((size_t)Wp + px) * 64] = sg * odd;
+        }
+      }
+    }
+    if (tile + 1 == t_end || (tile + 1) / tiles_per_img != n) {   // last tile of this image in this workgroup's range
+      double* st = a.stats + (size_t)n * kGnGroups * 2;
+      if (!(a.dbg & 1))
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
+      s[0] = s[1] = q[0] = q[1] = 0.f;
+    }
+  }
+#undef SERL_C8_FETCH
+}
+
+// conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> fp16 hi / lo planes [64][224] of the folded, scaled
+// weights (k' = ky*32 + kx*4 + lane; lane 3 = the bias lane, pixel slot kx = 7 is zero)
+__global__ void pack_conv_init_u8_kernel(const float* w, uint16_t* hi, uint16_t* lo) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 64 * kC8K) return;
+  const int n = e / kC8K, kp = e - n * kC8K;
+  const int ky = kp >> 5, kx = (kp >> 2) & 7, ln = kp & 3;
+  const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+  double v = 0.0;
+  if (kx < 7) {
+    if (ln < 3) v = (double)w[(size_t)(ky * 21 + kx * 3 + ln) * 64 + n] / (255.0 * stdv[ln]);
+    else
+      for (int c = 0; c < 3; ++c) v -= (double)w[(size_t)(ky * 21 + kx * 3 + c) * 64 + n] * (mean[c] / stdv[c]);
+  }
+  const float vs = (float)(v * (double)kC8Scale);
+  const _Float16 h = (_Float16)clamp_h(vs);
+  const _Float16 l = (_Float16)(vs - (float)h);   // unscaled residual: normal fp16 range thanks to the 2^12 weight scale
+  hi[e] = __builtin_bit_cast(uint16_t, h);
+  lo[e] = __builtin_bit_cast(uint16_t, l);
+}
+
 // conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> hi / lo' fp16 [64][176] (k' = ky*24 + kx*3 + c)
 __global__ void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -683,8 +967,12 @@ __global__ void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo
   lo[e] = __builtin_bit_cast(uint16_t, l);
 }
 
+// SERL_CONV_INIT_U8=0 selects the older 3-product kernel (normalised pixels through a LUT) for A/B runs
+static const bool kConvInitU8 = []() { const char* e = getenv("SERL_CONV_INIT_U8"); return !(e && e[0] == '0'); }();
+
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream) {
-  hipLaunchKernelGGL(pack_conv_init_kernel, dim3(cdiv(64 * kCbKP, 256)), dim3(256), 0, stream, w, hi, lo);
+  if (kConvInitU8) hipLaunchKernelGGL(pack_conv_init_u8_kernel, dim3(cdiv(64 * kC8K, 256)), dim3(256), 0, stream, w, hi, lo);
+  else hipLaunchKernelGGL(pack_conv_init_kernel, dim3(cdiv(64 * kCbKP, 256)), dim3(256), 0, stream, w, hi, lo);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -696,6 +984,8 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.tiles_y = cdiv(Ho, 16); a.tiles_x = cdiv(Wo, 16);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
+  static const int dbg = []() { const char* e = getenv("SERL_CI_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   const int grid = std::min(a.total_tiles, 512);  // 2 persistent workgroups per CU
   ProfScope prof("conv_init", stream);
   if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
@@ -704,9 +994,11 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
     a.pooled = out;
     a.first_rows = a.pooled + (size_t)N * (Ho / 2) * (Wo / 2) * 64;
     a.first_cols = a.first_rows + (size_t)N * a.tiles_y * Wo * 64;
-    hipLaunchKernelGGL(conv_init_f16x3_kernel<true>, dim3(grid), dim3(256), kCbLds, stream, a);
+    if (kConvInitU8) hipLaunchKernelGGL(conv_init_u8_kernel<true>, dim3(grid), dim3(256), kC8Lds, stream, a);
+    else hipLaunchKernelGGL(conv_init_f16x3_kernel<true>, dim3(grid), dim3(256), kCbLds, stream, a);
   } else {
-    hipLaunchKernelGGL(conv_init_f16x3_kernel<false>, dim3(grid), dim3(256), kCbLds, stream, a);
+    if (kConvInitU8) hipLaunchKernelGGL(conv_init_u8_kernel<false>, dim3(grid), dim3(256), kC8Lds, stream, a);
+    else hipLaunchKernelGGL(conv_init_f16x3_kernel<false>, dim3(grid), dim3(256), kCbLds, stream, a);
   }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
