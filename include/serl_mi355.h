@@ -151,7 +151,25 @@ typedef struct serl_agent_cfg {
   float std_min, std_max;  /* 1e-5, 5 */
   float target_entropy;    /* -act_dim/2, drq.py:88-89 */
   uint64_t seed;           /* device noise stream (production mode) */
+  /* Per-optimizer options of make_optimizer (common/optimizers.py:6-56), indexed by SERL_TX_*.  All zero (the
+   * default, what every example uses) = adam + the warm-up -> constant schedule above.
+   *   tx_lr            > 0: learning rate of this optimizer (else `lr`)
+   *   tx_warmup       >= 0: warm-up steps of this optimizer, given as steps + 1 (0 = use warmup_steps / temp_warmup_steps)
+   *   tx_cosine_steps  > 0: warmup_cosine_decay_schedule(0, lr, warmup, decay_steps = this, end 0) (optimizers.py:14-21)
+   *   tx_weight_decay_on != 0: optax.adamw with tx_weight_decay (optimizers.py:39-42); it decays the WHOLE tree, as the
+   *                    reference's tx.update(grads, state, params) does.  State-only agents (n_cam == 0) only: on a
+   *                    pixel agent it would decay the frozen pretrained trunk (SERL_ERR_UNSUPPORTED)
+   *   tx_clip_norm     > 0: optax.clip_by_global_norm on this optimizer's gradient tree (optimizers.py:36-37) */
+  float tx_lr[3];
+  int tx_warmup[3];
+  int tx_cosine_steps[3];
+  int tx_weight_decay_on[3];
+  float tx_weight_decay[3];
+  float tx_clip_norm[3];
 } serl_agent_cfg;
+#define SERL_TX_ACTOR 0
+#define SERL_TX_CRITIC 1
+#define SERL_TX_TEMPERATURE 2
 
 int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out);
 int serl_agent_destroy(serl_agent* a);
@@ -214,16 +232,26 @@ int serl_agent_select_slot(serl_agent* a, int slot);
 int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
                             const serl_noise* noise, int redq_row, void* stream);
 int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* noise, void* stream);
-#define SERL_APPLY_CRITIC 1
-#define SERL_APPLY_ACTOR_TEMP 2
+/* `which` = networks_to_update of SACAgent.update (sac.py:243-299) as a bit set; optimizers whose bit is clear still
+ * step with a zero gradient (sac.py:276-277).  The target EMA runs iff SERL_NET_CRITIC is set (sac.py:284-285). */
+#define SERL_NET_CRITIC 1
+#define SERL_NET_ACTOR 2
+#define SERL_NET_TEMPERATURE 4
+#define SERL_APPLY_CRITIC SERL_NET_CRITIC
+#define SERL_APPLY_ACTOR_TEMP (SERL_NET_ACTOR | SERL_NET_TEMPERATURE)
 int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream);
+/* SACAgent.update(batch, networks_to_update) (sac.py:243-299) on an augmented device batch: every selected loss is
+ * evaluated at the SAME (pre-update) parameters, then ONE optimizer step of all three Adam transforms (+ target EMA
+ * if the critic is selected).  nets = any non-empty combination of SERL_NET_*. */
+int serl_agent_update(serl_agent* a, const serl_batch* batch, int nets, const serl_noise* noise, void* stream);
 int serl_agent_begin_update(serl_agent* a, void* stream); /* clears the info accumulator */
 /* Batch-sharded data parallelism: the batches this agent is given are rows [global_offset, global_offset + local
  * batch) of a global batch of `global_batch` rows.  Device-generated noise (noise == NULL) is then indexed by the
  * GLOBAL row, so a sample gets the same eps / dropout mask whichever rank owns it and results do not depend on the
  * world size (the dormant pmean of common.py:213-214 made real).  global_batch = 0: not sharded (default). */
 int serl_agent_set_shard(serl_agent* a, int64_t global_offset, int64_t global_batch);
-/* which = SERL_APPLY_CRITIC: [critic grads | scalars]; SERL_APPLY_ACTOR_TEMP: [scalars | actor grads] */
+/* which = SERL_APPLY_CRITIC: [critic grads | scalars]; SERL_APPLY_ACTOR_TEMP (or any actor/temperature bit):
+ * [scalars | actor grads]; critic AND actor/temperature bits: the whole [critic grads | scalars | actor grads] range */
 int serl_agent_grad_view(serl_agent* a, int which, float** dev_ptr, int64_t* count);
 
 /* SACAgent.sample_actions (sac.py:301-320): policy forward with train=False on `n` observations

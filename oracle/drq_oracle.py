@@ -60,6 +60,8 @@ class Config:
     target_entropy: float = None    # drq.py:88-89: -A/2
     temp_warmup: int = None         # temperature optimizer's own warm-up (None: same as `warmup`); SACAgent.create
                                     # defaults: actor/critic warmup 2000, temperature none (sac.py:333-343)
+    opt: dict = None                # optional {"actor"|"critic"|"temperature": make_optimizer kwargs} (optimizers.py:6-13:
+                                    # learning_rate, warmup_steps, cosine_decay_steps, weight_decay, clip_grad_norm)
 
     def __post_init__(self):
         if self.target_entropy is None:
@@ -351,40 +353,67 @@ class TrainState:
                          "mu": {k: torch.zeros_like(v) for k, v in self.params.items()},
                          "nu": {k: torch.zeros_like(v) for k, v in self.params.items()}} for tx in TX_NAMES}
 
-    def lr_at(self, count, tx="critic"):  # optimizers.py:23-30 join_schedules([linear(0,lr,warmup), constant(lr)],[warmup])
+    def tx_opt(self, tx):
         c = self.cfg
         warm = c.warmup if (tx != "temperature" or c.temp_warmup is None) else c.temp_warmup
+        kw = {"learning_rate": c.lr, "warmup_steps": warm, "cosine_decay_steps": None, "weight_decay": None,
+              "clip_grad_norm": None}
+        kw.update((c.opt or {}).get(tx, {}))
+        return kw
+
+    def lr_at(self, count, tx="critic"):
+        """optimizers.py:14-30: join_schedules([linear(0, lr, warmup), constant(lr)], [warmup]) or
+        optax.warmup_cosine_decay_schedule(0, lr, warmup, cosine_decay_steps, 0)."""
+        kw = self.tx_opt(tx)
+        lr, warm = kw["learning_rate"], int(kw["warmup_steps"] or 0)
         if count < warm:
-            return c.lr * count / warm
-        return c.lr
+            return lr * count / warm
+        if kw["cosine_decay_steps"] is not None:
+            T = max(int(kw["cosine_decay_steps"]) - warm, 1)
+            return lr * 0.5 * (1.0 + math.cos(math.pi * min(count - warm, T) / T))
+        return lr
 
 
 def apply_gradients(st: TrainState, grads):
-    """common.py:136-168 + optax.adam (b1 .9, b2 .999, eps 1e-8, eps_root 0) restated.
+    """common.py:136-168 + optax.adam (b1 .9, b2 .999, eps 1e-8, eps_root 0) restated, with make_optimizer's optional
+    stages (optimizers.py:32-46): clip_by_global_norm first, adamw's decoupled weight decay on the WHOLE tree.
     grads: {tx: {name: tensor or None}}; a missing tx / name means an exact-zero gradient, which is
     still a real Adam step (moment decay + momentum update)."""
     b1, b2, eps = 0.9, 0.999, 1e-8
-    updates = {}
+    updates, trunk_decay = {}, 0.0
     for tx in TX_NAMES:
         o = st.opt[tx]
+        kw = st.tx_opt(tx)
         # optax.inject_hyperparams keeps the scheduled learning rate as a float32 array (the value the reference logs as
         # `<tx>_lr`): 3e-4 enters the update as float32(3e-4) = 0.00030000001425, also in an fp64 run
         lr = float(np.float32(st.lr_at(o["count"], tx)))
         o["count"] += 1
         t = o["count"]
         bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-        g_tx = grads.get(tx, {})
+        g_tx = {k: (grads.get(tx, {}).get(k) if grads.get(tx, {}).get(k) is not None else torch.zeros_like(st.params[k]))
+                for k in st.params}
+        if kw["clip_grad_norm"] is not None:    # optax.clip_by_global_norm over this optimizer's whole gradient tree
+            g_norm = torch.sqrt(sum((g * g).sum() for g in g_tx.values()))
+            if not bool(g_norm < kw["clip_grad_norm"]):
+                g_tx = {k: g / g_norm * kw["clip_grad_norm"] for k, g in g_tx.items()}
+        wd = kw["weight_decay"]
         upd = {}
         for k in st.params:
-            g = g_tx.get(k)
-            if g is None:
-                g = torch.zeros_like(st.params[k])
+            g = g_tx[k]
             o["mu"][k] = b1 * o["mu"][k] + (1.0 - b1) * g
             o["nu"][k] = b2 * o["nu"][k] + (1.0 - b2) * g * g
-            upd[k] = -lr * (o["mu"][k] / bc1) / (torch.sqrt(o["nu"][k] / bc2) + eps)
+            d = (o["mu"][k] / bc1) / (torch.sqrt(o["nu"][k] / bc2) + eps)
+            if wd is not None:                    # optax.adamw: add_decayed_weights before the -lr scaling
+                d = d + wd * st.params[k]
+            upd[k] = -lr * d
+        if wd is not None:                        # ... and the frozen trunk leaves are part of `params` too
+            trunk_decay += lr * wd
         updates[tx] = upd
     for k in st.params:
         st.params[k] = st.params[k] + ((updates["actor"][k] + updates["critic"][k]) + updates["temperature"][k])
+    if trunk_decay:
+        for k in st.trunk:
+            st.trunk[k] = st.trunk[k] - trunk_decay * st.trunk[k]
     st.step += 1
 
 
@@ -403,7 +432,7 @@ def _grad_dict(loss, params):
     return {k: g for k, g in zip(names, gs) if g is not None}
 
 
-def critic_update(st: TrainState, feats_obs, feats_next, state, next_state, action, reward, mask, noise):
+def critic_update(st: TrainState, feats_obs, feats_next, state, next_state, action, reward, mask, noise, apply=True):
     """SACAgent.update(networks_to_update={"critic"}) (sac.py:243-299) on precomputed (frozen)
     trunk features of the augmented batch.  noise: eps_next [B,A], mask_next {cam:[B,4096]},
     redq_idx (2,).  Returns info dict (sac.py:185-189) and the critic gradient dict."""
@@ -423,40 +452,77 @@ def critic_update(st: TrainState, feats_obs, feats_next, state, next_state, acti
     loss = ((q - target_q[None]) ** 2).mean()                                        # sac.py:181-183
     grads = _grad_dict(loss, p)
     info = {"critic_loss": loss.item(), "predicted_qs": q.mean().item(), "target_qs": target_q.mean().item()}
-    apply_gradients(st, {"critic": grads})
-    target_update(st)                                                                # sac.py:284-285
     aux = {"next_actions": next_a, "next_logp": next_logp, "target_q": target_q, "q": q.detach(),
            "grads": grads, "enc_obs": enc.detach()}
+    if apply:
+        apply_gradients(st, {"critic": grads})
+        target_update(st)                                                            # sac.py:284-285
     return info, aux
 
 
-def actor_temp_update(st: TrainState, feats_obs, feats_next, state, next_state, noise):
+def actor_temp_update(st: TrainState, feats_obs, feats_next, state, next_state, noise, apply=True, do_actor=True,
+                      do_temp=True):
     """SACAgent.update(networks_to_update={"actor","temperature"}) (sac.py:193-234,243-299).
     noise: eps_pi, mask_obs_pi {cam}, eps_temp, mask_next_temp {cam}."""
     cfg = st.cfg
-    p = {k: v.detach().clone().requires_grad_(True) for k, v in st.params.items()}
-    # policy loss: grads through the actions and log-probs only (critic/encoder-of-critic constant)
-    alpha = F.softplus(st.params["temp/lagrange"])                                   # forward_temperature
-    enc_pi = encode(p, cfg, feats_obs, state, drop_masks=noise["mask_obs_pi"], stop_gradient=True)
-    mean, std = policy_head(p, cfg, enc_pi)
-    a, logp = sample_and_log_prob(mean, std, noise["eps_pi"])
-    enc_c = encode(st.params, cfg, feats_obs, state)
-    q = critic_forward(st.params, cfg, enc_c, a).mean(dim=0)                         # sac.py:203-208
-    actor_loss = -(q - alpha * logp).mean()                                          # sac.py:212-213
-    g_actor = _grad_dict(actor_loss, p)
-    # temperature loss
-    with torch.no_grad():
-        enc_n = encode(st.params, cfg, feats_next, next_state, drop_masks=noise["mask_next_temp"], stop_gradient=True)
-        m2, s2 = policy_head(st.params, cfg, enc_n)
-        _, logp_n = sample_and_log_prob(m2, s2, noise["eps_temp"])
-        entropy = -logp_n.mean()                                                     # sac.py:229
-    lam = st.params["temp/lagrange"].detach().clone().requires_grad_(True)
-    temp_loss = F.softplus(lam) * (entropy - cfg.target_entropy)                     # lagrange.py:63-72
-    g_temp = {"temp/lagrange": torch.autograd.grad(temp_loss, lam)[0]}
-    info = {"actor_loss": actor_loss.item(), "temperature": alpha.item(), "entropy": (-logp.mean()).item(),
-            "temperature_loss": temp_loss.item()}
-    apply_gradients(st, {"actor": g_actor, "temperature": g_temp})                   # no EMA (sac.py:284)
-    return info, {"g_actor": g_actor, "g_temp": g_temp, "actions": a.detach(), "logp": logp.detach()}
+    info, grads, aux = {}, {}, {}
+    if do_actor:
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in st.params.items()}
+        # policy loss: grads through the actions and log-probs only (critic/encoder-of-critic constant)
+        alpha = F.softplus(st.params["temp/lagrange"])                               # forward_temperature
+        enc_pi = encode(p, cfg, feats_obs, state, drop_masks=noise["mask_obs_pi"], stop_gradient=True)
+        mean, std = policy_head(p, cfg, enc_pi)
+        a, logp = sample_and_log_prob(mean, std, noise["eps_pi"])
+        enc_c = encode(st.params, cfg, feats_obs, state)
+        q = critic_forward(st.params, cfg, enc_c, a).mean(dim=0)                     # sac.py:203-208
+        actor_loss = -(q - alpha * logp).mean()                                      # sac.py:212-213
+        grads["actor"] = _grad_dict(actor_loss, p)
+        info.update({"actor_loss": actor_loss.item(), "temperature": alpha.item(), "entropy": (-logp.mean()).item()})
+        aux.update({"g_actor": grads["actor"], "actions": a.detach(), "logp": logp.detach()})
+    if do_temp:
+        with torch.no_grad():
+            enc_n = encode(st.params, cfg, feats_next, next_state, drop_masks=noise["mask_next_temp"], stop_gradient=True)
+            m2, s2 = policy_head(st.params, cfg, enc_n)
+            _, logp_n = sample_and_log_prob(m2, s2, noise["eps_temp"])
+            entropy = -logp_n.mean()                                                 # sac.py:229
+        lam = st.params["temp/lagrange"].detach().clone().requires_grad_(True)
+        temp_loss = F.softplus(lam) * (entropy - cfg.target_entropy)                 # lagrange.py:63-72
+        grads["temperature"] = {"temp/lagrange": torch.autograd.grad(temp_loss, lam)[0]}
+        info["temperature_loss"] = temp_loss.item()
+        aux["g_temp"] = grads["temperature"]
+    if apply:
+        apply_gradients(st, grads)                                                   # no EMA (sac.py:284)
+    return info, aux
+
+
+def update(st: TrainState, batch, noise, networks=("actor", "critic", "temperature")):
+    """SACAgent.update(batch, networks_to_update) (sac.py:243-299) on an already augmented batch: every selected loss is
+    evaluated at the same (pre-update) parameters, the others are `lambda params, rng: (0.0, {})` (zero gradients that
+    still step their optimizer), ONE apply_gradients over all three optimizers, target EMA iff "critic" is selected."""
+    nets = set(networks)
+    assert nets and nets <= {"actor", "critic", "temperature"}, f"Invalid gradient steps: {networks}"
+    fo, fn = features(st, batch["obs"]), features(st, batch["next"])
+    n = dict(noise)
+    if "redq_idx" in noise:
+        n["redq_idx"] = np.asarray(noise["redq_idx"]).reshape(-1, 2)[0]
+    info, grads = {}, {}
+    if "critic" in nets:
+        ci, caux = critic_update(st, fo, fn, batch["state"], batch["next_state"], batch["action"], batch["reward"],
+                                 batch["mask"], n, apply=False)
+        info.update(ci)
+        grads["critic"] = caux["grads"]
+    if nets & {"actor", "temperature"}:
+        ai, aaux = actor_temp_update(st, fo, fn, batch["state"], batch["next_state"], n, apply=False,
+                                     do_actor="actor" in nets, do_temp="temperature" in nets)
+        info.update(ai)
+        if "actor" in nets:
+            grads["actor"] = aaux["g_actor"]
+        if "temperature" in nets:
+            grads["temperature"] = aaux["g_temp"]
+    apply_gradients(st, grads)
+    if "critic" in nets:
+        target_update(st)
+    return info
 
 
 def features(st: TrainState, frames_u8, chunk=64):

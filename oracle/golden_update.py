@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 
 from . import drq_oracle as O
-from .ref_update_runner import synth_packed_batch
+from .ref_update_runner import synth_flat_batch, synth_packed_batch
 
 FULL_MAX = 4096
 N_SAMPLE = 2048
@@ -72,7 +72,8 @@ def cfg_from_dict(d):
 
 def pack(res, param_seed, batch_seed):
     cfg = res["cfg"]
-    out = {"meta": np.array(json.dumps({"cfg": cfg_to_dict(cfg), "B": res["B"], "schedule": [list(s) for s in res["schedule"]],
+    out = {"meta": np.array(json.dumps({"cfg": cfg_to_dict(cfg), "B": res["B"],
+                                        "schedule": [[s[0]] + [list(x) if isinstance(x, (tuple, list)) else x for x in s[1:]] for s in res["schedule"]],
                                         "param_seed": param_seed, "batch_seed": batch_seed, "final_step": res["final"]["step"]}))}
     for i, st in enumerate(res["steps"]):
         for k, v in st["batch"]["frames"].items():
@@ -106,7 +107,8 @@ def unpack(npz):
     for i, item in enumerate(meta["schedule"]):
         kind = item[0]
         utd = item[1] if kind == "high_utd" else 1
-        pb = synth_packed_batch(cfg, B, meta["batch_seed"] + i)
+        nets = tuple(item[1]) if kind == "update" else ()
+        pb = (synth_flat_batch if cfg.state_only else synth_packed_batch)(cfg, B, meta["batch_seed"] + i)
         for k, v in pb["frames"].items():
             assert np.uint32(zlib.crc32(v.tobytes())) == npz[f"s{i}_crc_{k}"], "synthetic inputs drifted from the golden run's"
         noise = {}
@@ -121,8 +123,11 @@ def unpack(npz):
                         noise.setdefault(base, {})[cam] = np.unpackbits(npz[key])[:B * D].reshape(B, D)
             else:
                 noise[nm] = npz[key]
+        for eps_name, mask_name in (("eps_next", "mask_next"), ("eps_pi", "mask_obs_pi"), ("eps_temp", "mask_next_temp")):
+            if eps_name in noise:
+                noise.setdefault(mask_name, {})      # state-only agent: no cameras, no dropout masks
         info = dict(zip([str(k) for k in npz[f"s{i}_info_keys"]], npz[f"s{i}_info_vals"]))
-        steps.append({"kind": kind, "utd": utd, "batch": pb, "noise": noise, "info": info})
+        steps.append({"kind": kind, "utd": utd, "nets": nets, "batch": pb, "noise": noise, "info": info})
     final = {}
     for key in npz.files:
         if key.startswith("f_"):

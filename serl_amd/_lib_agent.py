@@ -13,7 +13,14 @@ class SerlAgentCfg(C.Structure):
         ("discount", C.c_float), ("tau", C.c_float), ("lr", C.c_float), ("dropout", C.c_float),
         ("std_min", C.c_float), ("std_max", C.c_float), ("target_entropy", C.c_float),
         ("seed", C.c_uint64),
+        # per-optimizer options of make_optimizer (common/optimizers.py:6-56), index = TX_INDEX[name]
+        ("tx_lr", C.c_float * 3), ("tx_warmup", C.c_int * 3), ("tx_cosine_steps", C.c_int * 3),
+        ("tx_weight_decay_on", C.c_int * 3), ("tx_weight_decay", C.c_float * 3), ("tx_clip_norm", C.c_float * 3),
     ]
+
+
+TX_INDEX = {"actor": 0, "critic": 1, "temperature": 2}   # SERL_TX_*
+NET_BITS = {"critic": 1, "actor": 2, "temperature": 4}   # SERL_NET_*
 
 
 class SerlNoise(C.Structure):
@@ -51,6 +58,7 @@ def declare(lib):
         "serl_agent_critic_grads": [vp, i32, i32, i32, P(SerlNoise), i32, vp],
         "serl_agent_actor_grads": [vp, i32, P(SerlNoise), vp],
         "serl_agent_apply": [vp, i32, f32, vp],
+        "serl_agent_update": [vp, P(SerlBatch), i32, P(SerlNoise), vp],
         "serl_agent_begin_update": [vp, vp],
         "serl_agent_set_shard": [vp, i64, i64],
         "serl_agent_grad_view": [vp, i32, P(vp), P(i64)],

@@ -8,9 +8,9 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._lib_agent import SerlAgentCfg, SerlInfo, SerlNoise
+from .._lib_agent import NET_BITS, TX_INDEX, SerlAgentCfg, SerlInfo, SerlNoise
 
-APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 2
+APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 6   # SERL_NET_CRITIC, SERL_NET_ACTOR | SERL_NET_TEMPERATURE
 TX_NAMES = ("actor", "critic", "temperature")
 
 
@@ -18,12 +18,29 @@ class AgentCore:
     def __init__(self, *, device=0, n_cam, H, W, state_dim, act_dim, batch, ensemble=10, hidden=256,
                  bottleneck=256, sle_features=8, proprio_dim=64, warmup_steps=0, discount=0.96,
                  tau=0.005, lr=3e-4, dropout=0.1, std_min=1e-5, std_max=5.0, target_entropy=None,
-                 seed=0, temp_warmup_steps=-1):
+                 seed=0, temp_warmup_steps=-1, optimizers=None):
+        """optimizers: optional {"actor"|"critic"|"temperature": make_optimizer kwargs (common/optimizers.py:6-13:
+        learning_rate, warmup_steps, cosine_decay_steps, weight_decay, clip_grad_norm)} overriding lr / warmup_steps."""
         if target_entropy is None:
             target_entropy = -act_dim / 2
         self.cfg = SerlAgentCfg(device, n_cam, H, W, state_dim, act_dim, batch, ensemble, hidden,
                                 bottleneck, sle_features, proprio_dim, warmup_steps, temp_warmup_steps, discount, tau,
                                 lr, dropout, std_min, std_max, target_entropy, seed)
+        for name, kw in (optimizers or {}).items():
+            i = TX_INDEX[name]
+            bad = set(kw) - {"learning_rate", "warmup_steps", "cosine_decay_steps", "weight_decay", "clip_grad_norm"}
+            if bad:
+                raise TypeError(f"make_optimizer() got unexpected keyword arguments {sorted(bad)}")
+            if kw.get("learning_rate") is not None:
+                self.cfg.tx_lr[i] = float(kw["learning_rate"])
+            if kw.get("warmup_steps") is not None:
+                self.cfg.tx_warmup[i] = int(kw["warmup_steps"]) + 1
+            if kw.get("cosine_decay_steps") is not None:
+                self.cfg.tx_cosine_steps[i] = int(kw["cosine_decay_steps"])
+            if kw.get("weight_decay") is not None:
+                self.cfg.tx_weight_decay_on[i], self.cfg.tx_weight_decay[i] = 1, float(kw["weight_decay"])
+            if kw.get("clip_grad_norm") is not None:
+                self.cfg.tx_clip_norm[i] = float(kw["clip_grad_norm"])
         self._h = C.c_void_p()
         self.L = _lib.lib()
         _lib.check(self.L.serl_agent_create(C.byref(self.cfg), C.byref(self._h)))
@@ -108,6 +125,13 @@ class AgentCore:
     def update_high_utd(self, batch, utd_ratio=1, noise=None):
         _lib.check(self.L.serl_agent_update_high_utd(self._h, C.byref(batch.cstruct), utd_ratio,
                                                      self._noise(noise), self._stream()))
+
+    def update(self, batch, networks=("actor", "critic", "temperature"), noise=None):
+        """SACAgent.update (sac.py:243-299): every selected loss at the same parameters, one optimizer step."""
+        bits = 0
+        for n in networks:
+            bits |= NET_BITS[n]
+        _lib.check(self.L.serl_agent_update(self._h, C.byref(batch.cstruct), bits, self._noise(noise), self._stream()))
 
     def read_info(self) -> dict:
         info = SerlInfo()

@@ -24,6 +24,19 @@ from .core import APPLY_ACTOR_TEMP, APPLY_CRITIC, TX_NAMES, AgentCore
 from .flax_tree import export_tree
 
 
+def lr_schedule(kw: dict, count: int) -> float:
+    """make_optimizer's learning-rate schedule (common/optimizers.py:14-30) at `count`."""
+    import math
+    peak, warm = float(kw.get("learning_rate", 3e-4)), int(kw.get("warmup_steps", 0) or 0)
+    if count < warm:
+        return peak * count / warm
+    cos = kw.get("cosine_decay_steps")
+    if cos is not None:
+        T = max(int(cos) - warm, 1)
+        return peak * 0.5 * (1.0 + math.cos(math.pi * min(count - warm, T) / T))
+    return peak
+
+
 class PendingInfo:
     """Info dict of the LAST update call; reading it synchronises the stream (the reference's jitted
     update returns device arrays that are also only materialised when logged)."""
@@ -37,10 +50,16 @@ class PendingInfo:
                 raise RuntimeError("info of an older update was overwritten; read it before the next update")
             r = self._agent.core.read_info()
             lr = {f"{n}_lr": r[f"{n}_lr"] for n in TX_NAMES}
-            out = {"critic": {k: r[k] for k in ("critic_loss", "predicted_qs", "target_qs")}}
-            if self._kind == "high_utd":
-                out["actor"] = {k: r[k] for k in ("actor_loss", "temperature", "entropy")}
-                out["temperature"] = {"temperature_loss": r["temperature_loss"]}
+            if isinstance(self._kind, frozenset):   # SACAgent.update: an info dict per network, {} for the skipped ones
+                nets = self._kind
+                out = {"critic": {k: r[k] for k in ("critic_loss", "predicted_qs", "target_qs")} if "critic" in nets else {},
+                       "actor": {k: r[k] for k in ("actor_loss", "temperature", "entropy")} if "actor" in nets else {},
+                       "temperature": {"temperature_loss": r["temperature_loss"]} if "temperature" in nets else {}}
+            else:
+                out = {"critic": {k: r[k] for k in ("critic_loss", "predicted_qs", "target_qs")}}
+                if self._kind == "high_utd":
+                    out["actor"] = {k: r[k] for k in ("actor_loss", "temperature", "entropy")}
+                    out["temperature"] = {"temperature_loss": r["temperature_loss"]}
             out.update(lr)
             self._val = out
         return self._val
@@ -81,7 +100,7 @@ class TrainStateView:
         out = {}
         for tx in TX_NAMES:
             out[tx] = {"count": self._a.core.step,
-                       "hyperparams": {"learning_rate": self._a.lr_at(self._a.core.step), "weight_decay": None},
+                       "hyperparams": {"learning_rate": self._a.lr_at(self._a.core.step, tx), "weight_decay": None},
                        "mu": export_tree(self._a.core, f"opt/{tx}/mu", self._a.image_keys),
                        "nu": export_tree(self._a.core, f"opt/{tx}/nu", self._a.image_keys)}
         return out
@@ -129,7 +148,9 @@ class DrQAgent:
                    temperature_init: float = 1.0, image_keys: Iterable[str] = ("image",),
                    discount: float = 0.95, soft_target_update_rate: float = 0.005,
                    target_entropy: Optional[float] = None, backup_entropy: bool = False,
-                   batch_size: int = 256, device: int = 0, learning_rate: float = 3e-4, **kwargs):
+                   batch_size: int = 256, device: int = 0, learning_rate: float = 3e-4,
+                   actor_optimizer_kwargs: dict = None, critic_optimizer_kwargs: dict = None,
+                   temperature_optimizer_kwargs: dict = None, **kwargs):
         """drq.py:104-242.  Only the configuration the reference's examples run is built natively:
         encoder_type="resnet-pretrained", use_proprio=True, REDQ subsample 2, tanh-squashed
         exp-parameterised policy, LayerNorm+tanh 256x256 MLPs (utils/launcher.py:79-116)."""
@@ -151,10 +172,15 @@ class DrQAgent:
         A = int(np.asarray(actions).shape[-1])
         if target_entropy is None:
             target_entropy = -A / 2  # drq.py:88-89
+        # drq.py:35-43: each optimizer = make_optimizer(learning_rate=3e-4) unless overridden (optimizers.py:6-13)
+        opts = {"actor": {"learning_rate": learning_rate, **(actor_optimizer_kwargs or {})},
+                "critic": {"learning_rate": learning_rate, **(critic_optimizer_kwargs or {})},
+                "temperature": {"learning_rate": learning_rate, **(temperature_optimizer_kwargs or {})}}
         core = AgentCore(device=device, n_cam=len(image_keys), H=H, W=W, state_dim=S, act_dim=A,
                          batch=batch_size, ensemble=critic_ensemble_size, discount=discount,
                          tau=soft_target_update_rate, lr=learning_rate, std_min=pk.get("std_min", 1e-5),
-                         std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed)
+                         std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed,
+                         optimizers={k: {"warmup_steps": 0, **v} for k, v in opts.items()})
         theta = pinit.init_theta(len(image_keys), H, W, S, A, seed=seed, temperature_init=temperature_init,
                                  ensemble=critic_ensemble_size)
         trunk = pinit.init_trunk(seed=seed)
@@ -165,11 +191,12 @@ class DrQAgent:
                       discount=discount, soft_target_update_rate=soft_target_update_rate,
                       target_entropy=target_entropy, backup_entropy=backup_entropy, image_keys=image_keys)
         agent = cls(core, image_keys, config, seed)
-        agent._lr, agent._warmup = learning_rate, 0
+        agent._opts = {k: {"warmup_steps": 0, **v} for k, v in opts.items()}
         return agent
 
-    def lr_at(self, count):
-        return self._lr * count / self._warmup if count < self._warmup else self._lr
+    def lr_at(self, count, tx="critic"):
+        """optimizers.py:14-30: warm-up -> constant, or warm-up -> cosine decay."""
+        return lr_schedule(self._opts[tx], count)
 
     def load_trunk_params(self, pretrained: Dict[str, dict]):
         """utils/train_utils.py:69-130: patch the frozen ResNet-10 trunk from the pretrained pickle's
@@ -256,6 +283,8 @@ class DrQAgent:
     def _slot_batch(self, slot, B):
         c = self.core.cfg
         if self._slot_batches[slot] is None or self._slot_batches[slot].batch != B:
+            if self._sched is not None:     # the side stream may still be reading the buffers about to be freed
+                self._sched.side_stream.synchronize()
             self._slot_batches[slot] = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
         return self._slot_batches[slot]
 
@@ -297,9 +326,19 @@ class DrQAgent:
         if nxt is not None and nxt.batch_size == B:
             s2 = 1 - slot
             self._produce(nxt, s2, self._slot_batch(s2, B))
-            self._prefetched = (self._lazy_key(nxt), s2)
+            # (the parts are kept alive with the key: a freed index array's address could otherwise be reused by a
+            # later sample and false-match)
+            self._prefetched = (self._lazy_key(nxt), s2, list(nxt.parts))
         self.core.select_slot(slot)
         return slot, db
+
+    def _sync_side_stream(self):
+        """The non-pipelined paths run the trunk on the caller's stream and share the trunk workspace with a prefetched
+        encode_slot that may still be in flight on the side stream: order behind it and drop the prefetch (it would
+        otherwise be consumed after its workspace was overwritten)."""
+        if self._sched is not None:
+            torch.cuda.current_stream(self.core.device).wait_stream(self._sched.side_stream)
+            self._prefetched = None
 
     # ------------------------------------------------------------------ updates
     def update_critics(self, batch, *, pmap_axis: Optional[str] = None, noise=None, crops=None):
@@ -312,6 +351,7 @@ class DrQAgent:
             self._sched.consumed(slot)
         else:
             db = self.prepare(batch, crops)
+            self._sync_side_stream()
             self.core.update_critics(db, noise)
         self._update_serial += 1
         return self, PendingInfo(self, "critics", self._update_serial)
@@ -334,35 +374,28 @@ class DrQAgent:
             db = self.prepare(batch, crops)
             assert db.batch % utd_ratio == 0, \
                 f"Batch size {db.batch} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
+            self._sync_side_stream()
             self.core.update_high_utd(db, utd_ratio, noise)
         self._update_serial += 1
         return self, PendingInfo(self, "high_utd", self._update_serial)
 
     def update(self, batch, *, pmap_axis: str = None,
                networks_to_update: FrozenSet[str] = frozenset({"actor", "critic", "temperature"}), noise=None):
-        """sac.py:243-299 on an already augmented batch.  Supported subsets: {"critic"} and
-        {"actor","temperature"} (the two the reference's learners use)."""
+        """sac.py:243-299 on an already augmented batch: every loss in `networks_to_update` is evaluated at the same
+        parameters, all three optimizers step once (zero gradients for the others), target EMA iff "critic" is in the
+        set.  Any non-empty subset works, the default (all three) included."""
         loss_keys = {"actor", "critic", "temperature"}
         assert set(networks_to_update).issubset(loss_keys), f"Invalid gradient steps: {networks_to_update}"
+        assert len(networks_to_update) > 0, "networks_to_update is empty"
         if isinstance(batch, DeviceBatch):
             db = batch
         else:  # identity crop (offset 4 = centre of the 9 shifts): the batch is taken as already augmented
             n = batch.batch_size if isinstance(batch, LazyBatch) else int(batch["rewards"].shape[0])
             db = self.prepare(batch, crops=(np.full((n, 2), 4, np.int32),) * 2)
-        self.core.begin_update()
-        self.core.encode(db)
-        if set(networks_to_update) == {"critic"}:
-            self.core.critic_grads(0, db.batch, db.batch, noise)
-            self.core.apply(APPLY_CRITIC)
-            kind = "critics"
-        elif set(networks_to_update) == {"actor", "temperature"}:
-            self.core.actor_grads(db.batch, noise)
-            self.core.apply(APPLY_ACTOR_TEMP)
-            kind = "high_utd"
-        else:
-            raise NotImplementedError(f"networks_to_update={set(networks_to_update)}")
+        self._sync_side_stream()
+        self.core.update(db, tuple(networks_to_update), noise)
         self._update_serial += 1
-        return self, PendingInfo(self, kind, self._update_serial)
+        return self, PendingInfo(self, frozenset(networks_to_update), self._update_serial)
 
     # ------------------------------------------------------------------ acting
     def sample_actions(self, observations, *, seed=None, argmax: bool = False, **kwargs):
@@ -374,6 +407,7 @@ class DrQAgent:
         batched = st.ndim == 3
         n = st.shape[0] if batched else 1
         frames = np.stack([np.asarray(observations[k], np.uint8).reshape(n, c.H, c.W, 3) for k in self.image_keys])
+        self._sync_side_stream()
         f = torch.from_numpy(frames).to(self.core.device)
         s = torch.from_numpy(st.reshape(n, -1)).to(self.core.device)
         eps = None

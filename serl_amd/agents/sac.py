@@ -42,8 +42,6 @@ class SACAgent(DrQAgent):
         ao = {"learning_rate": 3e-4, "warmup_steps": 2000, **(actor_optimizer_kwargs or {})}     # sac.py:333-336
         co = {"learning_rate": 3e-4, "warmup_steps": 2000, **(critic_optimizer_kwargs or {})}    # sac.py:337-340
         to = {"learning_rate": 3e-4, **(temperature_optimizer_kwargs or {})}                     # sac.py:341-343
-        if not (ao["learning_rate"] == co["learning_rate"] == to["learning_rate"]) or ao["warmup_steps"] != co["warmup_steps"]:
-            raise NotImplementedError("actor/critic optimizers must share learning rate and warm-up")
         seed = int(np.asarray(rng).reshape(-1)[-1]) if not isinstance(rng, int) else rng
         S = int(np.asarray(observations).shape[-1])
         A = int(np.asarray(actions).shape[-1])
@@ -53,7 +51,8 @@ class SACAgent(DrQAgent):
                          ensemble=critic_ensemble_size, discount=discount, tau=soft_target_update_rate,
                          lr=ao["learning_rate"], warmup_steps=int(ao["warmup_steps"]),
                          temp_warmup_steps=int(to.get("warmup_steps", 0)), std_min=pk.get("std_min", 1e-5),
-                         std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed)
+                         std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed,
+                         optimizers={"actor": ao, "critic": co, "temperature": {"warmup_steps": 0, **to}})
         theta = pinit.init_theta(0, 0, 0, S, A, seed=seed, temperature_init=temperature_init, ensemble=critic_ensemble_size)
         for sec in ("params", "target_params"):
             core.load_flat(sec, theta)
@@ -61,7 +60,7 @@ class SACAgent(DrQAgent):
                       discount=discount, soft_target_update_rate=soft_target_update_rate,
                       target_entropy=target_entropy, backup_entropy=backup_entropy)
         agent = cls(core, (), config, seed)
-        agent._lr, agent._warmup = ao["learning_rate"], int(ao["warmup_steps"])
+        agent._opts = {"actor": ao, "critic": co, "temperature": {"warmup_steps": 0, **to}}
         return agent
 
     # ------------------------------------------------------------------ batches (flat observations, no augmentation)

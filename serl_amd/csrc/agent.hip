@@ -62,7 +62,7 @@ constexpr int kScalars = 32;
 // scalar slots (device): local sums that are all-reduced together with the gradients
 enum { S_D2 = 0, S_Q = 1, S_Y = 2, S_QPI = 3, S_LOGP = 4, S_LOGP_NEXT = 5 };
 // aux slots (device, rank-local, never all-reduced)
-enum { X_ALPHA = 0, X_TGRAD = 1, X_N = 8 };
+enum { X_ALPHA = 0, X_TGRAD = 1, X_NORM2 = 2 /* [2] */, X_N = 8 };
 // info accumulator slots
 enum { I_CL = 0, I_PQ, I_TQ, I_AL, I_TEMP, I_ENT, I_TL, I_N };
 // adam_ema_kernel's info rider (heads.hip) indexes these slots by number
@@ -113,7 +113,7 @@ struct serl_agent {
   int64_t step = 0;
   uint64_t noise_ctr = 0;
   serl_info last_info{};
-  float lr_last = 0.f, lr_t_last = 0.f;
+  float lr_last[3] = {0.f, 0.f, 0.f};   // learning rates of the last apply, indexed by SERL_TX_*
   int last_global = 0;
   bool info_reset = true;
   // batch-sharded data parallelism: this rank's local batch is rows [shard_off, shard_off + local) of a global
@@ -691,10 +691,18 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
   }
 }
 
-float lr_at(const serl_agent_cfg& c, int64_t count, bool temperature = false) {  // optimizers.py:23-30
-  const int warm = (temperature && c.temp_warmup_steps >= 0) ? c.temp_warmup_steps : c.warmup_steps;
-  if (count < warm) return c.lr * (float)count / (float)warm;
-  return c.lr;
+// learning rate of optimizer `tx` at `count` (optimizers.py:14-30): warm-up -> constant, or warm-up -> cosine decay
+float lr_at(const serl_agent_cfg& c, int64_t count, int tx) {
+  const float peak = c.tx_lr[tx] > 0.f ? c.tx_lr[tx] : c.lr;
+  int warm = (tx == SERL_TX_TEMPERATURE && c.temp_warmup_steps >= 0) ? c.temp_warmup_steps : c.warmup_steps;
+  if (c.tx_warmup[tx] > 0) warm = c.tx_warmup[tx] - 1;
+  if (count < warm) return (float)((double)peak * (double)count / (double)warm);   // linear_schedule(0, peak, warm)
+  if (c.tx_cosine_steps[tx] > 0) {   // optax.warmup_cosine_decay_schedule(0, peak, warm, decay_steps, end_value = 0)
+    const double T = (double)std::max(c.tx_cosine_steps[tx] - warm, 1);
+    const double k = std::min((double)(count - warm), T);
+    return (float)((double)peak * 0.5 * (1.0 + std::cos(M_PI * k / T)));
+  }
+  return peak;
 }
 
 }  // namespace
@@ -710,6 +718,17 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   SERL_REQUIRE(cfg->proprio_dim == 64, "proprio_dim must be 64");
   SERL_REQUIRE(cfg->sle_features == 8, "sle_features must be 8");
   SERL_REQUIRE(cfg->batch >= 1 && cfg->ensemble >= 2 && cfg->state_dim >= 1 && cfg->act_dim >= 1 && cfg->act_dim <= 64, "bad dims");
+  for (int t = 0; t < 3; ++t) {
+    // adamw decays EVERY leaf of the tree the optimizer is given (common.py:142-147 passes the full params), i.e. it
+    // would un-freeze the pretrained trunk and make the online and target trunks differ, which the two-pass trunk
+    // evaluation relies on being equal: supported for the state-only agent only
+    if (cfg->tx_weight_decay_on[t] && cfg->n_cam > 0) {
+      set_error("weight_decay on a pixel agent would decay the frozen pretrained trunk (optimizers.py:39-42 over the full tree): unsupported");
+      return SERL_ERR_UNSUPPORTED;
+    }
+    SERL_REQUIRE(cfg->tx_lr[t] >= 0.f && cfg->tx_warmup[t] >= 0 && cfg->tx_cosine_steps[t] >= 0 && cfg->tx_clip_norm[t] >= 0.f,
+                 "bad optimizer options for optimizer %d", t);
+  }
   SERL_HIP(hipSetDevice(cfg->device));
   serl_agent* a = new serl_agent();
   a->cfg = *cfg;
@@ -1007,29 +1026,38 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
 
 int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) {
   SERL_REQUIRE(a, "NULL agent");
-  SERL_REQUIRE(which == SERL_APPLY_CRITIC || which == SERL_APPLY_ACTOR_TEMP, "bad `which`");
+  SERL_REQUIRE(which >= 1 && which <= 7, "bad `which` (a non-empty set of SERL_NET_* bits)");
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   hipStream_t st = (hipStream_t)stream;
   SERL_HIP(hipSetDevice(c.device));
-  const bool crit = which == SERL_APPLY_CRITIC;
+  const bool crit = which & SERL_NET_CRITIC, act = which & SERL_NET_ACTOR, temp = which & SERL_NET_TEMPERATURE;
   AdamArgs ad{};
   ad.theta = a->theta; ad.theta_target = a->theta_t;
   ad.P = o.P; ad.Pc = o.Pc; ad.Pa0 = o.Pa0; ad.Pa1 = o.Pa1;
   ad.g_critic = a->Gc; ad.g_actor = a->Ga;
   ad.m_c = a->m_c; ad.v_c = a->v_c; ad.m_a = a->m_a; ad.v_a = a->v_a; ad.m_t = a->m_t; ad.v_t = a->v_t;
   ad.sum_logp_next = a->SC + S_LOGP_NEXT; ad.temp_grad_out = a->aux + X_TGRAD;
-  ad.critic_on = crit ? 1 : 0; ad.actor_on = crit ? 0 : 1; ad.temp_on = crit ? 0 : 1;
-  const float lr = lr_at(c, a->step);  // all three txs share count == step and the same schedule
-  ad.lr_c = ad.lr_a = lr;
-  ad.lr_t = lr_at(c, a->step, true);
+  ad.critic_on = crit ? 1 : 0; ad.actor_on = act ? 1 : 0; ad.temp_on = temp ? 1 : 0;
+  ad.ema_on = crit ? 1 : 0;   // sac.py:284-285
+  // all three txs share count == step (common.py:136-168 steps every optimizer on every update)
+  ad.lr_a = lr_at(c, a->step, SERL_TX_ACTOR);
+  ad.lr_c = lr_at(c, a->step, SERL_TX_CRITIC);
+  ad.lr_t = lr_at(c, a->step, SERL_TX_TEMPERATURE);
   const int64_t t = a->step + 1;
   ad.bc1 = 1.0f - powf(0.9f, (float)t);
   ad.bc2 = 1.0f - powf(0.999f, (float)t);
   ad.tau = c.tau; ad.target_entropy = c.target_entropy;
   ad.inv_batch = a->last_global > 0 ? 1.0f / (float)a->last_global : 0.f;
   ad.frozen = a->trunk; ad.frozen_target = a->trunk_t; ad.n_frozen = a->trunk_count;  // common.py:124-134 covers every leaf
-  ad.info_mode = crit ? 1 : 2;
+  ad.wd_a = c.tx_weight_decay_on[SERL_TX_ACTOR] ? c.tx_weight_decay[SERL_TX_ACTOR] : 0.f;
+  ad.wd_c = c.tx_weight_decay_on[SERL_TX_CRITIC] ? c.tx_weight_decay[SERL_TX_CRITIC] : 0.f;
+  ad.wd_t = c.tx_weight_decay_on[SERL_TX_TEMPERATURE] ? c.tx_weight_decay[SERL_TX_TEMPERATURE] : 0.f;
+  ad.clip_a = c.tx_clip_norm[SERL_TX_ACTOR]; ad.clip_c = c.tx_clip_norm[SERL_TX_CRITIC]; ad.clip_t = c.tx_clip_norm[SERL_TX_TEMPERATURE];
+  ad.norm2 = a->aux + X_NORM2;
+  if ((ad.clip_c > 0.f && crit) || (ad.clip_a > 0.f && act))
+    RC(grad_norm2(a->Gc, o.Pc, a->Ga, o.Pa1 - o.Pa0, a->aux + X_NORM2, st));
+  ad.info_mode = (crit ? 1 : 0) | ((act || temp) ? 2 : 0);
   ad.info_reset = (crit && a->info_reset) ? 1 : 0;
   if (crit) a->info_reset = false;
   ad.scalars = a->SC; ad.alpha = a->aux + X_ALPHA; ad.info_acc = a->info_acc;
@@ -1037,18 +1065,29 @@ int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) 
   ad.inv_eb = a->last_global > 0 ? 1.0f / ((float)c.ensemble * (float)a->last_global) : 0.f;
   RC(adam_ema(ad, st));
   a->step += 1;
-  a->lr_last = lr;
-  a->lr_t_last = ad.lr_t;
+  a->lr_last[SERL_TX_ACTOR] = ad.lr_a; a->lr_last[SERL_TX_CRITIC] = ad.lr_c; a->lr_last[SERL_TX_TEMPERATURE] = ad.lr_t;
   return SERL_OK;
 }
 
 int serl_agent_grad_view(serl_agent* a, int which, float** dev_ptr, int64_t* count) {
   SERL_REQUIRE(a && dev_ptr && count, "NULL argument");
+  SERL_REQUIRE(which >= 1 && which <= 7, "bad `which`");
   const Offs& o = a->o;
-  if (which == SERL_APPLY_CRITIC) { *dev_ptr = a->Gc; *count = o.Pc + kScalars; }
-  else if (which == SERL_APPLY_ACTOR_TEMP) { *dev_ptr = a->SC; *count = kScalars + (o.Pa1 - o.Pa0); }
-  else { set_error("bad `which`"); return SERL_ERR_INVALID; }
+  const bool crit = which & SERL_NET_CRITIC, at = which & (SERL_NET_ACTOR | SERL_NET_TEMPERATURE);
+  if (crit && at) { *dev_ptr = a->G; *count = o.Pc + kScalars + (o.Pa1 - o.Pa0); }
+  else if (crit) { *dev_ptr = a->Gc; *count = o.Pc + kScalars; }
+  else { *dev_ptr = a->SC; *count = kScalars + (o.Pa1 - o.Pa0); }
   return SERL_OK;
+}
+
+int serl_agent_update(serl_agent* a, const serl_batch* batch, int nets, const serl_noise* noise, void* stream) {
+  SERL_REQUIRE(a && batch, "NULL argument");
+  SERL_REQUIRE(nets >= 1 && nets <= 7, "Invalid gradient steps: %d", nets);   // sac.py:272-274
+  RC(serl_agent_begin_update(a, stream));
+  RC(serl_agent_encode(a, batch, stream));
+  if (nets & SERL_NET_CRITIC) RC(serl_agent_critic_grads(a, 0, batch->batch, batch->batch, noise, 0, stream));
+  if (nets & (SERL_NET_ACTOR | SERL_NET_TEMPERATURE)) RC(serl_agent_actor_grads(a, batch->batch, noise, stream));
+  return serl_agent_apply(a, nets, 1.0f, stream);
 }
 
 int serl_agent_update_critics(serl_agent* a, const serl_batch* batch, const serl_noise* noise, void* stream) {
@@ -1083,8 +1122,8 @@ int serl_agent_read_info(serl_agent* a, serl_info* out, void* stream) {
   out->critic_loss = acc[I_CL]; out->predicted_qs = acc[I_PQ]; out->target_qs = acc[I_TQ];
   out->actor_loss = acc[I_AL]; out->temperature = acc[I_TEMP]; out->entropy = acc[I_ENT];
   out->temperature_loss = acc[I_TL];
-  out->actor_lr = out->critic_lr = a->lr_last;
-  out->temperature_lr = a->lr_t_last;
+  out->actor_lr = a->lr_last[SERL_TX_ACTOR]; out->critic_lr = a->lr_last[SERL_TX_CRITIC];
+  out->temperature_lr = a->lr_last[SERL_TX_TEMPERATURE];
   return SERL_OK;
 }
 

@@ -96,8 +96,14 @@ struct AdamArgs {
   float* temp_grad_out;        // device scalar (debug/export)
   int critic_on, actor_on, temp_on;
   float lr_c, lr_a, lr_t, bc1, bc2, tau, target_entropy, inv_batch;
-  // frozen (trunk) leaves appended to the index space when critic_on: target EMA only (common.py:124-134)
-  const float* frozen; float* frozen_target; long n_frozen;
+  // target EMA (common.py:124-134) runs when ema_on; optimizers with *_on == 0 step with a zero gradient
+  int ema_on;
+  // optional make_optimizer branches (optimizers.py:32-46); all zero = plain adam
+  float wd_c, wd_a, wd_t;           // adamw weight decay of each optimizer (applies to EVERY leaf of the tree)
+  float clip_c, clip_a, clip_t;     // clip_by_global_norm thresholds (<= 0: none)
+  const float* norm2;               // device [2]: squared global norm of g_critic / g_actor (when a clip is active)
+  // frozen (trunk) leaves appended to the index space: target EMA, and weight decay if any optimizer has one
+  float* frozen; float* frozen_target; long n_frozen;
   // info rider: 0 = none, 1 = critic step, 2 = actor/temperature step.  Slot order of `scalars` / `info_acc` as in
   // agent.hip (S_* / I_* enums); info_acc has 8 floats.
   int info_mode, info_reset;
@@ -105,6 +111,8 @@ struct AdamArgs {
   float info_w, inv_eb;
 };
 int adam_ema(const AdamArgs& a, hipStream_t stream);
+// out[0] = sum g_critic^2 over [0, nc), out[1] = sum g_actor^2 over [0, na) (deterministic single-block reduction)
+int grad_norm2(const float* g_critic, long nc, const float* g_actor, long na, float* out, hipStream_t stream);
 // kind 0: N(0,1) f32, 1: keep-mask u8.  The tensor is [planes][rows_local][row_elems]; the value of an element is a
 // hash of its position in the GLOBAL tensor [planes][rows_global][row_elems] (rows row_offset.. of it), so that a
 // batch-sharded job draws the same noise for a sample whichever rank owns it (rows_global == 0: local == global)

@@ -800,13 +800,14 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
   if (i == 0 && a.info_mode) {  // info dict of this step (riding along: one launch less on the chain)
     const float* sc = a.scalars;
     float* acc = a.info_acc;
-    if (a.info_mode == 1) {  // critic step (sac.py:118-191); weighted mean over UTD minibatches
+    if (a.info_mode & 1) {  // critic step (sac.py:118-191); weighted mean over UTD minibatches
       if (a.info_reset)
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
       acc[0] += a.info_w * sc[0] * a.inv_eb;   // critic_loss
       acc[1] += a.info_w * sc[1] * a.inv_eb;   // predicted_qs
       acc[2] += a.info_w * sc[2] * a.inv_batch;  // target_qs
-    } else {  // actor + temperature step (sac.py:193-234)
+    }
+    if (a.info_mode & 2) {  // actor + temperature step (sac.py:193-234)
       const float alpha = a.alpha[0];
       acc[3] = -(sc[3] - alpha * sc[4]) * a.inv_batch;  // actor_loss
       acc[4] = alpha;                                   // temperature
@@ -814,16 +815,26 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
       acc[6] = alpha * (-sc[5] * a.inv_batch - a.target_entropy);  // temperature_loss
     }
   }
-  if (i >= a.P) {  // frozen-trunk leaves: no optimizer touches them, the target EMA still covers them
+  // adamw (optimizers.py:39-42): every optimizer with a weight decay adds -lr*wd*p on EVERY leaf of the tree
+  const float wd_total = a.lr_c * a.wd_c + a.lr_a * a.wd_a + a.lr_t * a.wd_t;
+  if (i >= a.P) {  // frozen-trunk leaves: no gradient ever reaches them; weight decay and the target EMA still do
     const long k = i - a.P;
-    if (a.critic_on && k < a.n_frozen) a.frozen_target[k] = a.frozen[k] * a.tau + a.frozen_target[k] * (1.f - a.tau);
+    if (k < a.n_frozen) {
+      float p = a.frozen[k];
+      if (wd_total != 0.f) { p -= wd_total * p; a.frozen[k] = p; }
+      if (a.ema_on) a.frozen_target[k] = p * a.tau + a.frozen_target[k] * (1.f - a.tau);
+    }
     return;
   }
+  // clip_by_global_norm (optimizers.py:36-37): g <- g * max_norm / ||g|| when ||g|| >= max_norm
+  float cs_c = 1.f, cs_a = 1.f;
+  if (a.clip_c > 0.f && a.critic_on) { const float n = sqrtf(a.norm2[0]); if (!(n < a.clip_c)) cs_c = a.clip_c / n; }
+  if (a.clip_a > 0.f && a.actor_on) { const float n = sqrtf(a.norm2[1]); if (!(n < a.clip_a)) cs_a = a.clip_a / n; }
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  float p = a.theta[i];
+  const float p0 = a.theta[i];
   float ua = 0.f, uc = 0.f, ut = 0.f;
   if (i < a.Pc) {
-    const float g = a.critic_on ? a.g_critic[i] : 0.f;
+    const float g = a.critic_on ? a.g_critic[i] * cs_c : 0.f;
     const float m = b1 * a.m_c[i] + (1.f - b1) * g;
     const float v = b2 * a.v_c[i] + (1.f - b2) * g * g;
     a.m_c[i] = m; a.v_c[i] = v;
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
   }
   if (i >= a.Pa0 && i < a.Pa1) {
     const long k = i - a.Pa0;
-    const float g = a.actor_on ? a.g_actor[k] : 0.f;
+    const float g = a.actor_on ? a.g_actor[k] * cs_a : 0.f;
     const float m = b1 * a.m_a[k] + (1.f - b1) * g;
     const float v = b2 * a.v_a[k] + (1.f - b2) * g * g;
     a.m_a[k] = m; a.v_a[k] = v;
@@ -841,22 +852,49 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
     float g = 0.f;
     if (a.temp_on) {
       const float H = -a.sum_logp_next[0] * a.inv_batch;
-      g = (1.f / (1.f + expf(-p))) * (H - a.target_entropy);
+      g = (1.f / (1.f + expf(-p0))) * (H - a.target_entropy);
       a.temp_grad_out[0] = g;
+      if (a.clip_t > 0.f && !(fabsf(g) < a.clip_t)) g = g * a.clip_t / fabsf(g);
     }
     const float m = b1 * a.m_t[0] + (1.f - b1) * g;
     const float v = b2 * a.v_t[0] + (1.f - b2) * g * g;
     a.m_t[0] = m; a.v_t[0] = v;
     ut = -a.lr_t * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
   }
-  p = p + ((ua + uc) + ut);
+  // optax.adamw: -lr * (adam direction + wd * p); the three optimizers' updates are summed (common.py:161-164)
+  if (a.wd_a != 0.f) ua -= a.lr_a * a.wd_a * p0;
+  if (a.wd_c != 0.f) uc -= a.lr_c * a.wd_c * p0;
+  if (a.wd_t != 0.f) ut -= a.lr_t * a.wd_t * p0;
+  const float p = p0 + ((ua + uc) + ut);
   a.theta[i] = p;
-  if (a.critic_on) a.theta_target[i] = p * a.tau + a.theta_target[i] * (1.f - a.tau);
+  if (a.ema_on) a.theta_target[i] = p * a.tau + a.theta_target[i] * (1.f - a.tau);
 }
 
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
   ProfScope prof("adam_ema", stream);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P + (a.critic_on ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
+  const bool frozen = a.n_frozen > 0 && (a.ema_on || a.wd_c != 0.f || a.wd_a != 0.f || a.wd_t != 0.f);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P + (frozen ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// squared global norms of the two gradient ranges (clip_by_global_norm): one 1024-thread block per range, fp64 partials
+__global__ __launch_bounds__(1024) void grad_norm2_kernel(const float* gc, long nc, const float* ga, long na, float* out) {
+  const float* g = blockIdx.x ? ga : gc;
+  const long n = blockIdx.x ? na : nc;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
+  __shared__ double red[1024];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
+}
+int grad_norm2(const float* g_critic, long nc, const float* g_actor, long na, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(grad_norm2_kernel, dim3(2), dim3(1024), 0, stream, g_critic, nc, g_actor, na, out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -24,6 +24,26 @@ CASES = {
     "drq_128": (O.Config(image_keys=("front", "wrist"), H=128, W=128, S=24, A=6), 4, [("critics",), ("high_utd", 1)]),
     # one camera (the literal BASELINE.json configs[1] wording), non-square
     "drq_one_cam": (O.Config(image_keys=("image",), H=128, W=64, S=7, A=4), 6, [("high_utd", 1), ("critics",)]),
+    # SACAgent.update (sac.py:243-299) with the default networks_to_update (all three losses at the same parameters, one
+    # optimizer step) and other subsets
+    "drq_update_subsets": (O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3), 6,
+                           [("update", ("actor", "critic", "temperature")), ("update", ("critic", "actor")),
+                            ("update", ("temperature",)), ("critics",), ("update", ("actor",))]),
+    # make_optimizer's other branches (optimizers.py:14-21,36-37): warm-up -> cosine decay, clip_by_global_norm
+    "drq_optimizers": (O.Config(image_keys=("front",), H=64, W=64, S=5, A=3,
+                                opt={"critic": {"learning_rate": 1e-3, "warmup_steps": 3, "cosine_decay_steps": 6, "clip_grad_norm": 0.5},
+                                     "actor": {"warmup_steps": 2}, "temperature": {"clip_grad_norm": 0.01, "learning_rate": 1e-2}}), 6,
+                       [("critics",), ("update", ("actor", "critic", "temperature")), ("high_utd", 2), ("critics",), ("critics",), ("critics",)]),
+    # state-only SAC exactly as the reference's make_sac_agent builds it (launcher.py:50-76: warm-up 2000 for actor and
+    # critic, none for the temperature) ...
+    "sac_state": (O.Config(image_keys=(), S=10, A=4, discount=0.99, warmup=2000, temp_warmup=0), 8,
+                  [("high_utd", 2), ("update", ("actor", "critic", "temperature")), ("high_utd", 1)]),
+    # ... and with adamw / clipping / cosine decay (optimizers.py:39-42)
+    "sac_state_adamw": (O.Config(image_keys=(), S=10, A=4, discount=0.99,
+                                 opt={"actor": {"weight_decay": 0.01, "warmup_steps": 2},
+                                      "critic": {"weight_decay": 0.003, "warmup_steps": 0, "clip_grad_norm": 1.0},
+                                      "temperature": {"cosine_decay_steps": 5}}), 8,
+                        [("high_utd", 2), ("update", ("actor", "critic", "temperature")), ("high_utd", 1), ("update", ("critic",))]),
 }
 
 

@@ -70,7 +70,8 @@ def test_adam_with_schedule_matches_torch_optim():
     name = "actor/w2"
     p = torch.nn.Parameter(st.params[name].clone())
     opt = torch.optim.Adam([p], lr=cfg.lr, betas=(0.9, 0.999), eps=1e-8)
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda t: min(1.0, t / cfg.warmup))
+    # (the scheduled rate is a float32 value, as optax.inject_hyperparams stores it)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda t: float(np.float32(cfg.lr * min(1.0, t / cfg.warmup))) / cfg.lr)
     rng = np.random.default_rng(0)
     ref_other = {k: v.clone() for k, v in st.params.items()}
     for step in range(9):

@@ -31,8 +31,10 @@ def _run_oracle(cfg, steps, param_seed):
         b, n = RR.oracle_batch_and_noise(cfg, step, torch.float64)
         if step["kind"] == "critics":
             info, _ = O.update_critics(st, b, n)
-        else:
+        elif step["kind"] == "high_utd":
             info, _ = O.update_high_utd(st, b, n, step["utd"])
+        else:
+            info = O.update(st, b, n, step["nets"])
         infos.append(info)
     return st, infos
 
@@ -49,12 +51,19 @@ def test_oracle_reproduces_the_reference_golden(path):
     g = G.unpack(np.load(path))
     cfg = g["cfg"]
     st, infos = _run_oracle(cfg, g["steps"], g["meta"]["param_seed"])
+    sched = O.TrainState(cfg, {}, {}, torch.float64)
+    st_counts, c = [], 0
+    for step in g["steps"]:       # optimizer count before the LAST optimizer step of each call
+        c += {"critics": 1, "update": 1}.get(step["kind"], step["utd"] + 1)
+        st_counts.append(c - 1)
     for i, (info, step) in enumerate(zip(infos, g["steps"])):
         for k, v in info.items():
             r = step["info"][k]
             assert abs(v - r) <= F64_TOL * max(1.0, abs(r)), (i, k, v, r)
-        for tx in O.TX_NAMES:   # the reference logs the (float32) learning rate of every optimizer
-            assert abs(step["info"][f"{tx}_lr"] - np.float32(cfg.lr)) < 1e-12
+        # the reference logs the (float32) learning rate each optimizer used: schedule(count before the step)
+        count = st_counts[i]
+        for tx in O.TX_NAMES:
+            assert abs(step["info"][f"{tx}_lr"] - np.float32(sched.lr_at(count, tx))) < 1e-12, (i, tx)
     assert st.step == g["meta"]["final_step"]
     worst = 0.0
     for sec, tree in _oracle_sections(st).items():
@@ -66,7 +75,7 @@ def test_oracle_reproduces_the_reference_golden(path):
 
 
 def test_golden_fixtures_exist():
-    assert len(GOLDEN) >= 3, "tests/golden/update_*.npz missing: run tests/golden/make_golden_update.py in the build container"
+    assert len(GOLDEN) >= 7, "tests/golden/update_*.npz missing: run tests/golden/make_golden_update.py in the build container"
 
 
 needs_ref = pytest.mark.skipif(not RS.reference_available(), reason="/root/reference not present (GPU box)")
