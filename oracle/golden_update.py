@@ -70,11 +70,27 @@ def cfg_from_dict(d):
     return O.Config(**d)
 
 
+def _jsonable(t):
+    if isinstance(t, dict):
+        return {k: _jsonable(v) for k, v in t.items()}
+    return list(t)
+
+
+def shape_tree(t):
+    """nested dict of arrays / scalars -> nested dict of shape lists (the form stored in the golden's meta)"""
+    if isinstance(t, dict):
+        return {k: shape_tree(v) for k, v in t.items()}
+    return list(np.shape(t))
+
+
 def pack(res, param_seed, batch_seed):
     cfg = res["cfg"]
     out = {"meta": np.array(json.dumps({"cfg": cfg_to_dict(cfg), "B": res["B"],
                                         "schedule": [[s[0]] + [list(x) if isinstance(x, (tuple, list)) else x for x in s[1:]] for s in res["schedule"]],
-                                        "param_seed": param_seed, "batch_seed": batch_seed, "final_step": res["final"]["step"]}))}
+                                        "param_seed": param_seed, "batch_seed": batch_seed, "final_step": res["final"]["step"],
+                                        # shapes of the reference's agent.state.params / opt_states trees (flax state-dict form)
+                                        "param_tree": _jsonable(res["final"]["param_tree"]),
+                                        "opt_state_tree": _jsonable(res["final"]["opt_state_tree"])}))}
     for i, st in enumerate(res["steps"]):
         for k, v in st["batch"]["frames"].items():
             out[f"s{i}_crc_{k}"] = np.uint32(zlib.crc32(v.tobytes()))

@@ -97,12 +97,24 @@ class TrainStateView:
 
     @property
     def opt_states(self):
+        """{tx: InjectHyperparamsState} in flax's state-dict form (flax.serialization.to_state_dict: NamedTuples become
+        dicts of their fields, tuples dicts keyed '0', '1', ...).  Each reference tx is
+        optax.inject_hyperparams(chain([clip_by_global_norm], adam | adamw)) (common/optimizers.py:32-56):
+          {count, hyperparams: {learning_rate}, inner_state: {'0': <clip: {}>?, '<k>': {'0': {count, mu, nu}, '1': {} ...}}}
+        (non-numeric hyper-parameters such as weight_decay=None are not stored by optax)."""
         out = {}
+        step = np.int32(self._a.core.step)
         for tx in TX_NAMES:
-            out[tx] = {"count": self._a.core.step,
-                       "hyperparams": {"learning_rate": self._a.lr_at(self._a.core.step, tx), "weight_decay": None},
-                       "mu": export_tree(self._a.core, f"opt/{tx}/mu", self._a.image_keys),
-                       "nu": export_tree(self._a.core, f"opt/{tx}/nu", self._a.image_keys)}
+            kw = self._a._opts.get(tx, {})
+            adam = {"count": step, "mu": export_tree(self._a.core, f"opt/{tx}/mu", self._a.image_keys),
+                    "nu": export_tree(self._a.core, f"opt/{tx}/nu", self._a.image_keys)}
+            # optax.adam = chain(scale_by_adam, scale_by_learning_rate); adamw adds add_decayed_weights in between
+            inner_adam = {"0": adam, "1": {}} if kw.get("weight_decay") is None else {"0": adam, "1": {}, "2": {}}
+            stages = ([{}] if kw.get("clip_grad_norm") is not None else []) + [inner_adam]
+            hp = {"learning_rate": np.float32(self._a.lr_at(int(step), tx))}
+            if kw.get("weight_decay") is not None:
+                hp["weight_decay"] = np.float32(kw["weight_decay"])
+            out[tx] = {"count": step, "hyperparams": hp, "inner_state": {str(i): s for i, s in enumerate(stages)}}
         return out
 
     @property

@@ -5,9 +5,10 @@ The reference calls `flax.training.checkpoints.save_checkpoint(path, agent.state
 `flax.serialization.to_bytes(state)`: a msgpack map of the state's pytree fields (`step, params,
 target_params, opt_states, rng`; common/common.py:108-114) in which every ndarray is a msgpack ExtType(1)
 holding msgpack((shape, dtype.name, raw bytes)).  flax is not installable here, so this writer/reader
-restates that published format (UNVERIFIED against a flax install) -- the actor side of the reference can
-try `checkpoints.restore_checkpoint` on these files; `restore_checkpoint` below reads them back into the
-HIP agent (params, target_params, Adam moments, step).
+restates that published format; the TREE inside (parameter paths, the optax InjectHyperparamsState / chain /
+ScaleByAdamState nesting of `opt_states`) is checked against the state the reference's own code builds under the
+stand-ins of oracle/jaxshim (tests/test_reference_update.py).  `restore_checkpoint` below reads such files back into
+the HIP agent (params, target_params, Adam moments, step).
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ import msgpack
 import numpy as np
 
 from ..agents.core import TX_NAMES
-from ..agents.flax_tree import theta_paths, _trunk_paths
+from ..agents.flax_tree import theta_paths, trunk_owner, _trunk_paths
 
 _EXT_NDARRAY = 1
 
@@ -40,7 +41,7 @@ def _unpack_ext(code, data):
 
 def state_dict(agent) -> dict:
     st = agent.state
-    return {"step": np.int64(st.step), "params": st.params, "target_params": st.target_params,
+    return {"step": np.int32(st.step), "params": st.params, "target_params": st.target_params,
             "opt_states": st.opt_states, "rng": st.rng}
 
 
@@ -86,6 +87,19 @@ def restore_checkpoint(ckpt_dir_or_file: str, agent, step: Optional[int] = None,
     return load_state_dict(agent, sd)
 
 
+def _find_adam_state(node):
+    """The ScaleByAdamState {count, mu, nu} inside an InjectHyperparamsState / chain state dict (any nesting), or the
+    node itself for the flat {count, mu, nu} layout written by earlier versions of this module."""
+    if isinstance(node, dict):
+        if "mu" in node and "nu" in node:
+            return node
+        for v in node.values():
+            r = _find_adam_state(v)
+            if r is not None:
+                return r
+    return None
+
+
 def load_state_dict(agent, sd: dict):
     """Loads any of {params, target_params, opt_states, step} (flax-layout trees, e.g. a restored checkpoint or
     `agent.state.replace(...)` arguments) into the agent's HBM arena."""
@@ -99,11 +113,14 @@ def load_state_dict(agent, sd: dict):
         for leaf, paths in tp.items():
             core.set(section, leaf, _walk(tree, paths[0]))
         for leaf, sub in trunk.items():
-            core.set(section, leaf, _walk(tree, ("modules_actor", "encoder", f"encoder_{keys[0]}", "pretrained_encoder") + sub))
+            core.set(section, leaf, _walk(tree, ("modules_actor", "encoder", f"encoder_{trunk_owner(keys)}", "pretrained_encoder") + sub))
     if sd.get("opt_states") is not None:
         for tx in TX_NAMES:
+            adam = _find_adam_state(sd["opt_states"][tx])
+            if adam is None:
+                raise KeyError(f"opt_states['{tx}'] holds no ScaleByAdamState (mu / nu)")
             for mom in ("mu", "nu"):
-                tree = sd["opt_states"][tx][mom]
+                tree = adam[mom]
                 for leaf, paths in tp.items():
                     # leaves outside the optimizer's support are exact zeros; the C ABI accepts (and checks) them
                     core.set(f"opt/{tx}/{mom}", leaf, np.asarray(_walk(tree, paths[0]), np.float32))

@@ -85,7 +85,7 @@ def test_state_export_and_sample_actions(gpu):
     assert enc["encoder_front"]["pretrained_encoder"]["conv_init"]["kernel"].shape == (7, 7, 3, 64)
     assert enc["encoder_wrist"]["SpatialLearnedEmbeddings_0"]["kernel"].shape == (2, 2, 512, 8)
     assert enc["Dense_0"]["kernel"].shape == (S, 64)
-    assert p["modules_critic"]["critic_ensemble"]["Dense_0"]["kernel"].shape == (10, 2 * 256 + 64 + A, 256)
+    assert p["modules_critic"]["network"]["Dense_0"]["kernel"].shape == (10, 2 * 256 + 64 + A, 256)
     assert p["modules_actor"]["Dense_1"]["bias"].shape == (A,)
     assert p["modules_temperature"]["lagrange"].shape == ()
     tp = agent.state.target_params
