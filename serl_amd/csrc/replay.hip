@@ -68,6 +68,7 @@ struct Pcg64 {
 };
 
 constexpr int kRing = 8;           // staging slots for per-call index/crop parameters
+constexpr int kInsRing = 32;       // pinned staging slots for inserted transitions (one slot write each)
 constexpr int kRowsPerBlock = 32;  // output rows per workgroup in the gather/crop kernel
 
 }  // namespace serl
@@ -91,6 +92,16 @@ struct serl_rb {
   hipStream_t copy_stream = nullptr;
   hipEvent_t last_gather = nullptr;
   bool gather_pending = false;
+  // inserts are staged through a pinned ring and copied asynchronously on copy_stream: the caller's thread (the
+  // actor-facing server thread of data_store.py:104-106) holds the mutex for a host memcpy only, never for a stream
+  // synchronisation, so it cannot stall the learner thread's sample_indices / gather
+  uint8_t* ins_host = nullptr;
+  size_t ins_slot_bytes = 0;
+  hipEvent_t ins_done[serl::kInsRing] = {nullptr};
+  bool ins_used[serl::kInsRing] = {false};
+  int ins_next = 0;
+  hipEvent_t last_insert = nullptr;
+  bool insert_pending = false;
   // per-call parameter staging (pinned host + device), ring of kRing slots
   uint8_t* stage_host = nullptr;
   uint8_t* stage_dev = nullptr;
@@ -280,23 +291,38 @@ __global__ __launch_bounds__(256) void gather_packed_kernel(PackedArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------------
-static int wait_gathers(serl_rb* rb) {
+// An insert must not overwrite a slot that an in-flight gather may still read: the copy stream waits (on the device)
+// for the last enqueued gather.  Caller holds rb->mu.
+static int order_after_gathers(serl_rb* rb) {
   if (rb->gather_pending) {
-    SERL_HIP(hipEventSynchronize(rb->last_gather));
+    SERL_HIP(hipStreamWaitEvent(rb->copy_stream, rb->last_gather, 0));
     rb->gather_pending = false;
   }
   return SERL_OK;
 }
+// ... and a gather enqueued after an insert sees it: `stream` waits for the last insert's copies.  Caller holds rb->mu.
+static int order_after_inserts(serl_rb* rb, hipStream_t stream) {
+  if (rb->insert_pending) SERL_HIP(hipStreamWaitEvent(stream, rb->last_insert, 0));
+  return SERL_OK;
+}
 
-// writes slot `i` (record + one frame per camera) host -> HBM.  Caller holds rb->mu.
+// writes slot `i` (record + one frame per camera) host -> HBM through the pinned ring.  Caller holds rb->mu.
 static int write_slot(serl_rb* rb, int64_t i, const uint8_t* const* frames_host, const float* rec) {
   std::memcpy(&rb->rec_host[(size_t)i * rb->rec_len], rec, sizeof(float) * rb->rec_len);
-  SERL_HIP(hipMemcpyAsync(rb->rec + (size_t)i * rb->rec_len, rec, sizeof(float) * rb->rec_len,
-                          hipMemcpyHostToDevice, rb->copy_stream));
+  const int s = rb->ins_next;
+  rb->ins_next = (s + 1) % kInsRing;
+  if (rb->ins_used[s]) SERL_HIP(hipEventSynchronize(rb->ins_done[s]));  // ring wrapped: that copy is long done
+  uint8_t* h = rb->ins_host + (size_t)s * rb->ins_slot_bytes;
+  const size_t rec_bytes = sizeof(float) * rb->rec_len;
+  std::memcpy(h, rec, rec_bytes);
+  const size_t f0 = (rec_bytes + 255) & ~(size_t)255;
+  for (int c = 0; c < rb->n_cam; ++c) std::memcpy(h + f0 + (size_t)c * rb->frame_bytes, frames_host[c], rb->frame_bytes);
+  SERL_HIP(hipMemcpyAsync(rb->rec + (size_t)i * rb->rec_len, h, rec_bytes, hipMemcpyHostToDevice, rb->copy_stream));
   for (int c = 0; c < rb->n_cam; ++c)
-    SERL_HIP(hipMemcpyAsync(rb->frames[c] + (size_t)i * rb->frame_bytes, frames_host[c],
+    SERL_HIP(hipMemcpyAsync(rb->frames[c] + (size_t)i * rb->frame_bytes, h + f0 + (size_t)c * rb->frame_bytes,
                             rb->frame_bytes, hipMemcpyHostToDevice, rb->copy_stream));
-  SERL_HIP(hipStreamSynchronize(rb->copy_stream));
+  SERL_HIP(hipEventRecord(rb->ins_done[s], rb->copy_stream));
+  rb->ins_used[s] = true;
   rb->insert_index = (i + 1) % rb->cap;
   rb->size = rb->size + 1 < rb->cap ? rb->size + 1 : rb->cap;
   return SERL_OK;
@@ -314,9 +340,15 @@ static int copy_slot_to_head(serl_rb* rb, int64_t src) {
     SERL_HIP(hipMemcpyAsync(rb->frames[c] + (size_t)i * rb->frame_bytes,
                             rb->frames[c] + (size_t)src * rb->frame_bytes, rb->frame_bytes,
                             hipMemcpyDeviceToDevice, rb->copy_stream));
-  SERL_HIP(hipStreamSynchronize(rb->copy_stream));
   rb->insert_index = (i + 1) % rb->cap;
   rb->size = rb->size + 1 < rb->cap ? rb->size + 1 : rb->cap;
+  return SERL_OK;
+}
+
+// end of an insert: later gathers wait for its copies.  Caller holds rb->mu.
+static int finish_insert(serl_rb* rb) {
+  SERL_HIP(hipEventRecord(rb->last_insert, rb->copy_stream));
+  rb->insert_pending = true;
   return SERL_OK;
 }
 
@@ -391,6 +423,10 @@ int serl_rb_create(int device, int64_t capacity, int n_cam, int H, int W, int C,
   SERL_HIP(hipMalloc((void**)&rb->rec, (size_t)capacity * rb->rec_len * sizeof(float)));
   SERL_HIP(hipStreamCreateWithFlags(&rb->copy_stream, hipStreamNonBlocking));
   SERL_HIP(hipEventCreateWithFlags(&rb->last_gather, hipEventDisableTiming));
+  SERL_HIP(hipEventCreateWithFlags(&rb->last_insert, hipEventDisableTiming));
+  rb->ins_slot_bytes = ((sizeof(float) * rb->rec_len + 255) & ~(size_t)255) + (size_t)n_cam * rb->frame_bytes;
+  SERL_HIP(hipHostMalloc((void**)&rb->ins_host, rb->ins_slot_bytes * kInsRing, hipHostMallocDefault));
+  for (int s = 0; s < kInsRing; ++s) SERL_HIP(hipEventCreateWithFlags(&rb->ins_done[s], hipEventDisableTiming));
   rb->stage_slot_bytes = 1 << 16;  // idx (8B) + 2 crops (16B) per sample: up to ~2700 samples
   SERL_HIP(hipHostMalloc((void**)&rb->stage_host, rb->stage_slot_bytes * kRing, hipHostMallocDefault));
   SERL_HIP(hipMalloc((void**)&rb->stage_dev, rb->stage_slot_bytes * kRing));
@@ -412,6 +448,10 @@ int serl_rb_destroy(serl_rb* rb) {
   for (int s = 0; s < kRing; ++s)
     if (rb->stage_done[s]) (void)hipEventDestroy(rb->stage_done[s]);
   if (rb->last_gather) (void)hipEventDestroy(rb->last_gather);
+  if (rb->last_insert) (void)hipEventDestroy(rb->last_insert);
+  if (rb->ins_host) (void)hipHostFree(rb->ins_host);
+  for (int s = 0; s < kInsRing; ++s)
+    if (rb->ins_done[s]) (void)hipEventDestroy(rb->ins_done[s]);
   if (rb->copy_stream) (void)hipStreamDestroy(rb->copy_stream);
   delete rb;
   return SERL_OK;
@@ -448,7 +488,7 @@ int serl_rb_insert(serl_rb* rb, const uint8_t* const* obs_frames, const uint8_t*
   SERL_REQUIRE(rb->n_cam == 0 || (obs_frames && next_frames), "NULL frames");
   std::lock_guard<std::mutex> g(rb->mu);
   SERL_HIP(hipSetDevice(rb->device));
-  int rc = wait_gathers(rb);  // never overwrite a slot an in-flight gather may still read
+  int rc = order_after_gathers(rb);  // never overwrite a slot an in-flight gather may still read
   if (rc) return rc;
   const int T = rb->T, TS = rb->T * rb->S;
   if (rb->n_cam == 0) {  // ReplayBuffer.insert (replay_buffer.py:71-75): write at the head, advance, no bookkeeping
@@ -460,7 +500,8 @@ int serl_rb_insert(serl_rb* rb, const uint8_t* const* obs_frames, const uint8_t*
     r0[2 * TS + rb->A + 1] = mask;
     r0[2 * TS + rb->A + 2] = done ? 1.0f : 0.0f;
     rb->valid[rb->insert_index] = 1;
-    return write_slot(rb, rb->insert_index, nullptr, r0.data());
+    if ((rc = write_slot(rb, rb->insert_index, nullptr, r0.data()))) return rc;
+    return finish_insert(rb);
   }
   // wrap: re-insert the last T slots at the head as invalid (py:54-59)
   if (rb->insert_index == 0 && rb->cap == rb->size && !rb->first) {
@@ -489,7 +530,7 @@ int serl_rb_insert(serl_rb* rb, const uint8_t* const* obs_frames, const uint8_t*
   rb->valid[rb->insert_index] = 1;
   if ((rc = write_slot(rb, rb->insert_index, fr, rec.data()))) return rc;
   for (int t = 0; t < T; ++t) rb->valid[(rb->insert_index + t) % rb->size] = 0;  // py:87-89
-  return SERL_OK;
+  return finish_insert(rb);
 }
 
 int64_t serl_rb_len(serl_rb* rb) {
@@ -536,6 +577,28 @@ int serl_rb_sample_indices(serl_rb* rb, int batch, int64_t* host_idx_out) {
   return SERL_OK;
 }
 
+// The reference holds one lock across index draw and gather (data_store.py:108-111); here they are two calls (the
+// lazy / prefetched path), so an insert in between may have invalidated a drawn slot (the look-ahead invalidation of
+// memory_efficient_replay_buffer.py:87-89, a new episode's first-frame slot, the wrap re-insert).  A slot that is still
+// valid pairs with slot-1 consistently (writes are sequential), so validity is the whole check: stale indices are
+// re-drawn from the buffer's generator under the lock, exactly as the rejection loop would have.  `out` stays empty
+// when nothing changed.  Caller holds rb->mu.
+static int revalidate(serl_rb* rb, const int64_t* idx, int n, std::vector<int64_t>& out) {
+  if (rb->n_cam == 0) return SERL_OK;   // plain ReplayBuffer: every slot below `size` is valid
+  for (int i = 0; i < n; ++i) {
+    if (rb->valid[idx[i]]) continue;
+    if (out.empty()) out.assign(idx, idx + n);
+    SERL_REQUIRE(rb->rng.seeded, "replay buffer RNG not seeded");
+    const uint32_t sz = (uint32_t)rb->size;
+    int guard = 0;
+    do {
+      out[i] = rb->rng.bounded(sz);
+      SERL_REQUIRE(++guard < (1 << 24), "no valid slot found while re-drawing a stale index");
+    } while (!rb->valid[out[i]]);
+  }
+  return SERL_OK;
+}
+
 static int check_indices(serl_rb* rb, const int64_t* idx, int n) {
   for (int i = 0; i < n; ++i) {
     if (idx[i] < 0 || idx[i] >= rb->size) {
@@ -557,6 +620,10 @@ int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
   SERL_HIP(hipSetDevice(rb->device));
   int rc = check_indices(rb, host_idx, batch);
   if (rc) return rc;
+  std::vector<int64_t> fresh;
+  if ((rc = revalidate(rb, host_idx, batch, fresh))) return rc;
+  if (!fresh.empty()) host_idx = fresh.data();
+  if ((rc = order_after_inserts(rb, stream))) return rc;
   const void* srcs[1] = {host_idx};
   size_t sizes[1] = {sizeof(int64_t) * (size_t)batch}, offs[1];
   uint8_t* dparams;
@@ -636,11 +703,16 @@ int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* hos
     l0.lock();
   }
   SERL_HIP(hipSetDevice(r0->device));
+  std::vector<int64_t> fresh[SERL_MAX_BUFFERS];
+  const int64_t* use_idx[SERL_MAX_BUFFERS] = {nullptr};
   for (int b = 0; b < n_rb; ++b) {
     int rc = check_indices(rbs[b], host_idx[b], counts[b]);
     if (rc) return rc;
+    if ((rc = revalidate(rbs[b], host_idx[b], counts[b], fresh[b]))) return rc;
+    use_idx[b] = fresh[b].empty() ? host_idx[b] : fresh[b].data();
+    if ((rc = order_after_inserts(rbs[b], stream))) return rc;
   }
-  const void* srcs[4] = {host_idx[0], n_rb > 1 ? host_idx[1] : nullptr, host_crop_obs, host_crop_next};
+  const void* srcs[4] = {use_idx[0], n_rb > 1 ? use_idx[1] : nullptr, host_crop_obs, host_crop_next};
   size_t sizes[4] = {sizeof(int64_t) * (size_t)counts[0],
                      n_rb > 1 ? sizeof(int64_t) * (size_t)counts[1] : 0,
                      host_crop_obs ? sizeof(int32_t) * 2 * (size_t)total : 0,

@@ -24,7 +24,7 @@ from typing import List, Sequence, Tuple
 
 import numpy as np
 
-APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 2
+APPLY_CRITIC, APPLY_ACTOR_TEMP = 1, 6   # SERL_NET_CRITIC, SERL_NET_ACTOR | SERL_NET_TEMPERATURE
 
 
 def shard_parts(parts: Sequence[Tuple[object, np.ndarray]], rank: int, world: int):

@@ -47,7 +47,7 @@ def theta_shapes(n_cam, H, W, S, A, ensemble=10, hidden=256, bottleneck=256, sle
         return {
             "critic/w1": (N, S + A, Hd), "critic/b1": (N, Hd), "critic/ln1/scale": (N, Hd), "critic/ln1/bias": (N, Hd),
             "critic/w2": (N, Hd, Hd), "critic/b2": (N, Hd), "critic/ln2/scale": (N, Hd), "critic/ln2/bias": (N, Hd),
-            "critic/head/kernel": (N, Hd, 1), "critic/head/bias": (N,),
+            "critic/head/kernel": (N, Hd, 1), "critic/head/bias": (N, 1),   # vmapped Dense(1): one bias per member
             "actor/w1": (S, Hd), "actor/b1": (Hd,), "actor/ln1/scale": (Hd,), "actor/ln1/bias": (Hd,),
             "actor/w2": (Hd, Hd), "actor/b2": (Hd,), "actor/ln2/scale": (Hd,), "actor/ln2/bias": (Hd,),
             "actor/mean/kernel": (Hd, A), "actor/mean/bias": (A,),

@@ -86,7 +86,7 @@ def test_adam_ema_injected(gpu):
             core.debug_set("g_actor", g)
             core.debug_set("scalars", sc)
             O.apply_gradients(st, grads)
-            core.apply(2)
+            core.apply(6)   # SERL_NET_ACTOR | SERL_NET_TEMPERATURE
         for k in st.params:
             for sec, tree in (("params", st.params), ("target_params", st.target)):
                 got = core.get(sec, AH.product_name(k, cfg.image_keys))
@@ -251,7 +251,7 @@ def test_grad_view_aliases_library_memory(gpu):
     v.mul_(2.0)                                    # what all_reduce(SUM) over 2 identical ranks would do
     torch.cuda.synchronize()
     assert np.array_equal(core.debug("g_critic", pc), 2 * g)
-    va = core.grad_view(2)
+    va = core.grad_view(6)
     assert va.data_ptr() == v.data_ptr() + 4 * pc  # [scalars | actor grads] starts at the scalars
 
 
@@ -356,7 +356,7 @@ def test_rccl_all_reduce_on_the_zero_copy_gradient_view(gpu):
         core.debug_set("g_critic", g)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
-            for which in (1, 2):
+            for which in (1, 6):
                 dist.all_reduce(core.grad_view(which))
         torch.cuda.synchronize()
         assert np.array_equal(core.debug("g_critic", pc), g)
