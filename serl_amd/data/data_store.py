@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from ..transport.endpoint import DataStoreBase
 
 
 def _space_shape(space):
@@ -84,8 +85,10 @@ def concat_batches(offline_batch, online_batch, axis=1):
     return batch
 
 
-class MemoryEfficientReplayBufferDataStore:
-    """Drop-in for the reference class of the same name (data_store.py:83-144)."""
+class MemoryEfficientReplayBufferDataStore(DataStoreBase):
+    """Drop-in for the reference class of the same name (data_store.py:83-144), an agentlace `DataStoreBase`: a
+    TrainerServer thread may call insert() / batch_insert() while the learner thread samples (the buffer mutex lives in
+    libserl_mi355.so)."""
 
     def __init__(self, observation_space, action_space, capacity: int,
                  image_keys: Iterable[str] = ("image",), rlds_logger=None, device: int = 0):
@@ -109,6 +112,7 @@ class MemoryEfficientReplayBufferDataStore:
         self._S = sshape[1]
         self._A = _space_shape(action_space)[0]
         self._capacity = int(capacity)
+        DataStoreBase.__init__(self, self._capacity)
         self.device = device
         self._torch_device = torch.device("cuda", device)
         H, W, Cc = self._img_shape
@@ -264,6 +268,7 @@ class ReplayBufferDataStore(MemoryEfficientReplayBufferDataStore):
         self._S = int(np.prod(_space_shape(observation_space)))
         self._A = _space_shape(action_space)[0]
         self._capacity = int(capacity)
+        DataStoreBase.__init__(self, self._capacity)
         self.device = device
         self._torch_device = torch.device("cuda", device)
         self._h = C.c_void_p()

@@ -188,3 +188,18 @@ def test_state_replace_loads_trees_into_hbm(gpu):
         assert np.array_equal(dst.core.get(sec, leaf), src.core.get(sec, leaf)), (sec, leaf)
     with pytest.raises(TypeError):
         dst.state.replace(parms={})
+
+
+def test_learner_example_with_the_transport_endpoint(gpu):
+    """examples/learner_drq_synthetic.py: the reference's learner loop with a TrainerServer; a mock actor thread ships
+    transitions through TrainerClient.update(), requests send-stats and receives the published networks (next-row N2)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "learner_drq_synthetic.py"), "--steps", "9", "--batch_size", "32",
+                        "--critic_actor_ratio", "2", "--training_starts", "300", "--steps_per_update", "3", "--log_period", "4",
+                        "--port", "6712"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    done = [ln for ln in r.stdout.splitlines() if ln.startswith("done:")]
+    assert done and "18 grad-steps" in done[0] and "modules_actor" in done[0], r.stdout[-2000:]
