@@ -166,7 +166,14 @@ typedef struct serl_agent_cfg {
   int tx_weight_decay_on[3];
   float tx_weight_decay[3];
   float tx_clip_norm[3];
+  /* encoder_type of DrQAgent.create_drq (drq.py:137-186): SERL_ENCODER_RESNET_PRETRAINED (0, the frozen ResNet-10 of
+   * every example) or SERL_ENCODER_SMALL: the trainable SmallEncoder (vision/small_encoders.py:9-55, features
+   * (32,64,128,256), 3x3 stride-2 VALID convs + ReLU, average pool, Dense(256)+LayerNorm+tanh), gradients of the
+   * critic loss flow into its conv kernels */
+  int encoder_type;
 } serl_agent_cfg;
+#define SERL_ENCODER_RESNET_PRETRAINED 0
+#define SERL_ENCODER_SMALL 1
 #define SERL_TX_ACTOR 0
 #define SERL_TX_CRITIC 1
 #define SERL_TX_TEMPERATURE 2

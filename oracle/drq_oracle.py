@@ -34,6 +34,7 @@ import torch.nn.functional as F
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))  # (filters, stride) of the four ResNetBlocks
+SMALL_FEATURES = (3, 32, 64, 128, 256)             # SmallEncoder(features=(32, 64, 128, 256)) on RGB (drq.py:140-151)
 
 
 @dataclass
@@ -60,6 +61,9 @@ class Config:
     target_entropy: float = None    # drq.py:88-89: -A/2
     temp_warmup: int = None         # temperature optimizer's own warm-up (None: same as `warmup`); SACAgent.create
                                     # defaults: actor/critic warmup 2000, temperature none (sac.py:333-343)
+    encoder_type: str = "resnet-pretrained"   # or "small": the trainable SmallEncoder (vision/small_encoders.py:9-55,
+                                    # drq.py:137-153; the reference's call site passes it an `encode=` kwarg it does not
+                                    # accept -- SURVEY.md fact 4 -- so it is restated as if the kwarg were ignored)
     opt: dict = None                # optional {"actor"|"critic"|"temperature": make_optimizer kwargs} (optimizers.py:6-13:
                                     # learning_rate, warmup_steps, cosine_decay_steps, weight_decay, clip_grad_norm)
 
@@ -86,6 +90,10 @@ class Config:
         for _ in range(5):
             h, w = down(h), down(w)
         return h, w
+
+    @property
+    def small(self):
+        return self.encoder_type == "small"
 
     @property
     def sle_dim(self):
@@ -125,8 +133,14 @@ def trainable_param_shapes(cfg: Config):
     E, A, Hd, N = cfg.enc_dim, cfg.A, cfg.hidden, cfg.ensemble
     sh = {}
     for k in cfg.image_keys:
-        sh[f"enc/{k}/sle"] = (fh, fw, 512, cfg.sle_features)
-        sh[f"enc/{k}/dense/kernel"] = (cfg.sle_dim, cfg.bottleneck)
+        if cfg.small:
+            for l in range(4):
+                sh[f"enc/{k}/conv{l}/kernel"] = (3, 3, SMALL_FEATURES[l], SMALL_FEATURES[l + 1])
+                sh[f"enc/{k}/conv{l}/bias"] = (SMALL_FEATURES[l + 1],)
+            sh[f"enc/{k}/dense/kernel"] = (SMALL_FEATURES[4], cfg.bottleneck)
+        else:
+            sh[f"enc/{k}/sle"] = (fh, fw, 512, cfg.sle_features)
+            sh[f"enc/{k}/dense/kernel"] = (cfg.sle_dim, cfg.bottleneck)
         sh[f"enc/{k}/dense/bias"] = (cfg.bottleneck,)
         sh[f"enc/{k}/ln/scale"] = (cfg.bottleneck,)
         sh[f"enc/{k}/ln/bias"] = (cfg.bottleneck,)
@@ -172,7 +186,7 @@ def init_params(cfg: Config, seed: int = 42, perturb: bool = True):
         return ((0.1 * rng.standard_normal(shape)) if perturb else np.zeros(shape)).astype(np.float32)
 
     trunk = {}
-    for name, shp in ({} if cfg.state_only else trunk_param_shapes()).items():
+    for name, shp in ({} if (cfg.state_only or cfg.small) else trunk_param_shapes()).items():
         if len(shp) == 4:
             trunk[name] = normal(shp, math.sqrt(2.0 / (shp[0] * shp[1] * shp[2])))
         elif name.endswith("scale"):
@@ -181,7 +195,7 @@ def init_params(cfg: Config, seed: int = 42, perturb: bool = True):
             trunk[name] = bias(shp)
     theta = {}
     for name, shp in trainable_param_shapes(cfg).items():
-        if name.endswith("/sle"):
+        if name.endswith("/sle") or ("/conv" in name and name.endswith("kernel")):   # lecun_normal over (h, w, cin)
             theta[name] = normal(shp, math.sqrt(1.0 / (shp[0] * shp[1] * shp[2])))
         elif name.startswith("enc/") and name.endswith("dense/kernel") and "proprio" not in name:
             theta[name] = normal(shp, math.sqrt(1.0 / shp[0]))        # nn.Dense default lecun_normal
@@ -280,6 +294,17 @@ def sle(feats, kernel):
     return out.reshape(feats.shape[0], -1)
 
 
+def small_encoder_trunk(th, key, img_u8):
+    """SmallEncoder up to the pooling (small_encoders.py:23-41): x/255, 4 x (Conv 3x3 stride 2 VALID + bias, ReLU),
+    mean over (H, W).  img_u8 [N,H,W,3] uint8 (or float already) -> [N,256]."""
+    dt = th[f"enc/{key}/conv0/kernel"].dtype
+    x = img_u8.to(dt) / 255.0
+    for l in range(4):
+        x = conv_nhwc(x, th[f"enc/{key}/conv{l}/kernel"], 2, ((0, 0), (0, 0))) + th[f"enc/{key}/conv{l}/bias"]
+        x = torch.relu(x)
+    return x.mean(dim=(1, 2))
+
+
 def encode(th, cfg, feats, state, drop_masks=None, stop_gradient=False):
     """EncodingWrapper (encoding.py:26-72) on precomputed trunk features.
     feats: {cam: [N,h,w,512]}; state [N,S]; drop_masks: {cam: [N,4096] keep-mask} or None."""
@@ -287,9 +312,12 @@ def encode(th, cfg, feats, state, drop_masks=None, stop_gradient=False):
         return state        # encoder=None (actor_critic_nets.py:59-60,185-186)
     codes = []
     for k in cfg.image_keys:
-        f = sle(feats[k], th[f"enc/{k}/sle"])
-        if drop_masks is not None:                                           # nn.Dropout(0.1) :351
-            f = torch.where(drop_masks[k].bool(), f / (1.0 - cfg.dropout), torch.zeros_like(f))
+        if cfg.small:                                                        # small_encoders.py:19-41 (pool_method "avg")
+            f = small_encoder_trunk(th, k, feats[k])
+        else:
+            f = sle(feats[k], th[f"enc/{k}/sle"])
+            if drop_masks is not None:                                       # nn.Dropout(0.1) :351
+                f = torch.where(drop_masks[k].bool(), f / (1.0 - cfg.dropout), torch.zeros_like(f))
         z = f @ th[f"enc/{k}/dense/kernel"] + th[f"enc/{k}/dense/bias"]
         z = torch.tanh(layer_norm(z, th[f"enc/{k}/ln/scale"], th[f"enc/{k}/ln/bias"]))  # :371-374
         if stop_gradient:
@@ -530,6 +558,8 @@ def features(st: TrainState, frames_u8, chunk=64):
     out = {}
     if st.cfg.state_only:
         return out
+    if st.cfg.small:   # the trainable encoder runs inside encode() with the parameters of the caller (online / target)
+        return dict(frames_u8)
     with torch.no_grad():
         for k, v in frames_u8.items():
             parts = [trunk_forward(st.trunk, v[i:i + chunk], st.dtype) for i in range(0, v.shape[0], chunk)]

@@ -47,7 +47,7 @@ def theta_flax_paths(cfg):
     """oracle leaf name -> flax path of the reference's parameter tree (the product's export mapping: using it here also
     checks serl_amd/agents/flax_tree.py against the tree the reference really builds)."""
     from serl_amd.agents.flax_tree import theta_paths
-    prod = theta_paths(cfg.image_keys)
+    prod = theta_paths(cfg.image_keys, encoder_type=cfg.encoder_type)
     return {k: prod[_product_name(k, cfg.image_keys)][0] for k in O.trainable_param_shapes(cfg)}
 
 
@@ -119,6 +119,8 @@ def _parse_noise(cfg, B, recs, kind, utd, nets=()):
 
     def masks(rows):
         out = {}
+        if cfg.small:          # SmallEncoder(pool_method="avg") has no Dropout (small_encoders.py:43-52)
+            return out
         for k in cfg.image_keys:
             (r,) = t.take("bernoulli")
             assert r["context"] and r["context"][-1].endswith(f"encoder_{k}/Dropout_0"), r["context"]
@@ -157,7 +159,7 @@ def _parse_noise(cfg, B, recs, kind, utd, nets=()):
         mk.append(m)
         ep.append(e)
         rq.append(r)
-    noise["mask_next"] = {k: np.concatenate([m[k] for m in mk]) for k in cfg.image_keys}
+    noise["mask_next"] = {k: np.concatenate([m[k] for m in mk]) for k in (cfg.image_keys if mk[0] else ())}
     noise["eps_next"] = np.concatenate(ep)
     noise["redq_idx"] = np.stack(rq)
     if kind == "high_utd":       # loss_fns dict in sorted order: actor, (critic: zero), temperature
@@ -194,26 +196,42 @@ def _make_reference_agent(jax, jnp, cfg, trunk):
         return orig(cls, *a, **{**k, **extra})
 
     setattr(target, name, classmethod(patched))
+    se = se_orig = None
+    if cfg.small:
+        # Reference defect at this commit: EncodingWrapper calls every encoder with `encode=`
+        # (common/encoding.py:46) but SmallEncoder.__call__(observations, train) does not accept it -> TypeError.  The
+        # adapter below accepts and ignores the kwarg; everything else is the reference's own SmallEncoder.
+        import serl_launcher.vision.small_encoders as se
+        se_orig = se.SmallEncoder
+
+        class SmallEncoder(se_orig):   # same class name: flax auto-names would not change either
+            def __call__(self, observations, train=False, encode=True):
+                return se_orig.__call__(self, observations, train)
+
+        se.SmallEncoder = SmallEncoder
     try:
         if cfg.state_only:
             return make_sac_agent(0, jnp.asarray(np.zeros((cfg.S,), np.float32)), jnp.asarray(np.zeros((cfg.A,), np.float32)),
                                   discount=cfg.discount)
         home = tempfile.mkdtemp(prefix="serl_ref_home_")
         os.makedirs(os.path.join(home, ".serl"))
-        with open(os.path.join(home, ".serl", "resnet10_params.pkl"), "wb") as f:
-            pickle.dump(pretrained_pickle_tree(trunk), f)
+        if not cfg.small:
+            with open(os.path.join(home, ".serl", "resnet10_params.pkl"), "wb") as f:
+                pickle.dump(pretrained_pickle_tree(trunk), f)
         old_home = os.environ.get("HOME")
         os.environ["HOME"] = home            # train_utils.load_resnet10_params reads ~/.serl/resnet10_params.pkl
         try:
             sample_obs = {k: jnp.asarray(np.zeros((1, cfg.H, cfg.W, 3), np.uint8)) for k in cfg.image_keys}
             sample_obs["state"] = jnp.asarray(np.zeros((1, cfg.S), np.float32))
             return make_drq_agent(0, sample_obs, jnp.asarray(np.zeros((cfg.A,), np.float32)), image_keys=cfg.image_keys,
-                                  encoder_type="resnet-pretrained", discount=cfg.discount)
+                                  encoder_type=cfg.encoder_type, discount=cfg.discount)
         finally:
             if old_home is not None:
                 os.environ["HOME"] = old_home
     finally:
         setattr(target, name, classmethod(orig))
+        if se is not None:
+            se.SmallEncoder = se_orig
 
 
 def synth_flat_batch(cfg, B, seed):
@@ -243,7 +261,7 @@ def run_reference(cfg: O.Config, B: int, schedule, param_seed=42, batch_seed=100
     # the trunk came in through the reference's own loader; check it landed, then overwrite the trainable leaves
     paths = theta_flax_paths(cfg)
     params = jax.tree_map(lambda a: a, agent.state.params)     # fresh containers, shared leaves
-    first = sorted(cfg.image_keys)[0] if cfg.image_keys else None
+    first = sorted(cfg.image_keys)[0] if (cfg.image_keys and not cfg.small) else None
     if first is not None:
         pe = params["modules_actor"]["encoder"][f"encoder_{first}"]["pretrained_encoder"]
         assert np.array_equal(np.asarray(pe["conv_init"]["kernel"]), trunk["trunk/conv_init"]), "pretrained weights were not patched in"

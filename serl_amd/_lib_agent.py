@@ -16,6 +16,7 @@ class SerlAgentCfg(C.Structure):
         # per-optimizer options of make_optimizer (common/optimizers.py:6-56), index = TX_INDEX[name]
         ("tx_lr", C.c_float * 3), ("tx_warmup", C.c_int * 3), ("tx_cosine_steps", C.c_int * 3),
         ("tx_weight_decay_on", C.c_int * 3), ("tx_weight_decay", C.c_float * 3), ("tx_clip_norm", C.c_float * 3),
+        ("encoder_type", C.c_int),   # 0 = resnet-pretrained (frozen trunk), 1 = small (trainable SmallEncoder)
     ]
 
 

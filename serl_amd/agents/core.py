@@ -18,7 +18,7 @@ class AgentCore:
     def __init__(self, *, device=0, n_cam, H, W, state_dim, act_dim, batch, ensemble=10, hidden=256,
                  bottleneck=256, sle_features=8, proprio_dim=64, warmup_steps=0, discount=0.96,
                  tau=0.005, lr=3e-4, dropout=0.1, std_min=1e-5, std_max=5.0, target_entropy=None,
-                 seed=0, temp_warmup_steps=-1, optimizers=None):
+                 seed=0, temp_warmup_steps=-1, optimizers=None, encoder_type="resnet-pretrained"):
         """optimizers: optional {"actor"|"critic"|"temperature": make_optimizer kwargs (common/optimizers.py:6-13:
         learning_rate, warmup_steps, cosine_decay_steps, weight_decay, clip_grad_norm)} overriding lr / warmup_steps."""
         if target_entropy is None:
@@ -26,6 +26,7 @@ class AgentCore:
         self.cfg = SerlAgentCfg(device, n_cam, H, W, state_dim, act_dim, batch, ensemble, hidden,
                                 bottleneck, sle_features, proprio_dim, warmup_steps, temp_warmup_steps, discount, tau,
                                 lr, dropout, std_min, std_max, target_entropy, seed)
+        self.cfg.encoder_type = {"resnet-pretrained": 0, "small": 1}[encoder_type]
         for name, kw in (optimizers or {}).items():
             i = TX_INDEX[name]
             bad = set(kw) - {"learning_rate", "warmup_steps", "cosine_decay_steps", "weight_decay", "clip_grad_norm"}

@@ -166,8 +166,9 @@ class DrQAgent:
         """drq.py:104-242.  Only the configuration the reference's examples run is built natively:
         encoder_type="resnet-pretrained", use_proprio=True, REDQ subsample 2, tanh-squashed
         exp-parameterised policy, LayerNorm+tanh 256x256 MLPs (utils/launcher.py:79-116)."""
-        if encoder_type != "resnet-pretrained":
-            raise NotImplementedError(f"Unknown encoder type: {encoder_type} (only 'resnet-pretrained' is built)")
+        if encoder_type not in ("resnet-pretrained", "small"):
+            # drq.py:155-167 also has "resnet" (trainable ResNet-10, never selected by an example: not built)
+            raise NotImplementedError(f"Unknown encoder type: {encoder_type}")
         if not use_proprio or backup_entropy or critic_subsample_size != 2:
             raise NotImplementedError("only use_proprio=True, backup_entropy=False, critic_subsample_size=2")
         pk = policy_kwargs or {}
@@ -192,10 +193,10 @@ class DrQAgent:
                          batch=batch_size, ensemble=critic_ensemble_size, discount=discount,
                          tau=soft_target_update_rate, lr=learning_rate, std_min=pk.get("std_min", 1e-5),
                          std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed,
-                         optimizers={k: {"warmup_steps": 0, **v} for k, v in opts.items()})
+                         optimizers={k: {"warmup_steps": 0, **v} for k, v in opts.items()}, encoder_type=encoder_type)
         theta = pinit.init_theta(len(image_keys), H, W, S, A, seed=seed, temperature_init=temperature_init,
-                                 ensemble=critic_ensemble_size)
-        trunk = pinit.init_trunk(seed=seed)
+                                 ensemble=critic_ensemble_size, encoder_type=encoder_type)
+        trunk = pinit.init_trunk(seed=seed) if encoder_type == "resnet-pretrained" else {}
         for sec in ("params", "target_params"):  # JaxRLTrainState.create(target_params=params)
             core.load_flat(sec, theta)
             core.load_flat(sec, trunk)
@@ -289,8 +290,9 @@ class DrQAgent:
         return tuple((id(b), id(ix)) for b, ix in batch.parts)
 
     def _can_prefetch(self, batch, crops):
+        # (only the FROZEN trunk can run ahead of the update: a trainable encoder depends on the parameters)
         return (self.prefetch and crops is None and isinstance(batch, LazyBatch) and self.core.cfg.n_cam > 0
-                and batch.batch_size <= self.core.cfg.batch)
+                and self.core.cfg.encoder_type == 0 and batch.batch_size <= self.core.cfg.batch)
 
     def _slot_batch(self, slot, B):
         c = self.core.cfg

@@ -47,7 +47,7 @@ def _trunk_paths():
     return m
 
 
-def theta_paths(image_keys, critic_mlp_name="network"):
+def theta_paths(image_keys, critic_mlp_name="network", encoder_type="resnet-pretrained"):
     """flat trainable leaf -> list of flax paths (aliases)."""
     enc = ("modules_actor", "encoder")
     m = {}
@@ -57,7 +57,12 @@ def theta_paths(image_keys, critic_mlp_name="network"):
         return _state_paths()
     for i, k in enumerate(image_keys):
         e = enc + (f"encoder_{k}",)
-        m[f"enc/{i}/sle"] = [e + ("SpatialLearnedEmbeddings_0", "kernel")]
+        if encoder_type == "small":   # SmallEncoder (small_encoders.py:9-55): Conv_0..3 {kernel, bias}
+            for l in range(4):
+                m[f"enc/{i}/conv{l}/kernel"] = [e + (f"Conv_{l}", "kernel")]
+                m[f"enc/{i}/conv{l}/bias"] = [e + (f"Conv_{l}", "bias")]
+        else:
+            m[f"enc/{i}/sle"] = [e + ("SpatialLearnedEmbeddings_0", "kernel")]
         m[f"enc/{i}/dense/kernel"] = [e + ("Dense_0", "kernel")]
         m[f"enc/{i}/dense/bias"] = [e + ("Dense_0", "bias")]
         m[f"enc/{i}/ln/scale"] = [e + ("LayerNorm_0", "scale")]
@@ -115,16 +120,17 @@ def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: 
                 critic_mlp_name: str = "network", trunk_under_every_camera: bool = False) -> Dict:
     """Nested dict of np.float32 arrays in flax layout (HWIO convs, (in,out) dense, ensemble axis 0)."""
     cfg = core.cfg
-    shapes = theta_shapes(cfg.n_cam, cfg.H, cfg.W, cfg.state_dim, cfg.act_dim, ensemble=cfg.ensemble)
+    etype = "small" if cfg.encoder_type == 1 else "resnet-pretrained"
+    shapes = theta_shapes(cfg.n_cam, cfg.H, cfg.W, cfg.state_dim, cfg.act_dim, ensemble=cfg.ensemble, encoder_type=etype)
     tree: Dict = {}
-    for leaf, paths in theta_paths(image_keys, critic_mlp_name).items():
+    for leaf, paths in theta_paths(image_keys, critic_mlp_name, etype).items():
         v = core.get(section, leaf).reshape(shapes[leaf])
         for p in paths:
             _put(tree, p, v)
             if duplicate_encoder_under_critic and p[:2] == ("modules_actor", "encoder"):
                 _put(tree, ("modules_critic",) + p[1:], v)
     tshapes = trunk_shapes()
-    for leaf, sub in (_trunk_paths() if cfg.n_cam else {}).items():
+    for leaf, sub in (_trunk_paths() if (cfg.n_cam and etype != "small") else {}).items():
         v = core.get(section, leaf).reshape(tshapes[leaf])
         # ONE frozen trunk: drq.py:165-176 passes the same `pretrained_encoder` module to every camera's
         # PreTrainedResNetEncoder, flax adopts a shared module once -- under the first camera in sorted-key order --

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "heads.h"
+#include "small_encoder.h"
 
 using namespace serl;
 
@@ -25,7 +26,7 @@ struct Leaf {
   long off, count;
 };
 
-struct CamOff { long sle, dW, db, lng, lnb; };
+struct CamOff { long sle, dW, db, lng, lnb, conv; };   // sle: resnet-pretrained, conv: SmallEncoder
 struct Offs {
   CamOff cam[SERL_MAX_CAMS];
   long cam_stride;
@@ -75,6 +76,8 @@ struct serl_agent {
   serl_agent_cfg cfg{};
   int E = 0, D = 0, HW = 0, XA = 0;  // enc dim, sle dim, feature pixels, E + A
   bool state_only = false;           // n_cam == 0: SACAgent.create_states
+  bool small = false;                // encoder_type == "small": trainable SmallEncoder instead of the frozen trunk
+  SmallWorkspace sws{};
   Offs o{};
   std::vector<Leaf> theta_leaves, trunk_leaves;
   long trunk_count = 0;
@@ -154,8 +157,9 @@ void build_layout(serl_agent* a) {
   const serl_agent_cfg& c = a->cfg;
   const TrunkDims d = c.n_cam > 0 ? trunk_dims(c.H, c.W) : TrunkDims{};
   a->state_only = c.n_cam == 0;
-  a->HW = a->state_only ? 0 : d.h[5] * d.w[5];
-  a->D = a->state_only ? 0 : 512 * c.sle_features;
+  a->small = !a->state_only && c.encoder_type == SERL_ENCODER_SMALL;
+  a->HW = (a->state_only || a->small) ? 0 : d.h[5] * d.w[5];
+  a->D = a->state_only ? 0 : (a->small ? kSmallFeat[kSmallLayers] : 512 * c.sle_features);
   a->E = a->state_only ? c.state_dim : c.bottleneck * c.n_cam + c.proprio_dim;
   a->XA = a->E + c.act_dim;
   long off = 0;
@@ -170,7 +174,16 @@ void build_layout(serl_agent* a) {
   const long Hd = c.hidden, A = c.act_dim, N = c.ensemble;
   for (int k = 0; k < c.n_cam; ++k) {
     const std::string p = "enc/" + std::to_string(k) + "/";
-    o.cam[k].sle = leaf(L, p + "sle", (long)a->HW * 512 * c.sle_features);
+    if (a->small) {   // per layer [9*cin + 1][cout]: kernel (HWIO) immediately followed by the bias (small_encoder.hip)
+      o.cam[k].conv = off;
+      for (int l = 0; l < kSmallLayers; ++l) {
+        leaf(L, p + "conv" + std::to_string(l) + "/kernel", 9L * kSmallFeat[l] * kSmallFeat[l + 1]);
+        leaf(L, p + "conv" + std::to_string(l) + "/bias", kSmallFeat[l + 1]);
+      }
+      o.cam[k].sle = o.cam[k].conv;
+    } else {
+      o.cam[k].sle = leaf(L, p + "sle", (long)a->HW * 512 * c.sle_features);
+    }
     o.cam[k].dW = leaf(L, p + "dense/kernel", (long)a->D * c.bottleneck);
     o.cam[k].db = leaf(L, p + "dense/bias", c.bottleneck);
     o.cam[k].lng = leaf(L, p + "ln/scale", c.bottleneck);
@@ -215,7 +228,7 @@ void build_layout(serl_agent* a) {
   // trunk
   off = 0;
   a->trunk_count = 0;
-  if (a->state_only) return;
+  if (a->state_only || a->small) return;   // no frozen trunk
   std::vector<Leaf>& T = a->trunk_leaves;
   leaf(T, "trunk/conv_init", 7 * 7 * 3 * 64);
   leaf(T, "trunk/norm_init/scale", 64);
@@ -281,7 +294,7 @@ size_t carve(serl_agent* a, void* base) {
   a->info_acc = b.take<float>(8);
   a->aux = b.take<float>(X_N);
   const size_t persistent = b.off;  // zero-initialised region ends here
-  for (int k = 0; k < 3; ++k) a->feats_slot[k] = b.take<float>((k < 2 ? 2L : 1L) * c.n_cam * B * a->HW * 512);
+  for (int k = 0; k < 3; ++k) a->feats_slot[k] = b.take<float>((k < 2 ? 2L : 1L) * c.n_cam * B * a->HW * 512);   // (HW = 0 without a trunk)
   a->feats = a->feats_slot[0];
   auto enc = [&](EncBuf& e) {
     e.f = b.take<float>((long)c.n_cam * B * a->D);
@@ -329,7 +342,10 @@ size_t carve(serl_agent* a, void* base) {
     a->mask_buf[k] = b.take<uint8_t>((long)c.n_cam * B * a->D);
   }
   a->act_tmp = b.take<float>(B * A);
-  if (!a->state_only) {
+  if (a->small) {
+    void* smem = b.take<uint8_t>(small_workspace_bytes(c.n_cam * c.batch, c.H, c.W));
+    if (base) small_workspace_bind(a->sws, smem, c.n_cam * c.batch, c.H, c.W);
+  } else if (!a->state_only) {
     const int nimg = 2 * c.n_cam * c.batch;
     void* tmem = b.take<uint8_t>(trunk_workspace_bytes(nimg, c.H, c.W));
     if (base) trunk_workspace_bind(a->tws, tmem, nimg, c.H, c.W);
@@ -419,6 +435,14 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       pr.copy_cols = c.act_dim;
     }
   }
+  if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
+    const size_t fbytes = (size_t)c.H * c.W * 3;
+    for (int i = 0; i < n; ++i) {
+      const EncJob& j = jobs[i];
+      const uint8_t* fr = a->cur.frames + (((size_t)j.which * c.n_cam) * Bfull + off) * fbytes;
+      RC(small_forward(a->sws, j.P, o.cam[0].conv, o.cam_stride, fr, Bfull, c.n_cam, cnt, j.e->f, (long)c.batch * a->D, st));
+    }
+  } else
   RC(sle_fwd_multi(sv, n, 1.0f / (1.0f - c.dropout), cnt, a->HW, 512, c.n_cam, (long)c.batch * a->HW * 512, o.cam_stride,
                    Bfull * a->D, (long)c.batch * a->D, st));
   RC(gemm_f32_multi(gd, n, st));
@@ -643,6 +667,8 @@ int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt
            c.n_cam, a->D, Bn, cnt, st));
   RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
            a->D, Bn, st));
+  if (a->small)   // through the average pool and the four convs of the forward pass that ran last (theta at observations)
+    return small_backward(a->sws, P, o.cam[0].conv, o.cam_stride, c.n_cam, cnt, a->df, (long)cnt * a->D, a->Gc, st);
   const long sle_n = (long)a->HW * 512 * c.sle_features;
   {  // dK of every camera: one partial-sum launch (grid.z = camera x batch split) + one reduction
     const float* x = a->feats + (long)off * a->HW * 512;
@@ -682,7 +708,7 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
                                cnt_total, a->shard_global, a->shard_off, c.act_dim};
     *eps = a->eps_buf[slot];
   }
-  if (given_mask || a->state_only) *mask = given_mask;  // (no encoder, no dropout in the state-only agent)
+  if (given_mask || a->state_only || a->small) *mask = a->small ? nullptr : given_mask;  // (no dropout without the SLE branch)
   else {
     nb.jobs[nb.n++] = NoiseJob{a->mask_buf[slot], (long)c.n_cam * cnt_total * a->D,
                                c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)), 1, 1.0f - c.dropout,
@@ -713,6 +739,8 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   SERL_REQUIRE(cfg && out, "NULL argument");
   SERL_REQUIRE(cfg->n_cam >= 0 && cfg->n_cam <= SERL_MAX_CAMS, "n_cam %d not in [0,%d]", cfg->n_cam, SERL_MAX_CAMS);
   SERL_REQUIRE(cfg->n_cam == 0 || (cfg->H >= 32 && cfg->W >= 32), "images must be at least 32x32");
+  SERL_REQUIRE(cfg->encoder_type == SERL_ENCODER_RESNET_PRETRAINED || cfg->encoder_type == SERL_ENCODER_SMALL,
+               "Unknown encoder type: %d", cfg->encoder_type);
   SERL_REQUIRE(cfg->n_cam > 0 || cfg->ensemble <= 16, "state-only SAC supports ensembles of at most 16");
   SERL_REQUIRE(cfg->hidden == 256 && cfg->bottleneck == 256, "hidden/bottleneck must be 256 (got %d/%d)", cfg->hidden, cfg->bottleneck);
   SERL_REQUIRE(cfg->proprio_dim == 64, "proprio_dim must be 64");
@@ -742,7 +770,7 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   }
   carve(a, a->arena);
   SERL_HIP(hipMemset(a->arena, 0, bytes));
-  if (!a->state_only) bind_trunk_weights(a);
+  if (!a->state_only && !a->small) bind_trunk_weights(a);
   *out = a;
   return SERL_OK;
 }
@@ -846,7 +874,7 @@ int64_t serl_agent_get_step(serl_agent* a) { return a ? a->step : -1; }
 
 int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, float* dev_feats_out, void* stream) {
   SERL_REQUIRE(a && dev_frames && dev_feats_out, "NULL argument");
-  SERL_REQUIRE(!a->state_only, "a state-only agent has no trunk");
+  SERL_REQUIRE(!a->state_only && !a->small, "this agent has no frozen trunk");
   SERL_HIP(hipSetDevice(a->cfg.device));
   return trunk_forward(a->tw, a->tws, dev_frames, n, dev_feats_out, (hipStream_t)stream, a->trunk_mode ? &a->tpk : nullptr);
 }
@@ -873,7 +901,7 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
   const serl_agent_cfg& c = a->cfg;
   const int B = batch->batch;
   const size_t fbytes = (size_t)c.H * c.W * 3;
-  if (a->state_only) return SERL_OK;  // no encoder: nothing to precompute
+  if (a->state_only || a->small) return SERL_OK;  // no frozen encoder: nothing to precompute
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
     // (sub-batching the run to keep activations in the Infinity Cache was measured: slower -- DESIGN.md)
     return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr);
@@ -1137,7 +1165,7 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   SERL_HIP(hipSetDevice(c.device));
   // trunk on [n_cam][n] images -> feats slot 0; state goes through a temporary serl_batch view
   const size_t fbytes = (size_t)c.H * c.W * 3;
-  for (int k = 0; k < c.n_cam; ++k)
+  for (int k = 0; k < c.n_cam && !a->small; ++k)
     RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[2] + ((long)k * c.batch) * a->HW * 512, st, a->trunk_mode ? &a->tpk : nullptr));
   serl_batch saved = a->cur;
   const bool had = a->has_batch;
@@ -1146,6 +1174,7 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   a->cur = serl_batch{};
   a->cur.batch = n;
   a->cur.state = const_cast<float*>(dev_state);
+  a->cur.frames = const_cast<uint8_t*>(dev_frames);   // (the SmallEncoder reads the pixels in encode_multi)
   const EncJob ej{a->theta, 0, nullptr, &a->encP, nullptr, nullptr};  // train=False: no dropout
   RC(encode_multi(a, &ej, 1, 0, n, st));
   if (!dev_eps) {  // argmax -> mode = tanh(mean): zero noise

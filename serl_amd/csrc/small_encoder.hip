@@ -1,0 +1,254 @@
+// Trainable SmallEncoder: forward, and backward to every conv kernel / bias, on MI355X.
+// Reference: serl_launcher/vision/small_encoders.py:9-55 (features (32,64,128,256), 3x3 kernels, stride 2, padding
+// VALID, pool_method "avg" -- agents/continuous/drq.py:137-153).
+//
+// A conv layer is an explicit im2col + the update chain's fp32-MFMA GEMM (heads.hip gemm_f32: exact fp32 products on
+// v_mfma_f32_32x32x2_f32).  The im2col matrix carries a trailing column of ones and a layer's parameters sit in the
+// arena as [9*cin + 1][cout] (HWIO kernel immediately followed by the bias), so the bias is part of the forward GEMM and
+// its gradient part of the weight-gradient GEMM, which writes straight into the gradient arena.  The secondary
+// encoder of the north star: built for parity first (288 GB of HBM make the explicit im2col affordable); the frozen
+// ResNet-10 path is the one the benchmark times.
+#include <algorithm>
+
+#include "heads.h"
+#include "prof.h"
+#include "small_encoder.h"
+
+namespace serl {
+
+SmallDims small_dims(int H, int W) {
+  SmallDims d{};
+  d.H = H; d.W = W;
+  d.h[0] = H; d.w[0] = W;
+  for (int l = 0; l < kSmallLayers; ++l) {   // VALID, kernel 3, stride 2
+    d.h[l + 1] = (d.h[l] - 3) / 2 + 1;
+    d.w[l + 1] = (d.w[l] - 3) / 2 + 1;
+  }
+  return d;
+}
+long small_conv_offset(int layer) {
+  long off = 0;
+  for (int l = 0; l < layer; ++l) off += (9L * kSmallFeat[l] + 1) * kSmallFeat[l + 1];
+  return off;
+}
+long small_conv_params() { return small_conv_offset(kSmallLayers); }
+
+static int ldk(int l) { return (9 * kSmallFeat[l] + 1 + 3) & ~3; }   // row pitch of col_l: K + 1 rounded up to 4 floats
+static long rows_of(const SmallDims& d, int l, long n_img) { return n_img * d.h[l + 1] * d.w[l + 1]; }
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t carve(SmallWorkspace& ws, uint8_t* base, int max_images, int H, int W) {
+  ws.d = small_dims(H, W);
+  ws.max_images = max_images;
+  size_t off = 0;
+  auto take = [&](size_t floats) { float* p = base ? (float*)(base + off) : nullptr; off += al256(floats * 4); return p; };
+  long max_act = 0, max_col = 0;
+  for (int l = 0; l < kSmallLayers; ++l) {
+    const long r = rows_of(ws.d, l, max_images);
+    ws.col[l] = take((size_t)r * ldk(l));
+    ws.act[l] = take((size_t)r * kSmallFeat[l + 1]);
+    max_act = std::max(max_act, r * kSmallFeat[l + 1]);
+    max_col = std::max(max_col, r * ldk(l));
+  }
+  ws.dact = take(max_act);
+  ws.dact2 = take(max_act);
+  ws.dcol = take(max_col);
+  ws.slabs_cap = 64L * (9 * 128 + 1) * 256;   // up to 64 K-slices of the largest [K+1][cout] gradient
+  ws.slabs = take(ws.slabs_cap);
+  ws.bytes = off;
+  return off;
+}
+size_t small_workspace_bytes(int max_images, int H, int W) {
+  SmallWorkspace t;
+  return carve(t, nullptr, max_images, H, W);
+}
+int small_workspace_bind(SmallWorkspace& ws, void* mem, int max_images, int H, int W) {
+  carve(ws, (uint8_t*)mem, max_images, H, W);
+  return SERL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// col[m][(ky*3+kx)*cin + ci] = x[n][2*oy+ky][2*ox+kx][ci] (u8 input: /255, small_encoders.py:23), col[m][9*cin] = 1,
+// padding columns up to the pitch = 0.  One thread per (row m, tap).
+template <bool U8>
+__global__ __launch_bounds__(256) void small_im2col_kernel(const void* xin, float* col, long rows, int hi, int wi, int ho,
+                                                          int wo, int cin, int pitch, int n_per_cam, long cam_stride_img) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rows * 10) return;
+  const long m = e / 10;
+  const int tap = (int)(e - m * 10);
+  float* dst = col + m * pitch;
+  if (tap == 9) {   // ones column (the bias) + zero padding of the pitch
+    dst[9 * cin] = 1.0f;
+    for (int k = 9 * cin + 1; k < pitch; ++k) dst[k] = 0.0f;
+    return;
+  }
+  const long n = m / ((long)ho * wo);
+  const int rem = (int)(m - n * (long)ho * wo), oy = rem / wo, ox = rem - oy * wo;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  // (the u8 frames of a camera may be a slice of a larger batch: camera blocks are cam_stride_img images apart)
+  const long nn = U8 ? (n / n_per_cam) * cam_stride_img + (n % n_per_cam) : n;
+  const long src = ((nn * hi + 2 * oy + ky) * wi + 2 * ox + kx) * cin;
+  if (U8) {
+    const uint8_t* p = static_cast<const uint8_t*>(xin) + src;
+    for (int c = 0; c < cin; ++c) dst[tap * cin + c] = (float)p[c] / 255.0f;
+  } else {
+    const float* p = static_cast<const float*>(xin) + src;
+    for (int c = 0; c < cin; c += 4) *reinterpret_cast<float4*>(dst + tap * cin + c) = *reinterpret_cast<const float4*>(p + c);
+  }
+}
+
+__global__ __launch_bounds__(256) void small_relu_kernel(float* x, long n4) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 v = reinterpret_cast<float4*>(x)[e];
+  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  reinterpret_cast<float4*>(x)[e] = v;
+}
+
+// pooled[cam][img][c] = mean over the P pixels of act[(cam*n + img)*P + p][c]   (jnp.mean(x, axis=(-3, -2)))
+__global__ __launch_bounds__(256) void small_avgpool_kernel(const float* act, float* pooled, int n, int P, long pooled_cam_stride) {
+  const int img = blockIdx.x, c = threadIdx.x;   // 256 channels
+  const int cam = img / n, i = img - cam * n;
+  const float* a = act + (long)img * P * 256 + c;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += a[(long)p * 256];
+  pooled[(long)cam * pooled_cam_stride + (long)i * 256 + c] = s / (float)P;
+}
+
+// dact[(img*P + p)][c] = dpooled[cam][i][c] / P where act > 0
+__global__ __launch_bounds__(256) void small_avgpool_bwd_kernel(const float* dpooled, const float* act, float* dact, int n, int P,
+                                                               long dp_cam_stride) {
+  const int img = blockIdx.x, c = threadIdx.x;
+  const int cam = img / n, i = img - cam * n;
+  const float g = dpooled[(long)cam * dp_cam_stride + (long)i * 256 + c] / (float)P;
+  const long base = (long)img * P * 256 + c;
+  for (int p = 0; p < P; ++p) dact[base + (long)p * 256] = act[base + (long)p * 256] > 0.f ? g : 0.f;
+}
+
+// col2im as a gather, fused with the ReLU mask of the layer below:
+// dx[n][iy][ix][ci] = (x > 0) * sum over taps (ky,kx) with iy-ky = 2*oy, ix-kx = 2*ox in range of dcol[(n,oy,ox)][(ky*3+kx)*cin + ci]
+__global__ __launch_bounds__(256) void small_col2im_kernel(const float* dcol, const float* x, float* dx, long n_img, int hi, int wi,
+                                                          int ho, int wo, int cin, int pitch) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = cin / 4;
+  if (e >= n_img * hi * wi * c4n) return;
+  const int c4 = (int)(e % c4n);
+  long t = e / c4n;
+  const int ix = (int)(t % wi);
+  t /= wi;
+  const int iy = (int)(t % hi);
+  const long n = t / hi;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int y2 = iy - ky;
+    if (y2 < 0 || (y2 & 1) || (y2 >> 1) >= ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int x2 = ix - kx;
+      if (x2 < 0 || (x2 & 1) || (x2 >> 1) >= wo) continue;
+      const long m = (n * ho + (y2 >> 1)) * wo + (x2 >> 1);
+      const float4 v = *reinterpret_cast<const float4*>(dcol + m * pitch + (ky * 3 + kx) * cin + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  const float4 a = reinterpret_cast<const float4*>(x)[e];
+  s.x = a.x > 0.f ? s.x : 0.f; s.y = a.y > 0.f ? s.y : 0.f; s.z = a.z > 0.f ? s.z : 0.f; s.w = a.w > 0.f ? s.w : 0.f;
+  reinterpret_cast<float4*>(dx)[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+int small_forward(SmallWorkspace& ws, const float* P, long conv_off, long cam_stride, const uint8_t* frames,
+                  long frame_cam_stride, int n_cam, int n, float* pooled, long pooled_cam_stride, hipStream_t stream) {
+  const long n_img = (long)n_cam * n;
+  SERL_REQUIRE(n_img > 0 && n_img <= ws.max_images, "small_forward: %ld images exceed the workspace (%d)", n_img, ws.max_images);
+  const SmallDims& d = ws.d;
+  SERL_REQUIRE(d.h[kSmallLayers] >= 1 && d.w[kSmallLayers] >= 1, "image too small for the SmallEncoder");
+  ProfScope prof("small_encoder_fwd", stream);
+  for (int l = 0; l < kSmallLayers; ++l) {
+    const int cin = kSmallFeat[l], cout = kSmallFeat[l + 1], K = 9 * cin + 1, pitch = ldk(l);
+    const long rows = rows_of(d, l, n_img), rows_cam = rows_of(d, l, n);
+    const long tot = rows * 10;
+    if (l == 0)
+      hipLaunchKernelGGL(small_im2col_kernel<true>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const void*)frames, ws.col[0],
+                         rows, d.h[0], d.w[0], d.h[1], d.w[1], cin, pitch, n, frame_cam_stride);
+    else
+      hipLaunchKernelGGL(small_im2col_kernel<false>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const void*)ws.act[l - 1],
+                         ws.col[l], rows, d.h[l], d.w[l], d.h[l + 1], d.w[l + 1], cin, pitch, n, (long)n);
+    SERL_HIP(hipGetLastError());
+    GemmDesc g{};   // act[cam] = col[cam] ([rows_cam][K+1]) x [kernel ; bias]_cam ([K+1][cout])
+    g.A = ws.col[l]; g.sAm = pitch; g.sAk = 1; g.sAb = rows_cam * pitch;
+    g.B = P + conv_off + small_conv_offset(l); g.sBk = cout; g.sBn = 1; g.sBb = cam_stride;
+    g.C = ws.act[l]; g.ldc = cout; g.sCz = rows_cam * cout;
+    g.M = (int)rows_cam; g.N = cout; g.K = K; g.nbatch = n_cam; g.splitk = 1;
+    int rc = gemm_f32(g, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(small_relu_kernel, dim3(cdiv(rows * cout / 4, 256)), dim3(256), 0, stream, ws.act[l], rows * cout / 4);
+    SERL_HIP(hipGetLastError());
+  }
+  const int P4 = d.h[kSmallLayers] * d.w[kSmallLayers];
+  hipLaunchKernelGGL(small_avgpool_kernel, dim3((int)n_img), dim3(256), 0, stream, ws.act[kSmallLayers - 1], pooled, n, P4,
+                     pooled_cam_stride);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_stride, int n_cam, int n, const float* dpooled,
+                   long dp_cam_stride, float* G, hipStream_t stream) {
+  const long n_img = (long)n_cam * n;
+  const SmallDims& d = ws.d;
+  ProfScope prof("small_encoder_bwd", stream);
+  const int P4 = d.h[kSmallLayers] * d.w[kSmallLayers];
+  float* dy = ws.dact;
+  float* dnext = ws.dact2;
+  hipLaunchKernelGGL(small_avgpool_bwd_kernel, dim3((int)n_img), dim3(256), 0, stream, dpooled, ws.act[kSmallLayers - 1], dy, n,
+                     P4, dp_cam_stride);
+  SERL_HIP(hipGetLastError());
+  for (int l = kSmallLayers - 1; l >= 0; --l) {
+    const int cin = kSmallFeat[l], cout = kSmallFeat[l + 1], K = 9 * cin + 1, pitch = ldk(l);
+    const long rows_cam = rows_of(d, l, n);
+    {  // [dkernel ; dbias]_cam = col_cam^T x dy_cam, K-split over the rows, written into the gradient arena
+      int S = (int)std::min<long>(64, std::max<long>(1, rows_cam / 2048));
+      while (S > 1 && (long)S * n_cam * K * cout > ws.slabs_cap) S >>= 1;
+      GemmDesc g{};
+      g.A = ws.col[l]; g.sAm = 1; g.sAk = pitch; g.sAb = rows_cam * pitch;
+      g.B = dy; g.sBk = cout; g.sBn = 1; g.sBb = rows_cam * cout;
+      g.M = K; g.N = cout; g.K = (int)rows_cam; g.nbatch = n_cam; g.splitk = S;
+      float* out = G + conv_off + small_conv_offset(l);
+      if (S == 1) {
+        g.C = out; g.ldc = cout; g.sCz = cam_stride;
+        int rc = gemm_f32(g, stream);
+        if (rc) return rc;
+      } else {
+        g.C = ws.slabs; g.ldc = cout; g.sCz = (long)K * cout;
+        int rc = gemm_f32(g, stream);
+        if (rc) return rc;
+        rc = reduce_slabs(ws.slabs, S, (long)K * cout, n_cam, K, cout, nullptr, 0, out, cout, cam_stride, false, stream);
+        if (rc) return rc;
+      }
+    }
+    if (l == 0) break;   // the pixels need no gradient
+    {  // dcol_cam = dy_cam x kernel_cam^T  (the ones column has no input below it)
+      GemmDesc g{};
+      g.A = dy; g.sAm = cout; g.sAk = 1; g.sAb = rows_cam * cout;
+      g.B = P + conv_off + small_conv_offset(l); g.sBk = 1; g.sBn = cout; g.sBb = cam_stride;
+      g.C = ws.dcol; g.ldc = pitch; g.sCz = rows_cam * pitch;
+      g.M = (int)rows_cam; g.N = K - 1; g.K = cout; g.nbatch = n_cam; g.splitk = 1;
+      int rc = gemm_f32(g, stream);
+      if (rc) return rc;
+    }
+    const long tot = n_img * d.h[l] * d.w[l] * (cin / 4);
+    hipLaunchKernelGGL(small_col2im_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.dcol, ws.act[l - 1], dnext, n_img,
+                       d.h[l], d.w[l], d.h[l + 1], d.w[l + 1], cin, pitch);
+    SERL_HIP(hipGetLastError());
+    std::swap(dy, dnext);
+  }
+  return SERL_OK;
+}
+
+}  // namespace serl

@@ -104,8 +104,9 @@ def load_state_dict(agent, sd: dict):
     """Loads any of {params, target_params, opt_states, step} (flax-layout trees, e.g. a restored checkpoint or
     `agent.state.replace(...)` arguments) into the agent's HBM arena."""
     core, keys = agent.core, agent.image_keys
-    tp = theta_paths(keys)
-    trunk = _trunk_paths() if keys else {}   # the state-only agent has no encoder
+    etype = "small" if core.cfg.encoder_type == 1 else "resnet-pretrained"
+    tp = theta_paths(keys, encoder_type=etype)
+    trunk = _trunk_paths() if (keys and etype != "small") else {}   # state-only / SmallEncoder agents have no frozen trunk
     for section in ("params", "target_params"):
         tree = sd.get(section)
         if tree is None:

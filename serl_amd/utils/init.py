@@ -41,7 +41,11 @@ def feat_hw(H, W):
     return h, w
 
 
-def theta_shapes(n_cam, H, W, S, A, ensemble=10, hidden=256, bottleneck=256, sle_features=8, proprio_dim=64):
+SMALL_FEATURES = (3, 32, 64, 128, 256)   # SmallEncoder(features=(32, 64, 128, 256)) on RGB (drq.py:140-151)
+
+
+def theta_shapes(n_cam, H, W, S, A, ensemble=10, hidden=256, bottleneck=256, sle_features=8, proprio_dim=64,
+                 encoder_type="resnet-pretrained"):
     if n_cam == 0:   # state-only SAC (SACAgent.create_states, sac.py:486-542): no encoder, per-member Q heads
         N, Hd = ensemble, hidden
         return {
@@ -58,8 +62,14 @@ def theta_shapes(n_cam, H, W, S, A, ensemble=10, hidden=256, bottleneck=256, sle
     E = bottleneck * n_cam + proprio_dim
     sh = {}
     for k in range(n_cam):
-        sh[f"enc/{k}/sle"] = (fh, fw, 512, sle_features)
-        sh[f"enc/{k}/dense/kernel"] = (512 * sle_features, bottleneck)
+        if encoder_type == "small":    # 4 x Conv(3x3, stride 2, VALID) with bias, then mean-pool -> Dense(256)
+            for l in range(4):
+                sh[f"enc/{k}/conv{l}/kernel"] = (3, 3, SMALL_FEATURES[l], SMALL_FEATURES[l + 1])
+                sh[f"enc/{k}/conv{l}/bias"] = (SMALL_FEATURES[l + 1],)
+            sh[f"enc/{k}/dense/kernel"] = (SMALL_FEATURES[4], bottleneck)
+        else:
+            sh[f"enc/{k}/sle"] = (fh, fw, 512, sle_features)
+            sh[f"enc/{k}/dense/kernel"] = (512 * sle_features, bottleneck)
         sh[f"enc/{k}/dense/bias"] = (bottleneck,)
         sh[f"enc/{k}/ln/scale"] = (bottleneck,)
         sh[f"enc/{k}/ln/bias"] = (bottleneck,)
@@ -97,6 +107,8 @@ def init_theta(n_cam, H, W, S, A, seed=42, temperature_init=1e-2, **kw):
     out = {}
     for name, shp in theta_shapes(n_cam, H, W, S, A, **kw).items():
         if name.endswith("/sle"):  # lecun_normal over (h,w,c) (resnet_v1.py:86)
+            out[name] = (rng.standard_normal(shp) / math.sqrt(shp[0] * shp[1] * shp[2])).astype(np.float32)
+        elif name.startswith("enc/") and "/conv" in name and name.endswith("kernel"):   # nn.Conv default lecun_normal
             out[name] = (rng.standard_normal(shp) / math.sqrt(shp[0] * shp[1] * shp[2])).astype(np.float32)
         elif name.startswith("enc/") and name.endswith("dense/kernel") and "proprio" not in name:
             out[name] = (rng.standard_normal(shp) / math.sqrt(shp[0])).astype(np.float32)  # nn.Dense default

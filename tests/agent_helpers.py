@@ -17,7 +17,7 @@ def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0, trun
     from serl_amd.agents.core import AgentCore
     trunk, theta = O.init_params(cfg, seed)
     st = O.TrainState(cfg, trunk, theta, dtype)
-    core = AgentCore(n_cam=cfg.n_cam, H=cfg.H, W=cfg.W, state_dim=cfg.S, act_dim=cfg.A, batch=B,
+    core = AgentCore(encoder_type=cfg.encoder_type, n_cam=cfg.n_cam, H=cfg.H, W=cfg.W, state_dim=cfg.S, act_dim=cfg.A, batch=B,
                      ensemble=cfg.ensemble, discount=cfg.discount, tau=cfg.tau, lr=cfg.lr,
                      warmup_steps=cfg.warmup, dropout=cfg.dropout, std_min=cfg.std_min, std_max=cfg.std_max,
                      target_entropy=cfg.target_entropy, seed=agent_seed,
@@ -73,7 +73,7 @@ def noise_to_device(cfg, noise):
         if k.startswith("eps"):
             out[k] = torch.tensor(v, device="cuda")
         elif k.startswith("mask"):
-            if cfg.image_keys:
+            if cfg.image_keys and v:
                 out[k] = torch.tensor(np.stack([v[c] for c in cfg.image_keys]), device="cuda")
         elif k == "redq_idx":
             out[k] = np.asarray(v, np.int32)

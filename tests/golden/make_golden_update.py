@@ -34,6 +34,11 @@ CASES = {
                                 opt={"critic": {"learning_rate": 1e-3, "warmup_steps": 3, "cosine_decay_steps": 6, "clip_grad_norm": 0.5},
                                      "actor": {"warmup_steps": 2}, "temperature": {"clip_grad_norm": 0.01, "learning_rate": 1e-2}}), 6,
                        [("critics",), ("update", ("actor", "critic", "temperature")), ("high_utd", 2), ("critics",), ("critics",), ("critics",)]),
+    # the trainable SmallEncoder (vision/small_encoders.py:9-55 via create_drq(encoder_type="small"), run with the
+    # 3-line kwarg adapter of oracle/ref_update_runner.py for the reference's own call-site defect): the critic loss
+    # back-propagates into the conv kernels, the target critic uses the EMA'd encoder
+    "drq_small_encoder": (O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3, encoder_type="small"), 6,
+                          [("critics",), ("high_utd", 2), ("update", ("actor", "critic", "temperature")), ("critics",)]),
     # state-only SAC exactly as the reference's make_sac_agent builds it (launcher.py:50-76: warm-up 2000 for actor and
     # critic, none for the temperature) ...
     "sac_state": (O.Config(image_keys=(), S=10, A=4, discount=0.99, warmup=2000, temp_warmup=0), 8,

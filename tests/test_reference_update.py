@@ -75,7 +75,7 @@ def test_oracle_reproduces_the_reference_golden(path):
 
 
 def test_golden_fixtures_exist():
-    assert len(GOLDEN) >= 7, "tests/golden/update_*.npz missing: run tests/golden/make_golden_update.py in the build container"
+    assert len(GOLDEN) >= 8, "tests/golden/update_*.npz missing: run tests/golden/make_golden_update.py in the build container"
 
 
 needs_ref = pytest.mark.skipif(not RS.reference_available(), reason="/root/reference not present (GPU box)")
