@@ -64,8 +64,8 @@ def test_small_encoder_sequence(gpu):
         got = core.read_info()
         for k, v in info.items():
             assert abs(got[k] - v) < 2 * TOL * max(1.0, abs(v)), (it, kind, k, got[k], v)
-    _compare_state(cfg, st, core, steps=8)
-    assert core.step == st.step == 8
+    _compare_state(cfg, st, core, steps=9)
+    assert core.step == st.step == 9    # 1 + (2 + 1) + 1 + 1 + (2 + 1) optimizer steps
 
 
 def test_small_encoder_python_surface(gpu):
