@@ -552,6 +552,7 @@ size_t trunk_packed_bytes() {
       off += 2 * al256((size_t)K * Cout * 2);
     }
   off += 2 * al256((size_t)64 * 224 * 2);   // conv_init planes (u8 variant: [64][224]; the 3-product variant uses [64][176] of it)
+  off += 256;                                // zero page (the agent arena is zero-initialised and nothing writes here)
   return off;
 }
 
@@ -569,6 +570,7 @@ int trunk_packed_bind(TrunkPacked& p, void* mem) {
     }
   p.init.hi = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
   p.init.lo = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
+  p.zero = b + off; off += 256;
   p.dirty = true;
   return SERL_OK;
 }

@@ -33,6 +33,7 @@ struct ConvArgsB {
   const uint16_t* whi;  // [Cout][K]
   const uint16_t* wlo;
   int K;
+  int dbg;              // timing experiments only (SERL_CONV_DBG): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no LDS reads
 };
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
     }                                                                                                          \
     OK = 0;                                                                                                    \
+    if (!(ab.dbg & 2)) {                                                                                       \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       const bool ok = (rmask[i] >> tap) & 1u;                                                                  \
       OK |= (ok ? 1u : 0u) << i;                                                                               \
@@ -129,22 +131,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (min(c_, nchunks - 1) << 5) + s_ * 8; \
       RB[i] = *reinterpret_cast<const u32x4*>(wp_);                                                            \
     }                                                                                                          \
+    }                                                                                                          \
   }
 #define SERL_STORE_CHUNK_(BUF, RA, RB, OK)                                                                                  \
   {                                                                                                            \
     uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
+    if (!(ab.dbg & 4)) {                                                                                       \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       u32x4 v = RA[i];                                                                                         \
       if (!((OK >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                                      \
       const int row_ = (tid >> 3) + 32 * i;                                                                    \
-      const int off_ = swz(row_, kq >> 1) + (kq & 1) * 8;                                                      \
-      *reinterpret_cast<u32x2*>(st_ + off_) = (u32x2){v[0], v[1]};                                             \
-      *reinterpret_cast<u32x2*>(st_ + A_PLANE + off_) = (u32x2){v[2], v[3]};                                   \
+      *reinterpret_cast<u32x4*>(st_ + (kq & 1) * A_PLANE + swz(row_, kq >> 1)) = v;  /* unit kq = plane kq&1 */ \
     }                                                                                                          \
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
       *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = RB[i];                   \
+    }                                                                                                          \
     }                                                                                                          \
   }
 
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   {                                                                                                            \
     const uint8_t* st = smemb + (BUF) * STAGE;                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];                                                                \
+      f16x8 ahi[TM] = {}, alo[TM] = {}, bhi[TN] = {}, blo[TN] = {};                                            \
+      if (!(ab.dbg & 8)) {                                                                                     \
       _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                      \
         const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);                                           \
         ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
@@ -173,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
         bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
         blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);                                         \
       }                                                                                                        \
+      }                                                                                                        \
+      if (!(ab.dbg & 1))                                                                                       \
       _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                        \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                    \
           accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);      \
@@ -220,6 +226,222 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 #undef SERL_STORE_CHUNK_
 #undef SERL_LOAD_CHUNK
 #undef SERL_STORE_CHUNK
+
+  const int wrow0 = m0 + wm * WROWS;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) {
+        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+      }
+    }
+  if (PMODE != 3) {
+    const int gsize = a.Cout / kGnGroups;
+    constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
+    constexpr int NSLOT = WROWS / ROWS;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; ++slot) {
+      const int mrow = wrow0 + slot * ROWS;
+      const bool valid = mrow < a.M;
+      const int n = valid ? mrow / a.P : 0;
+      double* stp = a.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = tm * 32 + 8 * (r >> 2);
+            if (row / ROWS == slot) {
+              const float v = acc[tm][tn][r];
+              s += v;
+              q += v * v;
+            }
+          }
+        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the implicit GEMM (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through registers).
+// The register-staged kernel above serialises its phases -- measured on b2_conv1: MFMA-only 164 us, + LDS fragment
+// reads 8, + ds_write staging 34, + global-load waits 57 = 263 us -- because a chunk's loads have only one MFMA
+// phase to land and the staging registers (32 per chunk in flight) leave no room for a deeper pipeline next to two
+// 64-register accumulator sets.  Here a chunk is fetched by 16-byte LDS-DMA pieces issued one (NSTAGE = 2) or two
+// (NSTAGE = 3) chunks ahead: no staging registers, no ds_write pass, counted vmcnt waits, one raw s_barrier per chunk.
+//   * a DMA piece is 64 lanes x 16 B written lane-linearly, so swizzles are applied to the SOURCE address: a piece of
+//     the activation tile is 8 rows x 8 units (a row chunk = 32 channels = [hi8 lo8] x 4 in the split8 layout) and
+//     lane l fetches unit (l&7) ^ ((row>>1)&7) of row l>>3; a piece of a weight plane is 16 rows x 4 units and lane l
+//     fetches unit (l&3) ^ ((row>>2)&3).  Fragment reads apply the same XOR: conflict-free ds_read_b128.
+//   * out-of-image taps fetch from a zero page (the DMA cannot zero-fill).
+// Tile 128 x (64*TN) with 4 waves of 64 x (32*TN); epilogue identical to the register-staged kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int TN, int NSTAGE, int PMODE>
+__global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN, BM = 128, BN = 2 * WCOLS;
+  constexpr int A_BYTES = BM * 128, B_PLANE = BN * 64, STAGE = A_BYTES + 2 * B_PLANE;
+  constexpr int A_PIECES = BM / 8 / 4;            // per wave per chunk
+  constexpr int B_PIECES = 2 * (BN / 16) / 4;     // per wave per chunk (both planes)
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int ntaps = a.KH * a.KW;
+  // activation pieces of this wave: piece q covers tile rows (q*4 + wave)*8 .. +7; this lane's row / unit in it
+  unsigned rbase[A_PIECES];   // byte offset of the centre tap's pixel (+ this lane's swizzled unit)
+  unsigned rmask[A_PIECES];
+  const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(a.in);
+#pragma unroll
+  for (int q = 0; q < A_PIECES; ++q) {
+    const int row = (q * 4 + wave) * 8 + (lane >> 3);
+    const int u = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    rbase[q] = 0; rmask[q] = 0;
+    if (m < a.M) {
+      const int n = m / a.P, rem = m - n * a.P;
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      rbase[q] = (unsigned)((((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin) * 4 + u * 16);
+      for (int t = 0; t < ntaps; ++t) {
+        const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
+        if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) rmask[q] |= 1u << t;
+      }
+    }
+  }
+  // weight pieces: piece q -> plane / first row; this lane's row and swizzled unit
+  const uint8_t* wsrc[B_PIECES];
+#pragma unroll
+  for (int q = 0; q < B_PIECES; ++q) {
+    const int pb = q * 4 + wave, plane = pb / (BN / 16), prow = (pb % (BN / 16)) * 16 + (lane >> 2);
+    const int su = (lane & 3) ^ ((prow >> 2) & 3);
+    wsrc[q] = reinterpret_cast<const uint8_t*>(plane ? ab.wlo : ab.whi) + ((size_t)(n0 + prow) * ab.K) * 2 + su * 16;
+  }
+  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_chunk = 0;   // counters of the next chunk to latch (strictly in order)
+  const uint8_t* zp = zero_page + (lane & 7) * 16;
+
+  // One piece of the NEXT chunk (tap / channel offset in nx_*): pieces [0, A_PIECES) are activation pieces, the rest
+  // weight pieces.  Issued one at a time between the MFMA groups of the current chunk: an LDS-DMA instruction costs
+  // ~60 issue cycles among MFMAs but several hundred when eight of them sit in a row ahead of the MFMAs.
+  int nx_tap = 0, nx_toff = 0, nx_chunk = 0, nx_stage = 0;
+#define SERL_DMA_PIECE(PI)                                                                                     \
+  {                                                                                                            \
+    uint8_t* st_ = smemb + nx_stage * STAGE;                                                                   \
+    if ((PI) < A_PIECES) {                                                                                     \
+      const int q = (PI) < A_PIECES ? (PI) : 0;                                                                \
+      const bool ok = (rmask[q] >> nx_tap) & 1u;                                                               \
+      const uint8_t* src = ok ? in_bytes + (size_t)rbase[q] + (long)nx_toff : zp;                              \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st_ + (q * 4 + wave) * 1024), 16, 0, 0); \
+    } else {                                                                                                   \
+      const int q = (PI) >= A_PIECES ? (PI) - A_PIECES : 0;                                                    \
+      const int pb = q * 4 + wave, plane = pb / (BN / 16), prow0 = (pb % (BN / 16)) * 16;                      \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[q] + (size_t)nx_chunk * 64),                         \
+                                       (lds_void_t*)(st_ + A_BYTES + plane * B_PLANE + prow0 * 64), 16, 0, 0); \
+    }                                                                                                          \
+  }
+  // latch the addressing of chunk l_chunk into nx_* and advance the counters
+#define SERL_DMA_NEXT(STG)                                                                                     \
+  {                                                                                                            \
+    /* past the last chunk the counters stop: the last chunk is fetched again into the free stage (no branch */ \
+    /* around the DMA instructions inside the MFMA block; one wasted chunk of traffic per tile)              */ \
+    nx_tap = l_tap; nx_chunk = l_chunk; nx_stage = (STG);                                                      \
+    nx_toff = (((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + l_ci0) * 4;                                 \
+    if (l_chunk + 1 < nchunks) {                                                                               \
+      ++l_chunk;                                                                                               \
+      l_ci0 += 32;                                                                                             \
+      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
+    }                                                                                                          \
+  }
+#define SERL_DMA_ISSUE_ALL()                                                                                   \
+  {                                                                                                            \
+    SERL_DMA_PIECE(0) SERL_DMA_PIECE(1) SERL_DMA_PIECE(2) SERL_DMA_PIECE(3)                                    \
+    if (PIECES > 4) SERL_DMA_PIECE(4) if (PIECES > 5) SERL_DMA_PIECE(5)                                        \
+    if (PIECES > 6) SERL_DMA_PIECE(6) if (PIECES > 7) SERL_DMA_PIECE(7)                                        \
+  }
+
+  f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  int aoff[TM], asw[TM], boff[TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = wm * WROWS + tm * 32 + li;
+    aoff[tm] = row * 128;
+    asw[tm] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) boff[tn] = wn * WCOLS + tn * 32 + li;
+
+  // prologue: NSTAGE - 1 chunks in flight
+  SERL_DMA_NEXT(0);
+  SERL_DMA_ISSUE_ALL();
+  if (NSTAGE == 3) { SERL_DMA_NEXT(1); SERL_DMA_ISSUE_ALL(); }
+  constexpr int GROUPS = 2 * TM * TN;   // MFMA groups (3 MFMAs each) per chunk
+  for (int c = 0; c < nchunks; ++c) {
+    // chunk c has landed once at most the pieces of the chunks issued after it are outstanding
+    if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");   // every wave's pieces of chunk c are in LDS; stage (c-1) % NSTAGE is free
+    SERL_DMA_NEXT((c + NSTAGE - 1) % NSTAGE);  // the chunk to fetch during this iteration (if any)
+    const uint8_t* st = smemb + (c % NSTAGE) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int u = 2 * (2 * ks + lh);   // hi unit of this lane's k-block; the lo' unit is the next one
+        ahi[tm] = *reinterpret_cast<const f16x8*>(st + aoff[tm] + ((u ^ asw[tm]) << 4));
+        alo[tm] = *reinterpret_cast<const f16x8*>(st + aoff[tm] + (((u + 1) ^ asw[tm]) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int off = A_BYTES + swz(boff[tn], 2 * ks + lh);
+        bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);
+        blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
+          // one or two DMA pieces of the next chunk ride behind every MFMA group
+          const int g = (ks * TM + tm) * TN + tn;
+#pragma unroll
+          for (int pi = 0; pi < PIECES; ++pi)
+            if (pi % GROUPS == g) SERL_DMA_PIECE(pi)
+        }
+    }
+  }
+#undef SERL_DMA_PIECE
+#undef SERL_DMA_NEXT
+#undef SERL_DMA_ISSUE_ALL
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
 
   const int wrow0 = m0 + wm * WROWS;
 #pragma unroll
@@ -335,10 +557,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
       u32x4 v = ra[i];                                                                           \
       if (!((okmask >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                    \
       const int idx_ = tid + 256 * i;                                                            \
-      if (idx_ < MAXPIX * 4) {                                                                   \
-        *reinterpret_cast<u32x2*>(st_ + idx_ * 8) = (u32x2){v[0], v[1]};                         \
-        *reinterpret_cast<u32x2*>(st_ + A_PLANE + idx_ * 8) = (u32x2){v[2], v[3]};               \
-      }                                                                                          \
+      if (idx_ < MAXPIX * 4)   /* unit q = idx&3 of the pixel's 16 channels: plane q&1, 8-channel block q>>1 */ \
+        *reinterpret_cast<u32x4*>(st_ + (idx_ & 1) * A_PLANE + (idx_ >> 2) * 32 + ((idx_ >> 1) & 1) * 16) = v; \
     }                                                                                            \
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
       *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + kx * B_TAP + tid * 16) = rb[kx];             \
@@ -1053,14 +1273,22 @@ int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, i
 // ---------------------------------------------------------------------------------------------
 // elementwise producers of the split16 layout
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 to_split16(float4 v) {
+// The "split8" activation layout (same footprint and pixel addressing as the fp32 NHWC tensor): per 8 channels a
+// 16-byte unit of hi x8 fp16 followed by a 16-byte unit of lo' x8 fp16.  A conv loader then moves whole 16-byte units
+// (global -> LDS, by register or by LDS-DMA) and each unit IS an MFMA k-block of one plane.  Element e indexes
+// (pixel, 4-channel group): its hi half lands at byte e*16 - (e&1)*8, its lo' half 16 bytes further.
+__device__ __forceinline__ void store_split8(void* out, long e, float4 v) {
   uint2 hi, lo;
   split4(v, hi, lo);
-  return make_uint4(hi.x, hi.y, lo.x, lo.y);
+  uint8_t* p = static_cast<uint8_t*>(out) + e * 16 - (e & 1) * 8;
+  *reinterpret_cast<uint2*>(p) = hi;
+  *reinterpret_cast<uint2*>(p + 16) = lo;
 }
-__device__ __forceinline__ float4 from_split16(uint4 u) {
-  const h16x2 h0 = __builtin_bit_cast(h16x2, u.x), h1 = __builtin_bit_cast(h16x2, u.y);
-  const h16x2 l0 = __builtin_bit_cast(h16x2, u.z), l1 = __builtin_bit_cast(h16x2, u.w);
+__device__ __forceinline__ float4 load_split8(const void* in, long e) {
+  const uint8_t* p = static_cast<const uint8_t*>(in) + e * 16 - (e & 1) * 8;
+  const uint2 uh = *reinterpret_cast<const uint2*>(p), ul = *reinterpret_cast<const uint2*>(p + 16);
+  const h16x2 h0 = __builtin_bit_cast(h16x2, uh.x), h1 = __builtin_bit_cast(h16x2, uh.y);
+  const h16x2 l0 = __builtin_bit_cast(h16x2, ul.x), l1 = __builtin_bit_cast(h16x2, ul.y);
   return make_float4((float)h0[0] + (float)l0[0] * kLoInv, (float)h0[1] + (float)l0[1] * kLoInv,
                      (float)h1[0] + (float)l1[0] * kLoInv, (float)h1[1] + (float)l1[1] * kLoInv);
 }
@@ -1095,7 +1323,7 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_split_kernel(const float*
       m.w = fmaxf(m.w, fmaxf(v.w * s.w + h.w, 0.f));
     }
   }
-  out[e] = to_split16(m);
+  store_split8(out, e, m);
 }
 
 // Second half of the fused pool: completes the windows that cross a tile edge from the neighbours' first row / column,
@@ -1150,7 +1378,7 @@ __global__ __launch_bounds__(256) void pool_finish_split_kernel(const float* poo
     m.x *= sg.x; m.y *= sg.y; m.z *= sg.z; m.w *= sg.w;  // back to the raw extreme
     m.x = fmaxf(m.x * s.x + h.x, 0.f); m.y = fmaxf(m.y * s.y + h.y, 0.f);
     m.z = fmaxf(m.z * s.z + h.z, 0.f); m.w = fmaxf(m.w * s.w + h.w, 0.f);
-    out[o] = to_split16(m);
+    store_split8(out, (long)o, m);
   }
 }
 
@@ -1165,8 +1393,8 @@ __global__ __launch_bounds__(256) void gn_relu_split_kernel(const float* raw, Gn
   const float4 v = reinterpret_cast<const float4*>(raw)[e];
   float4 s, h;
   gn_coef4(gn, n, c4 * 4, s, h);
-  out[e] = to_split16(make_float4(fmaxf(v.x * s.x + h.x, 0.f), fmaxf(v.y * s.y + h.y, 0.f),
-                                  fmaxf(v.z * s.z + h.z, 0.f), fmaxf(v.w * s.w + h.w, 0.f)));
+  store_split8(out, e, make_float4(fmaxf(v.x * s.x + h.x, 0.f), fmaxf(v.y * s.y + h.y, 0.f),
+                                   fmaxf(v.z * s.z + h.z, 0.f), fmaxf(v.w * s.w + h.w, 0.f)));
 }
 
 // block output: relu(GN(raw_b) + residual); residual = x (split16) or GN(raw_proj); out split16 or fp32
@@ -1188,7 +1416,7 @@ __global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, 
     gn_coef4(rgn, n, c4 * 4, s2, h2);
     r.x = r.x * s2.x + h2.x; r.y = r.y * s2.y + h2.y; r.z = r.z * s2.z + h2.z; r.w = r.w * s2.w + h2.w;
   } else {
-    r = from_split16(res_split[e]);
+    r = load_split8(res_split, e);
   }
   float4 o;
   o.x = fmaxf(r.x + (v.x * s.x + h.x), 0.f);
@@ -1196,12 +1424,12 @@ __global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, 
   o.z = fmaxf(r.z + (v.z * s.z + h.z), 0.f);
   o.w = fmaxf(r.w + (v.w * s.w + h.w), 0.f);
   if (out_f32) reinterpret_cast<float4*>(out_f32)[e] = o;
-  else out_split[e] = to_split16(o);
+  else store_split8(out_split, e, o);
 }
 
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                             hipStream_t stream) {
+                             hipStream_t stream, const uint8_t* zero_page = nullptr) {
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgsB ab{};
   ConvArgs& a = ab.c;
@@ -1212,6 +1440,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
   ab.whi = w.hi; ab.wlo = w.lo; ab.K = ksz * ksz * Cin;
+  static const int conv_dbg = []() { const char* e = getenv("SERL_CONV_DBG"); return e ? atoi(e) : 0; }();
+  ab.dbg = conv_dbg;
   int cfg = Cout >= 128 ? 0 : 1;
   if (cfg == 0 && (long)cdiv(a.M, 128) * (Cout / 128) < 512) cfg = 2;
   // in between: 128x64 tiles (waves of 64x32) with three chunks in flight when there are enough of them
@@ -1238,9 +1468,33 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     const bool rp_ok = use_rp && ksz == 3 && stride == 1 && Cout == 64 && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
                        (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 &&
                        (long)N * Hi * Wi * Cin < (1L << 31);
+    // SERL_CONV_DMA: 0 = register-staged kernels only, 2 / 3 = LDS-DMA kernel with that many LDS stages (default 2)
+    static const int dma = []() { const char* e = getenv("SERL_CONV_DMA"); return e ? atoi(e) : 2; }();
+    const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4) && Cin % 32 == 0 && zero_page != nullptr &&
+                        (long)N * Hi * Wi * Cin * 4 < (1L << 32);
     if (rp_ok) {
       hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),
                          stream, ab);
+    } else if (dma_ok) {
+      static const int force_tn = []() { const char* e = getenv("SERL_CONV_DMA_TN"); return e ? atoi(e) : 0; }();
+      const int tn = force_tn ? force_tn : (cfg == 0 ? 2 : 1), bn = 64 * tn;
+      a.tiles_m = cdiv(a.M, 128); a.tiles_n = Cout / bn;
+      const dim3 g(a.tiles_m * a.tiles_n);
+      const int nst = dma >= 3 ? 3 : 2;
+      const size_t l = (size_t)nst * (128 * 128 + 2 * bn * 64);
+      if (pmode == 1 && cfg == 4) pmode = 3;
+#define SERL_LAUNCH_DMA(TN_, NS_)                                                                                        \
+  do {                                                                                                                   \
+    if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 0>), g, block, l, stream, ab, zero_page);        \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 1>), g, block, l, stream, ab, zero_page);   \
+    else if (pmode == 2) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 2>), g, block, l, stream, ab, zero_page);   \
+    else hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 3>), g, block, l, stream, ab, zero_page);                   \
+  } while (0)
+      if (tn == 2 && nst == 2) SERL_LAUNCH_DMA(2, 2);
+      else if (tn == 2) SERL_LAUNCH_DMA(2, 3);
+      else if (nst == 2) SERL_LAUNCH_DMA(1, 2);
+      else SERL_LAUNCH_DMA(1, 3);
+#undef SERL_LAUNCH_DMA
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
     else if (cfg == 4) {
@@ -1325,9 +1579,9 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
     auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo}; };
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero))) return rc;
     if (has_proj)
-      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream))) return rc;
+      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
     const long tot = (long)N * P * (f / 4);
     {
       ProfScope prof("gn_relu_split", stream);
@@ -1335,7 +1589,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
                          gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), reinterpret_cast<uint4*>(ws.blk[i].norm0), N, P, f);
       SERL_HIP(hipGetLastError());
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero))) return rc;
     const bool last = i == kTrunkStages - 1;
     {
       ProfScope prof("block_out", stream);
