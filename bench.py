@@ -74,8 +74,9 @@ def main():
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
-    ap.add_argument("--workload", choices=["drq", "sac_state"], default="drq",
-                    help="drq: the official bench line; sac_state: side measurement of configs[0] (state-only SAC)")
+    ap.add_argument("--workload", choices=["drq", "sac_state", "actor_latency"], default="drq",
+                    help="drq: the official bench line; sac_state: side measurement of configs[0] (state-only SAC); "
+                         "actor_latency: side measurement of the actor-side policy forward (sample_actions, batch 1)")
     ap.add_argument("--prio", choices=["auto", "update", "trunk", "none"], default="auto",
                     help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
@@ -88,6 +89,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "sac_state":
         return sac_state_main(max(args.steps, 50))
+    if args.workload == "actor_latency":
+        return actor_latency_main(max(args.steps, 200))
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -335,6 +338,42 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def actor_latency_main(iters):
+    """Side measurement (NOT the official bench line), next-row N3: the actor's policy forward
+    `agent.sample_actions(obs, seed=...)` / `argmax=True` (sac.py:301-320; call sites async_drq_sim.py:126-136 and the
+    eval loop) on ONE observation (2 x 128x128x3 + 24-d state): host wall time per call incl. the H2D of the observation
+    and the D2H of the action, and the device-only time of the enqueued kernels."""
+    from serl_amd.utils.launcher import make_drq_agent
+    obs0 = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8), "state": np.zeros((1, S), np.float32)}
+    agent = make_drq_agent(42, obs0, np.zeros((A,), np.float32), image_keys=KEYS, encoder_type="resnet-pretrained", batch_size=8)
+    rng = np.random.default_rng(0)
+    obs = {"front": rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8), "wrist": rng.integers(0, 256, (1, H, W, 3), dtype=np.uint8),
+           "state": rng.standard_normal((1, S)).astype(np.float32)}
+    for _ in range(20):
+        agent.sample_actions(obs, argmax=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        a = agent.sample_actions(obs, seed=np.array([0, i], np.uint32))
+    wall = (time.perf_counter() - t0) / iters
+    # device-only: frames already in HBM, no readback
+    fr = torch.tensor(np.stack([obs[k].reshape(1, H, W, 3) for k in KEYS]), device="cuda")
+    st = torch.tensor(obs["state"].reshape(1, -1), device="cuda")
+    eps = torch.zeros((1, A), device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        agent.core.sample_actions(fr, st, eps)
+    e1.record()
+    torch.cuda.synchronize()
+    dev = e0.elapsed_time(e1) / iters
+    print(json.dumps({"workload": "actor-side sample_actions, batch 1 (2 x 128x128x3 + 24-d state)", "calls": iters,
+                      "host_ms_per_call": round(wall * 1e3, 4), "device_ms_per_call": round(dev, 4),
+                      "actions_per_s": round(1.0 / wall, 1), "action": [round(float(x), 4) for x in np.asarray(a).reshape(-1)],
+                      "note": "a real actor steps its env at 10-20 Hz: the policy forward is not its bottleneck"}))
 
 
 def sac_state_main(iters):
