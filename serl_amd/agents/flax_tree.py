@@ -144,9 +144,13 @@ def export_tree(core, section: str, image_keys, duplicate_encoder_under_critic: 
 
 
 def trunk_from_flax(pretrained: Dict) -> Dict[str, np.ndarray]:
-    """resnet10_params.pkl tree (top-level keys matched by name, train_utils.py:124-127) -> flat leaves."""
+    """resnet10_params.pkl tree -> flat leaves.  Top-level keys are matched by name and a top-level key the pickle
+    does not hold keeps its current value (train_utils.py:124-127: `for k in new_encoder_params: if k in encoder_params`);
+    a top-level key that is present must hold the whole sub-tree."""
     out = {}
     for leaf, sub in _trunk_paths().items():
+        if sub[0] not in pretrained:
+            continue
         d = pretrained
         for p in sub:
             d = d[p]

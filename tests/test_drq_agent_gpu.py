@@ -203,3 +203,36 @@ def test_learner_example_with_the_transport_endpoint(gpu):
     assert r.returncode == 0, r.stderr[-3000:]
     done = [ln for ln in r.stdout.splitlines() if ln.startswith("done:")]
     assert done and "18 grad-steps" in done[0] and "modules_actor" in done[0], r.stdout[-2000:]
+
+
+def test_load_resnet10_params_from_a_synthetic_pickle(gpu, tmp_path):
+    """N1: load_resnet10_params (train_utils.py:69-130) on a pickle shaped like resnet10_params.pkl: the trunk leaves in
+    HBM (params AND target_params: sac.py:378-382 makes them one tree when the reference patches it) become the
+    pickle's, the trainable leaves are untouched, and the trunk features change to those of the new weights."""
+    import pickle
+    from serl_amd.agents.flax_tree import _trunk_paths
+    from serl_amd.utils import init as pinit
+    from serl_amd.utils.train_utils import load_resnet10_params
+    env, rb, agent = _setup(B=8)
+    new = pinit.init_trunk(seed=77)
+    tree = {}
+    for leaf, sub in _trunk_paths().items():
+        d = tree
+        for p in sub[:-1]:
+            d = d.setdefault(p, {})
+        d[sub[-1]] = new[leaf]
+    f = tmp_path / "resnet10_params.pkl"
+    pickle.dump(tree, open(f, "wb"))
+    before_w1 = agent.core.get("params", "critic/w1").copy()
+    frames = torch.randint(0, 256, (4, H, W, 3), dtype=torch.uint8, device="cuda")
+    feat0 = agent.core.trunk_forward(frames).cpu().numpy()
+    assert load_resnet10_params(agent, KEYS, file_path=str(f)) is agent
+    for leaf in new:
+        for sec in ("params", "target_params"):
+            assert np.array_equal(agent.core.get(sec, leaf).reshape(-1), new[leaf].reshape(-1)), (sec, leaf)
+    assert np.array_equal(agent.core.get("params", "critic/w1"), before_w1)
+    feat1 = agent.core.trunk_forward(frames).cpu().numpy()
+    assert np.abs(feat1 - feat0).max() > 1e-3
+    other = _setup(B=8)[2]
+    other.load_trunk_params(tree)
+    assert np.array_equal(other.core.trunk_forward(frames).cpu().numpy(), feat1)

@@ -113,3 +113,45 @@ def test_bench_flop_model_matches_the_survey():
     assert 2 * m["conv_init"] == 77_070_336 and blocks == 503_316_480
     assert 2 * m["conv_init"] + blocks == 580_386_816
     assert sum(1 for k in m if k.startswith("conv_igemm")) == 11
+
+
+def _pickle_tree(trunk):
+    """A tree shaped like resnet10_params.pkl (train_utils.py:113-127: top-level keys conv_init / norm_init /
+    ResNetBlock_i matched against `pretrained_encoder`'s children)."""
+    from serl_amd.agents.flax_tree import _trunk_paths
+    t = {}
+    for leaf, sub in _trunk_paths().items():
+        d = t
+        for p in sub[:-1]:
+            d = d.setdefault(p, {})
+        d[sub[-1]] = trunk[leaf]
+    return t
+
+
+def test_pretrained_pickle_maps_onto_the_trunk_leaves(tmp_path):
+    """load_resnet10_params (train_utils.py:69-130) on a synthetic pickle: every leaf lands on its flat trunk leaf;
+    a top-level key the pickle lacks keeps its value (train_utils.py:124-127); a missing file is an error (no download)."""
+    import pickle
+    from serl_amd.agents.flax_tree import trunk_from_flax
+    from serl_amd.utils.train_utils import load_resnet10_params
+    trunk = pinit.init_trunk(seed=5)
+    tree = _pickle_tree(trunk)
+    assert set(tree) == {"conv_init", "norm_init", "ResNetBlock_0", "ResNetBlock_1", "ResNetBlock_2", "ResNetBlock_3"}
+    flat = trunk_from_flax(tree)
+    assert set(flat) == set(trunk)
+    for k in trunk:
+        np.testing.assert_array_equal(flat[k], trunk[k])
+    part = {k: v for k, v in tree.items() if k != "ResNetBlock_3"}
+    assert not any(k.startswith("trunk/block3/") for k in trunk_from_flax(part))
+    assert len(trunk_from_flax(part)) == len(trunk) - sum(k.startswith("trunk/block3/") for k in trunk)
+
+    class FakeAgent:
+        def load_trunk_params(self, t):
+            self.got = trunk_from_flax(t)
+            return self
+    f = tmp_path / "resnet10_params.pkl"
+    pickle.dump(tree, open(f, "wb"))
+    a = load_resnet10_params(FakeAgent(), ("front", "wrist"), file_path=str(f))
+    np.testing.assert_array_equal(a.got["trunk/block2/conv1"], trunk["trunk/block2/conv1"])
+    with pytest.raises(FileNotFoundError):
+        load_resnet10_params(FakeAgent(), ("front",), file_path=str(tmp_path / "absent.pkl"))
