@@ -174,6 +174,22 @@ __device__ __forceinline__ uint4 shifted_chunk(const uint8_t* srow, int q, int s
   return r;
 }
 
+// record gather: one thread per (sample, float of the record)
+__device__ __forceinline__ void gather_record(const GatherArgs& a, int e) {
+  const int i = e / a.rec_len, f = e - i * a.rec_len;
+  if (i >= a.batch) return;
+  const int buf = (i < a.count0) ? 0 : 1;
+  const int64_t slot = a.idx[buf][buf == 0 ? i : i - a.count0];
+  const float v = a.rec[buf][(size_t)slot * a.rec_len + f];
+  const int S = a.S, A = a.A;
+  if (f < S) a.out_state[(size_t)i * S + f] = v;
+  else if (f < 2 * S) a.out_state[((size_t)a.batch + i) * S + (f - S)] = v;
+  else if (f < 2 * S + A) a.out_action[(size_t)i * A + (f - 2 * S)] = v;
+  else if (f == 2 * S + A) a.out_reward[i] = v;
+  else if (f == 2 * S + A + 1) a.out_mask[i] = v;
+  else a.out_done[i] = (uint8_t)(v != 0.0f);
+}
+
 template <int CT>
 __global__ __launch_bounds__(256) void gather_crop_kernel(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -223,20 +239,93 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(GatherArgs a) {
       *reinterpret_cast<uint4*>(dst + (size_t)r * rowb + q * 16) = val;
     }
   } else if (!a.from_packed) {
-    // record gather: one thread per (sample, float of the record)
-    const int e = (blockIdx.x - a.n_frame_blocks) * 256 + tid;
-    const int i = e / a.rec_len, f = e - i * a.rec_len;
-    if (i >= a.batch) return;
+    gather_record(a, (blockIdx.x - a.n_frame_blocks) * 256 + tid);
+  }
+}
+
+// RGB frames (C == 3, W*3 a multiple of 16 and >= 32): no LDS.  Each output 16-byte vector is ONE unaligned 16-byte
+// global load at byte offset q*16 + 3*sx of the (clamped) source row -- gfx950 global loads take any byte address --
+// so a workgroup is a pure stream of independent load -> store pairs (4 vectors per thread, all loads in flight
+// before the first store), with no barrier between a staging and a shifting phase.  Only the first / last vector of
+// a row can reach past the row when sx != 0: its load is clamped into the row and the result is shifted by n = 3|sx|
+// bytes with the border pixel replicated into the vacated bytes (n is a multiple of 3, so the replicated pattern's
+// phase does not depend on n).  The arithmetic is uniform: no divergent edge path.
+struct __attribute__((packed, aligned(1))) U128Unaligned { unsigned __int128 v; };
+constexpr int kDirectVec = 4;  // vectors per thread
+
+__global__ __launch_bounds__(256) void gather_crop_rgb_kernel(GatherArgs a) {
+  const int tid = threadIdx.x;
+  const int rowb = a.W * 3;
+  const int vec_per_row = rowb >> 4;
+  const int nvec = a.H * vec_per_row;
+  if ((int)blockIdx.x < a.n_frame_blocks) {
+    const int parts = (nvec + 256 * kDirectVec - 1) / (256 * kDirectVec);
+    int bid = blockIdx.x;
+    const int part = bid % parts;
+    bid /= parts;
+    const int i = bid % a.batch;
+    bid /= a.batch;
+    const int cam = bid % a.n_cam;
+    const int which = bid / a.n_cam;
     const int buf = (i < a.count0) ? 0 : 1;
-    const int64_t slot = a.idx[buf][buf == 0 ? i : i - a.count0];
-    const float v = a.rec[buf][(size_t)slot * a.rec_len + f];
-    const int S = a.S, A = a.A;
-    if (f < S) a.out_state[(size_t)i * S + f] = v;
-    else if (f < 2 * S) a.out_state[((size_t)a.batch + i) * S + (f - S)] = v;
-    else if (f < 2 * S + A) a.out_action[(size_t)i * A + (f - 2 * S)] = v;
-    else if (f == 2 * S + A) a.out_reward[i] = v;
-    else if (f == 2 * S + A + 1) a.out_mask[i] = v;
-    else a.out_done[i] = (uint8_t)(v != 0.0f);
+    const size_t fbytes = (size_t)a.H * rowb;
+    const uint8_t* src;
+    if (a.from_packed) {
+      src = a.packed[cam] + ((size_t)i * 2 + which) * fbytes;
+    } else {
+      int64_t start = a.idx[buf][buf == 0 ? i : i - a.count0] - 1;
+      if (start < 0) start += a.cap[buf] - 1;  // numpy negative window index (reference quirk, see gather_crop_kernel)
+      src = a.frames[buf][cam] + (size_t)(start + which) * fbytes;
+    }
+    const int32_t* crop = which == 0 ? a.crop_obs : a.crop_next;
+    const int dy = crop ? crop[2 * i] : 4, dx = crop ? crop[2 * i + 1] : 4;
+    const int sy = dy - 4, sx3 = (dx - 4) * 3;
+    uint8_t* dst = a.out_frames + (((size_t)which * a.n_cam + cam) * a.batch + i) * fbytes;
+    unsigned __int128 val[kDirectVec];
+    int shl[kDirectVec], shr[kDirectVec];
+#pragma unroll
+    for (int j = 0; j < kDirectVec; ++j) {
+      const int v = min((part * kDirectVec + j) * 256 + tid, nvec - 1);
+      const int r = v / vec_per_row, q = v - r * vec_per_row;
+      const int sh = min(max(r + sy, 0), a.H - 1);
+      const int b0 = q * 16 + sx3;
+      const int bc = min(max(b0, 0), rowb - 16);
+      shl[j] = (bc - b0) * 8;   // > 0: left border, vector starts before the row
+      shr[j] = (b0 - bc) * 8;   // > 0: right border
+      val[j] = reinterpret_cast<const U128Unaligned*>(src + (size_t)sh * rowb + bc)->v;
+    }
+#pragma unroll
+    for (int j = 0; j < kDirectVec; ++j) {
+      const int v = (part * kDirectVec + j) * 256 + tid;
+      unsigned __int128 x = val[j];
+      const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 96);
+      if (shl[j] > 0) {
+        // bytes p0 p1 p2 of the first pixel; pattern byte k = p[k % 3]
+        const uint32_t d0 = __builtin_amdgcn_perm(0, lo, 0x00020100u);  // p0 p1 p2 p0
+        const uint32_t d1 = __builtin_amdgcn_perm(0, lo, 0x01000201u);  // p1 p2 p0 p1
+        const uint32_t d2 = __builtin_amdgcn_perm(0, lo, 0x02010002u);  // p2 p0 p1 p2
+        const unsigned __int128 pat = (unsigned __int128)d0 | ((unsigned __int128)d1 << 32) | ((unsigned __int128)d2 << 64) |
+                                      ((unsigned __int128)d0 << 96);
+        const unsigned __int128 keep = (~(unsigned __int128)0) << shl[j];
+        x = (x << shl[j]) | (pat & ~keep);
+      } else if (shr[j] > 0) {
+        // bytes l0 l1 l2 of the last pixel = bytes 13..15 of the vector; pattern byte k = l[(k + 2) % 3]
+        const uint32_t d0 = __builtin_amdgcn_perm(0, hi, 0x03020103u);  // l2 l0 l1 l2   (hi bytes: 1,2,3 = l0,l1,l2)
+        const uint32_t d1 = __builtin_amdgcn_perm(0, hi, 0x01030201u);  // l0 l1 l2 l0
+        const uint32_t d2 = __builtin_amdgcn_perm(0, hi, 0x02010302u);  // l1 l2 l0 l1
+        const unsigned __int128 pat = (unsigned __int128)d0 | ((unsigned __int128)d1 << 32) | ((unsigned __int128)d2 << 64) |
+                                      ((unsigned __int128)d0 << 96);
+        const unsigned __int128 keep = (~(unsigned __int128)0) >> shr[j];
+        x = (x >> shr[j]) | (pat & ~keep);
+      }
+      if (v < nvec) {
+        uint4 o;
+        o.x = (uint32_t)x; o.y = (uint32_t)(x >> 32); o.z = (uint32_t)(x >> 64); o.w = (uint32_t)(x >> 96);
+        *reinterpret_cast<uint4*>(dst + (size_t)v * 16) = o;
+      }
+    }
+  } else if (!a.from_packed) {
+    gather_record(a, (blockIdx.x - a.n_frame_blocks) * 256 + tid);
   }
 }
 
@@ -653,11 +742,19 @@ int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
 }
 
 static int launch_gather_crop(GatherArgs& a, hipStream_t stream) {
+  const int rec_blocks = a.from_packed ? 0 : cdiv((long)a.batch * a.rec_len, 256);
+  ProfScope prof("gather_crop", stream);
+  static const bool lds_path = [] { const char* e = getenv("SERL_GATHER_LDS"); return e && atoi(e) != 0; }();
+  if (a.C == 3 && (a.W * 3) % 16 == 0 && a.W * 3 >= 32 && !lds_path) {
+    const int nvec = a.H * (a.W * 3 / 16);
+    a.n_frame_blocks = 2 * a.n_cam * a.batch * cdiv(nvec, 256 * kDirectVec);
+    hipLaunchKernelGGL(gather_crop_rgb_kernel, dim3(a.n_frame_blocks + rec_blocks), dim3(256), 0, stream, a);
+    SERL_HIP(hipGetLastError());
+    return SERL_OK;
+  }
   const int chunks = cdiv(a.H, kRowsPerBlock);
   a.n_frame_blocks = 2 * a.n_cam * a.batch * chunks;
-  const int rec_blocks = a.from_packed ? 0 : cdiv((long)a.batch * a.rec_len, 256);
   const size_t lds = (size_t)kRowsPerBlock * ((size_t)a.W * a.C + 16);
-  ProfScope prof("gather_crop", stream);
   if (a.C == 3) hipLaunchKernelGGL(gather_crop_kernel<3>, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(gather_crop_kernel<0>, dim3(a.n_frame_blocks + rec_blocks), dim3(256), lds, stream, a);
   SERL_HIP(hipGetLastError());

@@ -549,9 +549,9 @@ size_t trunk_packed_bytes() {
       if (k == 2 && i == 0) continue;
       int K, Cout;
       conv_dims(i, k, K, Cout);
-      off += 2 * al256((size_t)K * Cout * 2);
+      off += 2 * al256((size_t)K * Cout * 2) + al256((size_t)Cout * 4);
     }
-  off += 2 * al256((size_t)64 * 224 * 2);   // conv_init planes (u8 variant: [64][224]; the 3-product variant uses [64][176] of it)
+  off += 2 * al256((size_t)64 * 224 * 2) + al256(64 * 4);   // conv_init planes (u8 variant: [64][224]; the 3-product variant uses [64][176] of it)
   off += 256;                                // zero page (the agent arena is zero-initialised and nothing writes here)
   return off;
 }
@@ -567,9 +567,11 @@ int trunk_packed_bind(TrunkPacked& p, void* mem) {
       conv_dims(i, k, K, Cout);
       p.blk[i][k].hi = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
       p.blk[i][k].lo = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
+      p.blk[i][k].inv = (float*)(b + off); off += al256((size_t)Cout * 4);
     }
   p.init.hi = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
   p.init.lo = (uint16_t*)(b + off); off += al256((size_t)64 * 224 * 2);
+  p.init.inv = (float*)(b + off); off += al256(64 * 4);
   p.zero = b + off; off += 256;
   p.dirty = true;
   return SERL_OK;
@@ -582,11 +584,11 @@ static int trunk_pack(const TrunkWeights& w, TrunkPacked& p, hipStream_t stream)
       if (!src) continue;
       int K, Cout;
       conv_dims(i, k, K, Cout);
-      int rc = pack_conv_weights_f16x3(src, p.blk[i][k].hi, p.blk[i][k].lo, K, Cout, stream);
+      int rc = pack_conv_weights_f16x3(src, p.blk[i][k].hi, p.blk[i][k].lo, p.blk[i][k].inv, K, Cout, stream);
       if (rc) return rc;
     }
   {
-    int rc = pack_conv_init_f16x3(w.conv_init, p.init.hi, p.init.lo, stream);
+    int rc = pack_conv_init_f16x3(w.conv_init, p.init.hi, p.init.lo, p.init.inv, stream);
     if (rc) return rc;
   }
   p.dirty = false;

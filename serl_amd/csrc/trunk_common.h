@@ -71,18 +71,22 @@ struct ConvArgs {
   int M, P, tiles_m, tiles_n;
 };
 
+// Every output channel n carries its own power-of-two scale s_n (max_k |w[k][n]| * s_n in [128, 256)): the fp16 planes
+// hold w * s_n, so neither a strong filter can overflow fp16 nor a weak one sink into its subnormals, and the conv
+// epilogue multiplies the fp32 accumulator by inv[n] = 1 / s_n (exact).
 struct PackedConvWeights {
-  const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous)
-  const uint16_t* lo;  // fp16 [Cout][K]  (w - float(hi)) * 2^11
+  const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous) of w * s_n
+  const uint16_t* lo;  // fp16 [Cout][K]  (w * s_n - float(hi)) * 2^11
+  const float* inv;    // [Cout] 1 / s_n
 };
-// w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K]
-int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream);
+// w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K], inv [Cout]
+int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream);
 // whole trunk in split-fp16 arithmetic (trunk_f16x3.hip)
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
                         float* feats_out, hipStream_t stream);
 
 // conv_init in split-fp16 (weights re-indexed and padded to [64][176])
-int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream);
+int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream);
 // pool_gamma != nullptr: fused 3x3/2 max-pool (trunk_f16x3.hip); `out` then receives the three compact outputs
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
                            int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr);

