@@ -1514,7 +1514,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
                        (long)N * Hi * Wi * Cin < (1L << 31);
     // SERL_CONV_DMA: 0 = register-staged kernels only, 2 / 3 = LDS-DMA kernel with that many LDS stages (default 2)
     static const int dma = []() { const char* e = getenv("SERL_CONV_DMA"); return e ? atoi(e) : 2; }();
-    const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4) && Cin % 32 == 0 && zero_page != nullptr &&
+    static const bool dma_c64 = []() { const char* e = getenv("SERL_CONV_DMA_C64"); return e && atoi(e) != 0; }();
+    const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4 || (cfg == 1 && dma_c64)) && Cin % 32 == 0 && zero_page != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
     if (rp_ok) {
       hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),

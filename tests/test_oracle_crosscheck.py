@@ -1,5 +1,6 @@
 """CPU: the update oracle (oracle/drq_oracle.py) restates flax / optax / distrax arithmetic by hand because none of
-those packages is installable here (its parity against the reference stays UNPINNED).  These tests cross-check
+those packages is installable here (the reference's own code pins it through tests/test_reference_update.py, the
+library primitives underneath are restatements).  These tests cross-check
 every restated library primitive against PyTorch's own, independently written implementation of the same
 published algorithm -- not a substitute for reference outputs, but it rules out transcription slips in the
 formulas the HIP kernels are then held to."""
