@@ -26,6 +26,7 @@ struct TrunkDims {
 };
 TrunkDims trunk_dims(int H, int W);
 
+constexpr int kSyncPerImage = 8, kSyncTickets = 16;
 struct TrunkWorkspace {
   int max_images = 0;
   TrunkDims d{};
@@ -35,6 +36,8 @@ struct TrunkWorkspace {
     float *raw0, *raw1, *rawp, *out, *norm0;
   } blk[kTrunkStages]{};
   double* stats = nullptr;  // 13 GN layers x [N][4][2]
+  int* sync = nullptr;      // directly behind `stats` (one memset): 13 layers x (kSyncPerImage arrival counters per image + kSyncTickets ints)
+  size_t stats_sync_bytes = 0;
   void* base = nullptr;     // single allocation backing everything above
   size_t bytes = 0;
 };

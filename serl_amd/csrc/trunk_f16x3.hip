@@ -28,8 +28,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
 
+// GroupNorm (+ residual) + ReLU + split8 re-layout in the PRODUCING conv's epilogue (mode != 0) instead of a separate
+// elementwise pass over the raw fp32 tensor.  GroupNorm needs the statistics of the whole image, which 2..8 workgroups
+// produce: each adds its partial sums (fp64 atomics, as before), then bumps an arrival counter of the image and waits
+// until all of the image's workgroups have arrived.  Tiles are handed out by an atomic TICKET taken when a workgroup
+// starts running, so every ticket below the newest one belongs to a workgroup that is resident (or done): a waiting
+// workgroup only ever waits for workgroups that are already running, whatever order the hardware dispatches blocks in.
+struct FuseArgs {
+  int mode;                 // 0 off; 1 relu(GN(y)); 2 relu(GN(y) + res_split); 3 relu(GN(y) + GN_res(res_raw))
+  int expected;             // arrivals per counter
+  int* sync;                // [image][tiles_n] arrival counters, zeroed with the statistics
+  int* ticket;              // zeroed with the statistics
+  GnRef gn;                 // this conv's statistics (being produced), scale, bias
+  GnRef res_gn;             // mode 3: the projection's GroupNorm (complete: that conv ran before)
+  const uint8_t* res_split; // mode 2: the block input (split8)
+  const float* res_raw;     // mode 3: raw projection output
+  uint8_t* out_split;       // split8 output
+};
+
 struct ConvArgsB {
   ConvArgs c;           // .w unused
+  FuseArgs fz;
   const uint16_t* whi;  // [Cout][K]
   const uint16_t* wlo;
   const float* winv;    // [Cout] 1 / (per-output-channel weight scale)
@@ -60,6 +79,137 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 
 // byte offset of 16-byte slot `slot` (0..3) of row `row` in a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ int fused_ticket(const FuseArgs& fz) {
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return s_ticket;
+}
+
+// Ordering without cache maintenance: the statistics and the counter are only ever touched by device-scope atomics
+// (performed at the memory side, past the per-XCD L2s), so no L2 write-back / invalidate is needed -- an agent-scope
+// acquire in the polling loop would invalidate the XCD's whole L2 on every poll (measured: convs 4x slower).  A wave's
+// no-return atomics are complete when its vmcnt reaches 0 (workgroup-scope release fence = s_waitcnt only); the
+// barrier then orders every wave's statistics before thread 0's arrival; pollers read the statistics with atomic loads.
+__device__ __forceinline__ void fused_arrive_and_wait(int* ctr, int expected) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the bound turns a protocol error into a kernel abort instead of a hung GPU; a real wait is a few microseconds)
+    for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected; ++spins) {
+      __builtin_amdgcn_s_sleep(4);
+      if (spins > (1 << 22)) __builtin_trap();
+    }
+  }
+  __syncthreads();
+}
+
+// gn_coef4 for one channel; LIVE: the statistics were written by other workgroups of this launch (read at L2)
+template <bool LIVE>
+__device__ __forceinline__ void gn_coef1(const GnRef& g, int n, int c, float& sc, float& sh) {
+  const double* st = g.stats + ((size_t)n * kGnGroups + c / g.gsize) * 2;
+  const double s0 = LIVE ? __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st[0];
+  const double s1 = LIVE ? __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st[1];
+  const double mean = s0 * g.inv_count, m2 = s1 * g.inv_count;
+  const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+  const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
+  sc = g.gamma[c] * rstd;
+  sh = g.beta[c] - mf * sc;
+}
+
+__device__ __forceinline__ uint32_t swap_adjacent_lanes(uint32_t v) {   // quad_perm [1, 0, 3, 2]
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t b) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)(b & 0xffffu));
+}
+
+// The MFMA C layout gives a lane ONE channel (col0 + 32 tn + li) of 16 rows per 32x32 tile; the split8 layout wants
+// the 8 hi halves of 8 consecutive channels in one 16-byte unit and their lo' halves in the next.  Adjacent lanes
+// (channels c, c+1) trade halves: the even lane ends up with the dword of the two hi halves, the odd lane with the dword
+// of the two lo' halves, so 32 lanes write the same contiguous 128 bytes a row of 32 fp32 values took.  Two rows are
+// processed together (packed fp32 math, one cvt_pkrtz / cvt_pk per pair, ONE lane exchange per pair): the epilogue's
+// VALU work competes with the other workgroup's MFMAs on the same SIMD, so instruction count matters here.
+template <int TM, int TN>
+struct FusedResidual { uint32_t v[TM][TN][16]; };
+
+// residual operand of this lane's elements, loaded BEFORE the statistics wait so the latency hides behind it
+template <int TM, int TN>
+__device__ __forceinline__ void fused_load_residual(const ConvArgsB& ab, FusedResidual<TM, TN>& res, int wrow0, int col0,
+                                                    int li, int lh) {
+  const FuseArgs& fz = ab.fz;
+  if (fz.mode < 2) return;
+  const int Cout = ab.c.Cout;
+  const bool odd = li & 1;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const size_t rowb = (size_t)m * Cout * 4;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int c = col0 + tn * 32 + li;
+        if (fz.mode == 2) res.v[tm][tn][r] = *reinterpret_cast<const uint32_t*>(fz.res_split + rowb + (c & ~7) * 4 + (odd ? 16 : 0) + (c & 6) * 2);
+        else res.v[tm][tn][r] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(fz.res_raw) + rowb + c * 4);
+      }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16 (&acc)[TM][TN],
+                                               const FusedResidual<TM, TN>& res, int n_img, int wrow0, int col0, int li, int lh) {
+  const FuseArgs& fz = ab.fz;
+  const int Cout = ab.c.Cout;
+  const bool odd = li & 1;
+  // v_perm selectors (byte k of the result: 0..3 = bytes of the 2nd operand, 4..7 = bytes of the 1st)
+  const uint32_t sel_r0 = odd ? 0x01000504u : 0x05040100u;   // (keep, recv) low halves  -> even: keep|recv<<16, odd: recv|keep<<16
+  const uint32_t sel_r1 = odd ? 0x03020706u : 0x07060302u;   // same for the high halves
+  const uint32_t sel_lo = 0x05040100u, sel_hi = 0x07060302u; // (a.lo16 | b.lo16 << 16), (a.hi16 | b.hi16 << 16) of perm(b, a, .)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int c = col0 + tn * 32 + li;
+    float sc, sh, rs = 0.f, rh = 0.f;
+    gn_coef1<true>(fz.gn, n_img, c, sc, sh);
+    if (fz.mode == 3) gn_coef1<false>(fz.res_gn, n_img, c, rs, rh);
+    const int cbyte = (c & ~7) * 4 + (odd ? 16 : 0) + (c & 6) * 2;
+    const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh}, rs2 = {rs, rs}, rh2 = {rh, rh};
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int rp = 0; rp < 8; ++rp) {
+        const int r0 = 2 * rp, r1 = r0 + 1;   // rows m and m + 1
+        const int m = wrow0 + tm * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lh;
+        f32x2 v = (f32x2){acc[tm][tn][r0], acc[tm][tn][r1]} * sc2 + sh2;
+        if (fz.mode == 2) {
+          const uint32_t o0 = res.v[tm][tn][r0], o1 = res.v[tm][tn][r1];
+          // what the neighbour needs from me (even: my hi16 = hi[c+1]; odd: my lo16 = lo[c-1]) and what I keep
+          const uint32_t send = __builtin_amdgcn_perm(o1, o0, odd ? sel_lo : sel_hi);
+          const uint32_t mine = __builtin_amdgcn_perm(o1, o0, odd ? sel_hi : sel_lo);
+          const uint32_t recv = swap_adjacent_lanes(send);
+          const uint32_t H = odd ? recv : mine, L = odd ? mine : recv;   // (x_hi row0 | x_hi row1 << 16), same for lo'
+          const f16x2 Hh = __builtin_bit_cast(f16x2, H), Lh = __builtin_bit_cast(f16x2, L);
+          const f32x2 xh = {(float)Hh[0], (float)Hh[1]}, xl = {(float)Lh[0], (float)Lh[1]};
+          v = (xh + xl * (f32x2){kLoInv, kLoInv}) + v;
+        } else if (fz.mode == 3) {
+          const f32x2 x = {__builtin_bit_cast(float, res.v[tm][tn][r0]), __builtin_bit_cast(float, res.v[tm][tn][r1])};
+          v = (x * rs2 + rh2) + v;
+        }
+        v = (f32x2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+        const h16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+        const f32x2 hf = {(float)hp[0], (float)hp[1]};
+        const f16x2 lp = __builtin_convertvector((v - hf) * (f32x2){kLoScale, kLoScale}, f16x2);
+        const uint32_t hpb = __builtin_bit_cast(uint32_t, hp), lpb = __builtin_bit_cast(uint32_t, lp);
+        const uint32_t keep = odd ? lpb : hpb;
+        const uint32_t recv = swap_adjacent_lanes(odd ? hpb : lpb);
+        uint8_t* o = fz.out_split + (size_t)m * Cout * 4 + cbyte;
+        *reinterpret_cast<uint32_t*>(o) = __builtin_amdgcn_perm(recv, keep, sel_r0);
+        *reinterpret_cast<uint32_t*>(o + (size_t)Cout * 4) = __builtin_amdgcn_perm(recv, keep, sel_r1);
+      }
+  }
+}
 
 // A operand = activations already in "split16" layout (written by the elementwise producers below):
 // per 4 channels one 16-byte record {hi x4 fp16 | lo' x4 fp16}, i.e. the same footprint and addressing
@@ -307,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int ntaps = a.KH * a.KW;
@@ -457,17 +607,21 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+  FusedResidual<TM, TN> fres;
+  if (PMODE == 0 && ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0 + wn * WCOLS, li, lh);
+  if (!ab.fz.mode) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < a.M) {
-        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+      for (int r = 0; r < 16; ++r) {
+        const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.M) {
+          float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+          for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+        }
       }
-    }
+  }
   if (PMODE != 3) {
     const int gsize = a.Cout / kGnGroups;
     constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
@@ -496,6 +650,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
       }
     }
   }
+  if (PMODE == 0 && ab.fz.mode) {   // the launcher guarantees P % BM == 0: the whole tile lies in one image
+    const int n_img = m0 / a.P;
+    fused_arrive_and_wait(ab.fz.sync + n_img * a.tiles_n + bn, ab.fz.expected);
+    fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0 + wn * WCOLS, li, lh);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -517,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
   constexpr int AI = (MAXPIX * 4 + 255) / 256;   // 16-byte activation records per thread per chunk
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
   const int m0 = id * BM, n0 = 0;
   const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
   const int pw = a.Wo + 2, npix = (BM / a.Wo) * pw;
@@ -633,15 +792,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+  FusedResidual<TM, TN> fres;
+  if (ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0, li, lh);
+  if (!ab.fz.mode) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float* o = a.out + (size_t)m * a.Cout + n0 + li;
+      for (int r = 0; r < 16; ++r) {
+        const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = a.out + (size_t)m * a.Cout + n0 + li;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
-    }
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+      }
+  }
   {
     const int gsize = a.Cout / kGnGroups;
     double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
@@ -658,6 +821,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
         }
       stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
     }
+  }
+  if (ab.fz.mode) {
+    fused_arrive_and_wait(ab.fz.sync + n_img, ab.fz.expected);
+    fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0, li, lh);
   }
 }
 
@@ -1473,7 +1640,9 @@ __global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, 
 
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                             hipStream_t stream, const uint8_t* zero_page = nullptr) {
+                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr) {
+  // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
+  // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgsB ab{};
   ConvArgs& a = ab.c;
@@ -1517,7 +1686,11 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     static const bool dma_c64 = []() { const char* e = getenv("SERL_CONV_DMA_C64"); return e && atoi(e) != 0; }();
     const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4 || (cfg == 1 && dma_c64)) && Cin % 32 == 0 && zero_page != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
+    bool fused = false;
     if (rp_ok) {
+      if (fuse && fuse->mode && a.P % 256 == 0) {
+        ab.fz = *fuse; ab.fz.expected = a.P / 256; fused = true;
+      }
       hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),
                          stream, ab);
     } else if (dma_ok) {
@@ -1528,6 +1701,9 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       const int nst = dma >= 3 ? 3 : 2;
       const size_t l = (size_t)nst * (128 * 128 + 2 * bn * 64);
       if (pmode == 1 && cfg == 4) pmode = 3;
+      if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage) {
+        ab.fz = *fuse; ab.fz.expected = a.P / 128; fused = true;
+      }
 #define SERL_LAUNCH_DMA(TN_, NS_)                                                                                        \
   do {                                                                                                                   \
     if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 0>), g, block, l, stream, ab, zero_page);        \
@@ -1562,6 +1738,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
 #undef SERL_LAUNCH_DEEP
     }
 #undef SERL_LAUNCH_CONV
+    if (fuse && !fused) fuse->mode = 0;
   }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {
@@ -1584,9 +1761,16 @@ static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
                         float* feats_out, hipStream_t stream) {
   const TrunkDims& d = ws.d;
-  constexpr int kLayers = 1 + 3 * kTrunkStages;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
-  SERL_HIP(hipMemsetAsync(ws.stats, 0, (size_t)kLayers * ws.max_images * kGnGroups * 2 * sizeof(double), stream));
+  SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
+  auto fuse_of = [&](int layer, int mode) {
+    FuseArgs f{};
+    static const bool on = []() { const char* e = getenv("SERL_GN_FUSE"); return !(e && e[0] == '0'); }();
+    f.mode = on ? mode : 0;
+    f.sync = ws.sync + (size_t)layer * ((size_t)ws.max_images * kSyncPerImage + kSyncTickets);
+    f.ticket = f.sync + (size_t)ws.max_images * kSyncPerImage;
+    return f;
+  };
   int rc;
   static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
   const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
@@ -1624,19 +1808,33 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
     auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv}; };
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero))) return rc;
+    // GroupNorm + ReLU (+ residual) + split8 in the conv epilogue where the kernel for this shape supports it
+    // (fz.mode comes back 0 otherwise and the elementwise pass below runs instead)
+    FuseArgs fz0 = fuse_of(l0, 1);
+    fz0.gn = gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f);
+    fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0))) return rc;
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
     const long tot = (long)N * P * (f / 4);
-    {
+    if (!fz0.mode) {
       ProfScope prof("gn_relu_split", stream);
       hipLaunchKernelGGL(gn_relu_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw0,
                          gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), reinterpret_cast<uint4*>(ws.blk[i].norm0), N, P, f);
       SERL_HIP(hipGetLastError());
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero))) return rc;
     const bool last = i == kTrunkStages - 1;
-    {
+    FuseArgs fz1 = fuse_of(l1, last ? 0 : (has_proj ? 3 : 2));
+    fz1.gn = gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f);
+    fz1.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].out);
+    if (has_proj) {
+      fz1.res_raw = ws.blk[i].rawp;
+      fz1.res_gn = gn_ref_b(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f);
+    } else {
+      fz1.res_split = reinterpret_cast<const uint8_t*>(x);
+    }
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1))) return rc;
+    if (!fz1.mode) {
       ProfScope prof("block_out", stream);
       hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,
                          gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f),
