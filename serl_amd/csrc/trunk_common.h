@@ -29,8 +29,17 @@ __device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /
   const int lane = threadIdx.x & 63;
   if (valid && (lane & 15) == 0 && lane < 32) {
     const int g = chan / gsize;
-    atomicAdd(&stats_ng[2 * g], (double)s);
-    atomicAdd(&stats_ng[2 * g + 1], (double)q);
+    // SYSTEM scope (sc1): performed at the memory side, past the per-XCD L2s -- the fused GroupNorm epilogues read
+    // these sums from workgroups on other XCDs while the kernel is still running.  RETURNING atomics: the old value
+    // coming back is the only proof that the read-modify-write has been performed (a no-return atomic leaves vmcnt
+    // when the L2 has accepted it), and the epilogue's arrival counter must not overtake the sums.
+    const double o0 = __hip_atomic_fetch_add(&stats_ng[2 * g], (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double o1 = __hip_atomic_fetch_add(&stats_ng[2 * g + 1], (double)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifndef SERL_STATS_NORETURN   // (development switch: the racy no-return variant, to prove the stress test catches it)
+    asm volatile("" ::"v"(o0), "v"(o1));
+#else
+    (void)o0; (void)o1;
+#endif
   }
 }
 
@@ -89,6 +98,6 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream);
 // pool_gamma != nullptr: fused 3x3/2 max-pool (trunk_f16x3.hip); `out` then receives the three compact outputs
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr);
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr, int* ticket = nullptr);
 
 }  // namespace serl

@@ -82,23 +82,25 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot
 
 __device__ __forceinline__ int fused_ticket(const FuseArgs& fz) {
   __shared__ int s_ticket;
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   return s_ticket;
 }
 
-// Ordering without cache maintenance: the statistics and the counter are only ever touched by device-scope atomics
-// (performed at the memory side, past the per-XCD L2s), so no L2 write-back / invalidate is needed -- an agent-scope
-// acquire in the polling loop would invalidate the XCD's whole L2 on every poll (measured: convs 4x slower).  A wave's
-// no-return atomics are complete when its vmcnt reaches 0 (workgroup-scope release fence = s_waitcnt only); the
-// barrier then orders every wave's statistics before thread 0's arrival; pollers read the statistics with atomic loads.
+// Ordering without cache maintenance: the statistics, the counter and the ticket are only ever touched by SYSTEM-scope
+// atomics (sc1: performed at the memory side, past the 8 per-XCD L2s -- an image's workgroups can sit on different XCDs,
+// and agent-scope atomics performed in one XCD's L2 reached the others late: 1e-4 errors at 1024 images), so no L2
+// write-back / invalidate is needed (an agent-scope acquire in the polling loop invalidates the XCD's whole L2 on every
+// poll: measured 4x slower convs).  A wave's no-return atomics are complete when its vmcnt reaches 0 (workgroup-scope
+// release fence = s_waitcnt only), which is what the AMDGPU memory model itself relies on; the barrier then orders every
+// wave's statistics before thread 0's arrival; pollers read the statistics with atomic loads.
 __device__ __forceinline__ void fused_arrive_and_wait(int* ctr, int expected) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (the bound turns a protocol error into a kernel abort instead of a hung GPU; a real wait is a few microseconds)
-    for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected; ++spins) {
+    for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < expected; ++spins) {
       __builtin_amdgcn_s_sleep(4);
       if (spins > (1 << 22)) __builtin_trap();
     }
@@ -110,8 +112,8 @@ __device__ __forceinline__ void fused_arrive_and_wait(int* ctr, int expected) {
 template <bool LIVE>
 __device__ __forceinline__ void gn_coef1(const GnRef& g, int n, int c, float& sc, float& sh) {
   const double* st = g.stats + ((size_t)n * kGnGroups + c / g.gsize) * 2;
-  const double s0 = LIVE ? __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st[0];
-  const double s1 = LIVE ? __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st[1];
+  const double s0 = LIVE ? __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : st[0];
+  const double s1 = LIVE ? __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : st[1];
   const double mean = s0 * g.inv_count, m2 = s1 * g.inv_count;
   const float var = fmaxf((float)(m2 - mean * mean), 0.f);
   const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
@@ -849,6 +851,8 @@ struct ConvInitArgsB {
   float* first_rows;    // [N][tiles_y][Wo][64] raw conv outputs of rows 0 mod 16
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
   int dbg;              // timing experiments only (SERL_CI_DBG): 1 no stats atomics, 2 no pool epilogue, 4 no MFMA loop, 8 no patch fill
+  int chunk;            // conv_init_u8: tiles per scheduling chunk (divides tiles_y * tiles_x)
+  int* ticket;          // conv_init_u8: chunk ticket (zeroed per pass) or nullptr = static round-robin
 };
 
 constexpr int kCbKP = 176;       // padded K
@@ -1150,16 +1154,25 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       }                                                                                                 \
     }                                                                                                   \
   }
-  // every workgroup walks a CONTIGUOUS range of tiles (whole images where the counts divide): the GroupNorm partial
-  // sums stay in registers across the tiles of an image and are flushed once per image (the per-tile fp64 atomics of
-  // 16 workgroups on the same 8 words cost 40 us per pass), and neighbouring tiles share their halo in L2
-  const int per_wg = (a.total_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t_begin = (int)blockIdx.x * per_wg, t_end = min(t_begin + per_wg, a.total_tiles);
-  const int tiles_per_img = a.tiles_y * a.tiles_x;
+  // Tiles are handed out in CHUNKS of a.chunk consecutive tiles of one image (a.chunk divides tiles_per_img): the
+  // GroupNorm partial sums stay in registers across a chunk and are flushed once per chunk (per-tile fp64 atomics of 16
+  // workgroups on the same 8 words cost 40 us per pass), and neighbouring tiles share their halo in L2.  The first chunk
+  // of a workgroup is its block index, the following ones come from an atomic ticket: with a static partition a
+  // workgroup that cannot become resident at once (the update chain's kernels own some wave slots when the two streams
+  // overlap) starts its whole share late and the kernel takes up to twice as long (measured 259 us alone, 485 us
+  // co-running); with tickets a late workgroup simply takes fewer chunks.
+  __shared__ int s_next_chunk;
+  const int nchunks = a.total_tiles / a.chunk;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
   const float winv[2] = {a.winv[li], a.winv[32 + li]};
-  if (t_begin < t_end) SERL_C8_FETCH(t_begin);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  int chunk = blockIdx.x, next_chunk = 0;
+  int tile = chunk * a.chunk, t_end = tile + a.chunk;
+  if (chunk < nchunks) SERL_C8_FETCH(tile);
+  while (chunk < nchunks) {
+    const bool first_of_chunk = tile == chunk * a.chunk;
+    if (first_of_chunk && tid == 0)
+      s_next_chunk = (int)gridDim.x + (a.ticket ? __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : chunk / (int)gridDim.x * (int)gridDim.x + (int)blockIdx.x);
     int b = tile;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
@@ -1191,7 +1204,9 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       }
     }
     __syncthreads();
-    SERL_C8_FETCH(min(tile + 1, a.total_tiles - 1));  // next tile's bytes, in flight under the MFMAs
+    if (first_of_chunk) next_chunk = s_next_chunk;   // written before this tile's first barrier
+    // next tile's bytes (the first tile of the next chunk after the last one of this chunk), in flight under the MFMAs
+    SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
     int abase[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -1327,12 +1342,15 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
         }
       }
     }
-    if (tile + 1 == t_end || (tile + 1) / tiles_per_img != n) {   // last tile of this image in this workgroup's range
+    if (++tile == t_end) {   // last tile of the chunk (a chunk lies in one image)
       double* st = a.stats + (size_t)n * kGnGroups * 2;
       if (!(a.dbg & 1))
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
       s[0] = s[1] = q[0] = q[1] = 0.f;
+      chunk = next_chunk;
+      tile = chunk * a.chunk;
+      t_end = tile + a.chunk;
     }
   }
 #undef SERL_C8_FETCH
@@ -1404,7 +1422,7 @@ int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv,
 }
 
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma) {
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma, int* ticket) {
   ConvInitArgsB a{};
   a.img = img; a.whi = w.hi; a.wlo = w.lo; a.winv = w.inv; a.out = out; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
@@ -1412,7 +1430,14 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   static const int dbg = []() { const char* e = getenv("SERL_CI_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
-  const int grid = std::min(a.total_tiles, 512);  // 2 persistent workgroups per CU
+  const int tpi = a.tiles_y * a.tiles_x;
+  static const int chunk_env = []() { const char* e = getenv("SERL_CI_CHUNK"); return e ? atoi(e) : 0; }();
+  a.chunk = tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1);
+  if (chunk_env > 0 && tpi % chunk_env == 0) a.chunk = chunk_env;
+  static const bool static_sched = []() { const char* e = getenv("SERL_CI_STATIC"); return e && atoi(e) != 0; }();
+  a.ticket = static_sched ? nullptr : ticket;
+  // 2 persistent workgroups per CU
+  const int grid = kConvInitU8 ? std::min(a.total_tiles / a.chunk, 512) : std::min(a.total_tiles, 512);
   ProfScope prof("conv_init", stream);
   if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
     SERL_REQUIRE(Ho % 16 == 0 && Wo % 16 == 0, "fused conv_init pooling needs full 16x16 tiles");
@@ -1765,8 +1790,8 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
   auto fuse_of = [&](int layer, int mode) {
     FuseArgs f{};
-    static const bool on = []() { const char* e = getenv("SERL_GN_FUSE"); return !(e && e[0] == '0'); }();
-    f.mode = on ? mode : 0;
+    const char* e = getenv("SERL_GN_FUSE");   // read per pass: tests flip it inside one process
+    f.mode = (e && e[0] == '0') ? 0 : mode;
     f.sync = ws.sync + (size_t)layer * ((size_t)ws.max_images * kSyncPerImage + kSyncTickets);
     f.ticket = f.sync + (size_t)ws.max_images * kSyncPerImage;
     return f;
@@ -1775,7 +1800,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
   const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
   if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
-                                   d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr))) return rc;
+                                   d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket))) return rc;
   if (fuse_pool) {
     const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
     const int ty = d.h[0] / 16, tx = d.w[0] / 16;

@@ -514,3 +514,25 @@ def test_trunk_with_negative_and_zero_groupnorm_scales(gpu, mode):
     ref = O.trunk_forward(st.trunk, torch.tensor(img), torch.float64).numpy()
     got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
     assert (g < 0).sum() > 10 and AH.rel_err(got, ref) < (TOL if mode == "f16x3" else 2e-5)
+
+
+def test_fused_groupnorm_epilogue_is_race_free_at_full_batch(gpu, monkeypatch):
+    """Stages 0-1 apply GroupNorm (+ residual) + ReLU + the split8 re-layout in the producing conv's epilogue: the 2..4
+    workgroups of an image exchange statistics through atomics and an arrival counter while the kernel runs.  At the
+    benchmark's 1024 images per pass (4096 workgroups, tiles handed out by tickets in completion order) the features must
+    equal those of the separate elementwise passes (SERL_GN_FUSE=0) on every repetition -- a visibility race shows up as
+    a 1e-4 error in a few images, intermittently."""
+    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=512, trunk_mode="f16x3")
+    n = 1024
+    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda")
+    monkeypatch.setenv("SERL_GN_FUSE", "0")
+    ref = core.trunk_forward(img).clone()
+    scale = float(ref.abs().max())
+    monkeypatch.setenv("SERL_GN_FUSE", "1")
+    worst = 0.0
+    for it in range(40):
+        got = core.trunk_forward(img)
+        worst = max(worst, float((got - ref).abs().max()) / scale)
+    print(f"fused vs elementwise GroupNorm over 40 passes of {n} images: worst rel diff {worst:.2e}")
+    assert worst < 2e-6, worst

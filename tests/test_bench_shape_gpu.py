@@ -65,7 +65,9 @@ def test_update_critics_at_bench_shape(gpu, keys, A):
     assert AH.rel_err(core.debug("target_q", B), aux["target_q"].numpy()) < TOL
     # the [enc | action] critic input: 2 x 256 image codes (4x4 SLE -> Dense -> LN -> tanh) + 64 proprio + actions
     x = core.debug("x", B * (cfg.enc_dim + cfg.A)).reshape(B, -1)
-    assert AH.rel_err(x[:, :cfg.enc_dim], aux["enc_obs"].numpy()) < TOL
+    e_enc = AH.rel_err(x[:, :cfg.enc_dim], aux["enc_obs"].numpy())
+    print(f"encoder output {keys}: rel err vs fp64 = {e_enc:.2e}")
+    assert e_enc < TOL
     worst, worst_el = _grad_report(cfg, core, aux["grads"], "g_critic", 0)
     _assert_grads(worst, worst_el, f"critic grads {keys}")
     assert core.step == st.step == 1
