@@ -252,19 +252,31 @@ def main():
         except Exception:
             traffic = None
     n_launch = max(1, sum(c for t, (m, c) in prof.items() if t.startswith("conv_igemm")))
+    # executed-MFMA fraction per stage (b0: row-patch kernel, b1..b3: LDS-DMA kernel + 1x1 projection)
+    frac_by_stage = {}
+    for st in range(4):
+        fl = sum(2.0 * macs[t] * n_img * c for t, (m, c) in prof.items() if t.startswith(f"conv_igemm/b{st}_") and t in macs)
+        ms_ = sum(m for t, (m, c) in prof.items() if t.startswith(f"conv_igemm/b{st}_") and t in macs)
+        if ms_ > 0:
+            frac_by_stage[f"b{st}"] = round((3.0 if args.trunk == "f16x3" else 1.0) * fl / (ms_ * 1e-3) / 1e12 /
+                                            (PEAK_F16_MFMA if args.trunk == "f16x3" else PEAK_F32_MFMA), 4)
     if args.trunk == "f16x3":
         # every fp32 product is three fp16 MFMA products (hi*hi, hi*lo', lo'*hi): the matrix pipe executes
         # 3x the algorithmic FLOPs, and that executed rate is what the fp16-MFMA roofline bounds
         executed = 3.0 * achieved
         roofline = {"bound": "mfma",
-                    "kernel": "conv_igemm_f16x3_kernel + conv3x3_rowpatch_f16x3_kernel (split-fp16 MFMA implicit GEMM, fp32 accumulate; 11 launches per trunk pass)",
+                    "kernel": "block convs of the frozen trunk: conv_dma_f16x3_kernel (stages 1-3) + conv3x3_rowpatch_f16x3_kernel (stage 0) + "
+                              "conv_igemm_f16x3_kernel (1x1 projections); split-fp16 MFMA implicit GEMM, fp32 accumulate; 11 launches per trunk pass",
                     "achieved": round(executed, 3), "peak": PEAK_F16_MFMA, "unit": "TFLOP/s",
                     "frac": round(executed / PEAK_F16_MFMA, 4), "traffic": traffic,
                     "algorithmic_tflops": round(achieved, 3),
                     "algorithmic_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4),
                     "note": "achieved = 3 x algorithmic fp32 conv FLOP/s (executed fp16 MFMA work); "
                             "algorithmic_tflops = 2*M*K*N per launch / HIP-event duration; "
-                            f"HIP events around every {PROFILE_EVERY}th launch of each kernel inside the timed region",
+                            f"HIP events around every {PROFILE_EVERY}th launch of each kernel inside the timed region; the durations of "
+                            "the stage-0/1 convs INCLUDE the GroupNorm + residual + ReLU + split8 re-layout they apply in their epilogue "
+                            "(SERL_GN_FUSE=0 restores the separate elementwise passes: higher frac, slower step)",
+                    "frac_by_stage": frac_by_stage,
                     "flop_per_launch_avg": tot_flop / n_launch, "per_kernel": per_kernel}
     else:
         roofline = {"bound": "mfma",
@@ -273,7 +285,7 @@ def main():
                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
                     "flop_per_launch_avg": tot_flop / n_launch, "per_kernel": per_kernel}
     if "gather_crop" in per_kernel:
-        roofline["sample_aug_hbm"] = {"bound": "hbm", "kernel": "gather_crop_kernel", "achieved": per_kernel["gather_crop"]["TBps"],
+        roofline["sample_aug_hbm"] = {"bound": "hbm", "kernel": "gather_crop_rgb_kernel", "achieved": per_kernel["gather_crop"]["TBps"],
                                       "peak": PEAK_HBM, "unit": "TB/s", "frac": per_kernel["gather_crop"]["frac_hbm"]}
 
     out = {
