@@ -8,6 +8,13 @@ Per kernel family: the mean counter value per dispatch and two ratios --
       cycles in which a SIMD's matrix pipe is busy over cycles in which the shader engine's SQ has waves; both are summed over the
       units rocprofv3 aggregates, so the ratio -- not the absolute values -- is the figure of merit; the guide's note on
       SQ_BUSY_CYCLES per-SE accounting applies)
+  mfma_util_per_simd = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) (SQ_VALU_MFMA_BUSY_CYCLES counts 32 cycles per 32x32x16 MFMA
+      over all waves = busy cycles summed over the 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 8 XCDs x 4 shader engines, so
+      SQ_BUSY_CYCLES / 32 is the kernel's duration in shader cycles: checked against the kernel trace of the same pass.  The
+      ratio is the fraction of cycles a SIMD's matrix pipe is busy AT THE CLOCK THE PASS RAN AT (profiled passes run below the
+      2.4 GHz the 2.5 PF peak assumes, so it sits above the time-derived roofline.frac by that clock ratio)
+  mfma_busy_over_wave_cycles = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_WAVE_CYCLES)   (SQ_WAVE_CYCLES counts quad-cycles: share of a
+      wave's lifetime the matrix pipe works for it; x resident waves per SIMD = the utilisation above)
   lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE         (share of LDS cycles lost to bank conflicts)."""
 import collections, csv, glob, json, os, sys
 
@@ -44,11 +51,12 @@ for name, pats in FAMILIES:
             rec[c + "_per_dispatch"] = round(v / n, 1)
     if "SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch" in rec and rec.get("SQ_BUSY_CYCLES_per_dispatch"):
         rec["mfma_busy_over_sq_busy"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch"] / rec["SQ_BUSY_CYCLES_per_dispatch"], 4)
+        rec["mfma_util_per_simd"] = round(rec["mfma_busy_over_sq_busy"] / 32.0, 4)
     if "SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch" in rec and rec.get("SQ_WAVE_CYCLES_per_dispatch"):
-        rec["mfma_busy_over_wave_cycles"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch"] / rec["SQ_WAVE_CYCLES_per_dispatch"], 4)
+        rec["mfma_busy_over_wave_cycles"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES_per_dispatch"] / (4.0 * rec["SQ_WAVE_CYCLES_per_dispatch"]), 4)
     if "SQ_LDS_BANK_CONFLICT_per_dispatch" in rec and rec.get("SQ_LDS_IDX_ACTIVE_per_dispatch"):
         rec["lds_conflict_frac"] = round(rec["SQ_LDS_BANK_CONFLICT_per_dispatch"] / rec["SQ_LDS_IDX_ACTIVE_per_dispatch"], 4)
     if rec:
         out[name] = rec
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if "over" in kk or "frac" in kk} for k, v in out.items() if isinstance(v, dict)}))
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if "over" in kk or "frac" in kk or "util" in kk} for k, v in out.items() if isinstance(v, dict)}))

@@ -659,22 +659,82 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   }
 }
 
+// Epilogue of a 256 x 64 output tile held by 4 waves of 64 x 64 (all rows in image n_img): combine the two accumulators,
+// undo the weight scale, GroupNorm statistics, then either the raw fp32 store or the fused GroupNorm modes.
+__device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], int m0, int n0,
+                                                 int n_img, int wave, int li, int lh) {
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, TN = 2, WROWS = 64;
+  const int wrow0 = m0 + wave * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + tn * 32 + li];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+  FusedResidual<TM, TN> fres;
+  if (ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0, li, lh);
+  if (!ab.fz.mode) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = a.out + (size_t)m * a.Cout + n0 + li;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+      }
+  }
+  {
+    const int gsize = a.Cout / kGnGroups;
+    double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[tm][tn][r];
+          s += v;
+          q += v * v;
+        }
+      stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
+    }
+  }
+  if (ab.fz.mode) {
+    fused_arrive_and_wait(ab.fz.sync + n_img, ab.fz.expected);
+    fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0, li, lh);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-patch variant for the stride-1 3x3 convs with 64 output channels (stage 0: the largest M and the
 // smallest N, where the im2col loader's 9x re-read of every input pixel through L2 -> LDS is the bound).
 // A K chunk is (ky, 16 input channels): the workgroup stages the TR x (Wo+2) input pixels of that kernel
 // row ONCE and serves the three kx taps from LDS by shifting the pixel index, so the activation operand
 // crosses L2 -> LDS 3x instead of 9x.  256 x 64 output tile = TR = 256/Wo whole output rows of one image.
-// LDS pixel rows are 32 bytes per plane (16 fp16), so MFMA fragment reads (lane -> consecutive pixels)
-// are contiguous and conflict-free without a swizzle.  Epilogue identical to the generic kernel.
+// Epilogue identical to the generic kernel (plus the fused GroupNorm modes).
 // ---------------------------------------------------------------------------------------------
+constexpr int kRowpatchLds = 2 * (4 * (288 * 16 + 32) + 3 * 2 * 2 * (64 * 16 + 64));   // two stages, see the layout in the kernel
 __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
   constexpr int MAXPIX = 288;                    // 8 x 34 (Wo = 32) or 16 x 18 (Wo = 16)
-  constexpr int A_PLANE = MAXPIX * 32;           // one fp16 plane: [pixel][16 channels]
-  constexpr int B_PLANE = BN * 32, B_TAP = 2 * B_PLANE;  // per tap: [hi | lo'][cout][16 k]
-  constexpr int STAGE = 2 * A_PLANE + 3 * B_TAP;
+  // LDS image of a chunk: 16-byte units (8 fp16 = one MFMA k-half of one plane) laid out so that the 32 lanes of an
+  // MFMA fragment read (consecutive pixels / output channels, same plane and k-half) touch CONSECUTIVE units --
+  // ds_read_b128 serves 16-lane groups over a 256-byte bank row, and the former [pixel][32 B] rows put lanes l and l+8 of
+  // a group on the same banks (PMC: 45 % of this kernel's LDS cycles were bank conflicts).  Activations: 4 regions
+  // (plane, k-half) of [pixel][16 B]; weights per tap: 4 regions of [cout][16 B].  Region strides are padded so that the 8
+  // lanes of a ds_write_b128 group (units of 2 pixels x 4 regions, or 4 couts x 2 k-halves) cover all 32 write banks.
+  constexpr int A_REGION = MAXPIX * 16 + 32;     // region q = plane + 2 * k-half at q * A_REGION
+  constexpr int A_BYTES = 4 * A_REGION;
+  constexpr int B_HALF = BN * 16 + 64, B_PLANE = 2 * B_HALF, B_TAP = 2 * B_PLANE;  // per tap: [plane][k-half][cout][16 B]
+  constexpr int STAGE = A_BYTES + 3 * B_TAP;
+  static_assert(2 * STAGE == kRowpatchLds, "LDS size of the launch");
   constexpr int AI = (MAXPIX * 4 + 255) / 256;   // 16-byte activation records per thread per chunk
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -726,10 +786,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
       if (!((okmask >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                    \
       const int idx_ = tid + 256 * i;                                                            \
       if (idx_ < MAXPIX * 4)   /* unit q = idx&3 of the pixel's 16 channels: plane q&1, 8-channel block q>>1 */ \
-        *reinterpret_cast<u32x4*>(st_ + (idx_ & 1) * A_PLANE + (idx_ >> 2) * 32 + ((idx_ >> 1) & 1) * 16) = v; \
+        *reinterpret_cast<u32x4*>(st_ + (idx_ & 3) * A_REGION + (idx_ >> 2) * 16) = v;             \
     }                                                                                            \
     _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
-      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + kx * B_TAP + tid * 16) = rb[kx];             \
+      *reinterpret_cast<u32x4*>(st_ + A_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = rb[kx]; \
   }
 
   f32x16 acc[TM][TN], accx[TM][TN];
@@ -746,9 +806,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
   for (int tm = 0; tm < TM; ++tm) {
     const int r = wave * WROWS + tm * 32 + li;
     const int y = r / a.Wo, x = r - y * a.Wo;
-    arow[tm] = (y * pw + x) * 32 + lh * 16;
+    arow[tm] = 2 * lh * A_REGION + (y * pw + x) * 16;   // hi plane of k-half lh; the lo' plane is one region further
   }
-  const int boff = 2 * A_PLANE + li * 32 + lh * 16;
+  const int boff = A_BYTES + lh * B_HALF + li * 16;
   SERL_RP_LOAD(0);
   SERL_RP_STORE(0);
   __syncthreads();
@@ -761,13 +821,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
       f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
-        ahi[tm] = *reinterpret_cast<const f16x8*>(st + arow[tm] + kx * 32);
-        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_PLANE + arow[tm] + kx * 32);
+        ahi[tm] = *reinterpret_cast<const f16x8*>(st + arow[tm] + kx * 16);
+        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_REGION + arow[tm] + kx * 16);
       }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        bhi[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + tn * 32 * 32);
-        blo[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + B_PLANE + tn * 32 * 32);
+        bhi[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + tn * 32 * 16);
+        blo[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + B_PLANE + tn * 32 * 16);
       }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
@@ -784,50 +844,142 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 #undef SERL_RP_LOAD
 #undef SERL_RP_STORE
 
-  const int wrow0 = m0 + wave * WROWS;
-  float winv[TN];
+  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-SLAB variant of the row-patch kernel (default for stage 0).  PMC on the row-patch kernel: 0 LDS bank conflicts after
+// the layout fix, MFMA pipe busy 27 % -- the kernel moves 1.43 GB from L2 to LDS per launch (4096 tiles x 12 chunks x
+// (17 KB of activations + 12 KB of weights)) in 300 us = 4.8 TB/s: it is bound by L2 -> LDS traffic, not by LDS or MFMA.
+// Here the K loop is channel-major: for each group of 16 input channels the workgroup stages the (TR + 2) x (Wo + 2)
+// input pixels ONCE (a slab: 22 KB) and serves all NINE taps from it (ky shifts the row, kx the pixel); only the 3 taps'
+// weights (13 KB) are streamed per (channel group, ky) sub-chunk.  The next slab is fetched in three parts under the three
+// sub-chunks of the current one, so a thread stages 2 activation units + 3 weight units per sub-chunk (20 registers
+// instead of 32).  Activation traffic 835 -> 357 MB per launch (the operand crosses L2 -> LDS 1.25x instead of 3x).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowslabPix = 340;   // (8 + 2) x 34 (Wo = 32); (16 + 2) x 18 = 324 (Wo = 16)
+constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (64 * 16 + 64);
+__global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
+  constexpr int A_REGION = kRowslabPix * 16 + 32, A_BYTES = 4 * A_REGION;   // layout as in the row-patch kernel
+  constexpr int B_HALF = BN * 16 + 64, B_PLANE = 2 * B_HALF, B_TAP = 2 * B_PLANE, B_BYTES = 3 * B_TAP;
+  static_assert(2 * A_BYTES + 2 * B_BYTES == kRowslabLds, "LDS size of the launch");
+  constexpr int AJ = 2;   // activation units per thread per sub-chunk: 3 x 2 x 256 = 1536 >= 340 x 4
+  static_assert(3 * AJ * 256 >= kRowslabPix * 4, "a slab is fetched in three parts");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  uint8_t* const smA = smemb;
+  uint8_t* const smB = smemb + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
+  const int m0 = id * BM, n0 = 0;
+  const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
+  const int pw = a.Wo + 2, npix = (BM / a.Wo + 2) * pw;
+  const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
+  int rbase[3][AJ];        // element offset of unit (part, j) of a slab at channel group 0 (clamped into the image)
+  unsigned okbits = 0;     // bit part*AJ + j: the unit's pixel lies inside the image (else it is stored as zeros)
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + tn * 32 + li];
+  for (int part = 0; part < 3; ++part)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int u = (part * AJ + j) * 256 + tid, pix = u >> 2, q = u & 3;
+      const int sy = pix / pw, sx = pix - sy * pw;
+      const int iy = oy0 - 1 + sy, ix = sx - 1;
+      const int iyc = min(max(iy, 0), a.Hi - 1), ixc = min(max(ix, 0), a.Wi - 1);
+      rbase[part][j] = ((n_img * a.Hi + iyc) * a.Wi + ixc) * a.Cin + 4 * q;
+      if (pix < npix && iy == iyc && ix == ixc) okbits |= 1u << (part * AJ + j);
+    }
+  const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
+  const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
+  u32x4 ra[AJ], rb[3];
+
+// fetch into registers: part PART of the slab of channel group CG (activations), the 3 taps of (channel group BG, row BKY)
+#define SERL_RS_LOAD_A(PART, CG)                                                                   \
+  _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                   \
+    ra[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[PART][j] + ((CG) << 4));
+#define SERL_RS_LOAD_B(BG, BKY)                                                                    \
+  _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
+    rb[kx] = *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
+#define SERL_RS_STORE_A(PART, ABUF)                                                                \
+  _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                 \
+    const int u_ = ((PART) * AJ + j) * 256 + tid;                                                  \
+    u32x4 v = ra[j];                                                                               \
+    if (!((okbits >> ((PART) * AJ + j)) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                        \
+    if (u_ < kRowslabPix * 4)                                                                      \
+      *reinterpret_cast<u32x4*>(smA + (ABUF) * A_BYTES + (u_ & 3) * A_REGION + (u_ >> 2) * 16) = v; \
+  }
+#define SERL_RS_STORE_B(BBUF)                                                                      \
+  _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
+    *reinterpret_cast<u32x4*>(smB + (BBUF) * B_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = rb[kx];
+
+  f32x16 acc[TM][TN], accx[TM][TN];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
-  FusedResidual<TM, TN> fres;
-  if (ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0, li, lh);
-  if (!ab.fz.mode) {
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+
+  const int li = lane & 31, lh = lane >> 5;
+  int arow[TM];  // LDS byte offset of this lane's pixel at (ky, kx) = (0, 0) for each 32-row MFMA tile
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float* o = a.out + (size_t)m * a.Cout + n0 + li;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
-      }
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wave * WROWS + tm * 32 + li;
+    const int y = r / a.Wo, x = r - y * a.Wo;
+    arow[tm] = 2 * lh * A_REGION + (y * pw + x) * 16;
   }
-  {
-    const int gsize = a.Cout / kGnGroups;
-    double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
+  const int boff = lh * B_HALF + li * 16;
+  // prologue: slab 0 (three parts) and the weights of sub-chunk 0
+  SERL_RS_LOAD_B(0, 0);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      float s = 0.f, q = 0.f;
+  for (int part = 0; part < 3; ++part) {
+    SERL_RS_LOAD_A(part, 0);
+    SERL_RS_STORE_A(part, 0);
+  }
+  SERL_RS_STORE_B(0);
+  __syncthreads();
+  int cg = 0, ky = 0;   // channel group and kernel row of sub-chunk c
+  for (int c = 0; c < nchunks; ++c) {
+    // next sub-chunk's weights; part ky of the next slab (the last slab re-fetches itself: harmless, keeps the loop uniform)
+    const int ncg = ky == 2 ? cg + 1 : cg, nky = ky == 2 ? 0 : ky + 1;
+    const int ncg_c = min(ncg, c16n - 1), slab_next = min(cg + 1, c16n - 1);
+    SERL_RS_LOAD_B(ncg_c, nky);
+    if (ky == 0) { SERL_RS_LOAD_A(0, slab_next); } else if (ky == 1) { SERL_RS_LOAD_A(1, slab_next); } else { SERL_RS_LOAD_A(2, slab_next); }
+    const uint8_t* sa = smA + (cg & 1) * A_BYTES + ky * pw * 16;
+    const uint8_t* sb = smB + (c & 1) * B_BYTES;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        ahi[tm] = *reinterpret_cast<const f16x8*>(sa + arow[tm] + kx * 16);
+        alo[tm] = *reinterpret_cast<const f16x8*>(sa + A_REGION + arow[tm] + kx * 16);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        bhi[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + tn * 32 * 16);
+        blo[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + B_PLANE + tn * 32 * 16);
+      }
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[tm][tn][r];
-          s += v;
-          q += v * v;
+        for (int tn = 0; tn < TN; ++tn) {
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
         }
-      stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
     }
+    // the other weight buffer was last read in sub-chunk c - 1, the other slab buffer during the previous channel group
+    SERL_RS_STORE_B((c + 1) & 1);
+    if (ky == 0) { SERL_RS_STORE_A(0, (cg + 1) & 1); } else if (ky == 1) { SERL_RS_STORE_A(1, (cg + 1) & 1); } else { SERL_RS_STORE_A(2, (cg + 1) & 1); }
+    __syncthreads();
+    cg = ncg; ky = nky;
   }
-  if (ab.fz.mode) {
-    fused_arrive_and_wait(ab.fz.sync + n_img, ab.fz.expected);
-    fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0, li, lh);
-  }
+#undef SERL_RS_LOAD_A
+#undef SERL_RS_LOAD_B
+#undef SERL_RS_STORE_A
+#undef SERL_RS_STORE_B
+  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1716,8 +1868,9 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       if (fuse && fuse->mode && a.P % 256 == 0) {
         ab.fz = *fuse; ab.fz.expected = a.P / 256; fused = true;
       }
-      hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)2 * (2 * 288 * 32 + 3 * 2 * 64 * 32),
-                         stream, ab);
+      static const bool slab = []() { const char* e = getenv("SERL_CONV_ROWSLAB"); return !(e && e[0] == '0'); }();
+      if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowslabLds, stream, ab);
+      else hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowpatchLds, stream, ab);
     } else if (dma_ok) {
       static const int force_tn = []() { const char* e = getenv("SERL_CONV_DMA_TN"); return e ? atoi(e) : 0; }();
       const int tn = force_tn ? force_tn : (cfg == 0 ? 2 : 1), bn = 64 * tn;
