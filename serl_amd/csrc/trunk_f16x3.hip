@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
 // Epilogue of a 256 x 64 output tile held by 4 waves of 64 x 64 (all rows in image n_img): combine the two accumulators,
 // undo the weight scale, GroupNorm statistics, then either the raw fp32 store or the fused GroupNorm modes.
 __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], int m0, int n0,
-                                                 int n_img, int wave, int li, int lh) {
+                                                 int n_img, int wave, int li, int lh, int sync_idx) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64;
   const int wrow0 = m0 + wave * WROWS;
@@ -706,7 +706,7 @@ __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&a
     }
   }
   if (ab.fz.mode) {
-    fused_arrive_and_wait(ab.fz.sync + n_img, ab.fz.expected);
+    fused_arrive_and_wait(ab.fz.sync + sync_idx, ab.fz.expected);
     fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0, li, lh);
   }
 }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 #undef SERL_RP_LOAD
 #undef SERL_RP_STORE
 
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh);
+  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -872,7 +872,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   uint8_t* const smB = smemb + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
-  const int m0 = id * BM, n0 = 0;
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;   // 64-channel column tiles of one row tile are neighbours (shared slab in L2)
+  const int m0 = bm * BM, n0 = bn * BN;
   const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
   const int pw = a.Wo + 2, npix = (BM / a.Wo + 2) * pw;
   const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 #undef SERL_RS_LOAD_B
 #undef SERL_RS_STORE_A
 #undef SERL_RS_STORE_B
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh);
+  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1855,7 +1856,10 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3>), grid, block, lds, stream, ab);                 \
   } while (0)
     static const bool use_rp = []() { const char* e = getenv("SERL_CONV_ROWPATCH"); return !(e && e[0] == '0'); }();
-    const bool rp_ok = use_rp && ksz == 3 && stride == 1 && Cout == 64 && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
+    static const bool slab = []() { const char* e = getenv("SERL_CONV_ROWSLAB"); return !(e && e[0] == '0'); }();
+    // SERL_CONV_ROWSLAB_MAXC: widest layer (output channels) the row-slab kernel takes over from the LDS-DMA kernel
+    static const int slab_maxc = []() { const char* e = getenv("SERL_CONV_ROWSLAB_MAXC"); return e ? atoi(e) : 128; }();
+    const bool rp_ok = use_rp && ksz == 3 && stride == 1 && (Cout == 64 || (slab && Cout <= slab_maxc && Cout / 64 <= kSyncPerImage)) && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
                        (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 &&
                        (long)N * Hi * Wi * Cin < (1L << 31);
     // SERL_CONV_DMA: 0 = register-staged kernels only, 2 / 3 = LDS-DMA kernel with that many LDS stages (default 2)
@@ -1868,8 +1872,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       if (fuse && fuse->mode && a.P % 256 == 0) {
         ab.fz = *fuse; ab.fz.expected = a.P / 256; fused = true;
       }
-      static const bool slab = []() { const char* e = getenv("SERL_CONV_ROWSLAB"); return !(e && e[0] == '0'); }();
-      if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowslabLds, stream, ab);
+      a.tiles_m = a.M / 256; a.tiles_n = slab ? Cout / 64 : 1;
+      if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       else hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowpatchLds, stream, ab);
     } else if (dma_ok) {
       static const int force_tn = []() { const char* e = getenv("SERL_CONV_DMA_TN"); return e ? atoi(e) : 0; }();
