@@ -273,6 +273,28 @@ int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64
 /* inject gradients / scalars ("g_critic", "g_actor", "scalars") before serl_agent_apply: optimizer tests */
 int serl_agent_debug_set(serl_agent* a, const char* what, const float* host, int64_t count);
 
+/* ---------------------------------------------------------------------------------------------
+ * Reward classifier, inference only (next-row N4; serl_launcher/networks/reward_classifier.py:16-113).
+ * BinaryClassifier = EncodingWrapper(use_proprio=False) over the frozen ResNet-10 trunk (per camera:
+ * SpatialLearnedEmbeddings(8) -> Dense(256) -> LayerNorm -> tanh, concatenated) -> Dense(256) -> [Dropout: identity at
+ * train=False] -> LayerNorm -> ReLU -> Dense(1).  serl_classifier_logits is the function load_classifier_func
+ * (reward_classifier.py:93-113) returns: observations in, logits out.  Leaves (flat fp32, HWIO kernels / [in][out]
+ * dense kernels): the trunk leaves of the agent ("trunk/..."), "enc/<k>/{sle, dense/kernel, dense/bias, ln/scale,
+ * ln/bias}", "head/dense0/{kernel,bias}", "head/ln/{scale,bias}", "head/dense1/{kernel,bias}".
+ * --------------------------------------------------------------------------------------------- */
+typedef struct serl_classifier serl_classifier;
+typedef struct {
+  int device, n_cam, H, W, max_batch;
+} serl_classifier_cfg;
+int serl_classifier_create(const serl_classifier_cfg* cfg, serl_classifier** out);
+int serl_classifier_destroy(serl_classifier* c);
+int serl_classifier_num_leaves(serl_classifier* c);
+int serl_classifier_leaf_info(serl_classifier* c, int i, char* name_out, int name_cap, int64_t* count);
+int serl_classifier_set(serl_classifier* c, const char* leaf, const float* host, int64_t count);
+int serl_classifier_get(serl_classifier* c, const char* leaf, float* host_out, int64_t count);
+/* dev_frames u8[n_cam][n][H][W][3] (device), n <= max_batch; dev_logits f32[n] (device) */
+int serl_classifier_logits(serl_classifier* c, const uint8_t* dev_frames, int n, float* dev_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

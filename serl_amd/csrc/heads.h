@@ -29,6 +29,7 @@ struct LnFwdArgs {
   // optional fused row-dot (critic head, actor_critic_nets.py:65-73): dot_out[row] = sum_col y*dot_w + dot_b[0]
   const float* dot_w; const float* dot_b; float* dot_out;
   long dot_gstride, dot_b_gstride;  // 0: one head shared by all groups (DrQ critic); else per-group heads (ensemblized Critic)
+  int relu;              // 0: tanh (the MLPs / encoder heads); 1: ReLU (BinaryClassifier, reward_classifier.py:24-26)
 };
 int ln_tanh_fwd_multi(const LnFwdArgs* a, int n, int D, hipStream_t stream);
 

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
   for (int j = 0; j < VPL; ++j) {
     const int col = lane * VPL + j;
     const float xh = (v[j] - mean) * rstd;
-    const float y = tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]);
+    const float pre = xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col];
+    const float y = a.relu ? fmaxf(pre, 0.f) : tanhf(pre);
     a.y[(long)(row - grp * a.rows_per_group) * a.ld_y + (long)grp * a.y_goff + col] = y;
     if (a.xhat) a.xhat[(long)row * D + col] = xh;
   }
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
     for (int j = 0; j < VPL; ++j) {
       const int col = lane * VPL + j;
       const float xh = (v[j] - mean) * rstd;
-      d += tanhf(xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col]) *
-           a.dot_w[(long)grp * a.dot_gstride + col];
+      const float pre = xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col];
+      d += (a.relu ? fmaxf(pre, 0.f) : tanhf(pre)) * a.dot_w[(long)grp * a.dot_gstride + col];
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off);

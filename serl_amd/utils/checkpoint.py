@@ -87,6 +87,26 @@ def restore_checkpoint(ckpt_dir_or_file: str, agent, step: Optional[int] = None,
     return load_state_dict(agent, sd)
 
 
+def read_checkpoint_tree(ckpt_dir_or_file: str, step: Optional[int] = None, prefix: str = "checkpoint_") -> dict:
+    """The state dict stored in a flax checkpoint file (or the latest / the given step of a directory of them)."""
+    path = ckpt_dir_or_file
+    if os.path.isdir(path):
+        path = os.path.join(path, f"{prefix}{step}") if step is not None else latest_checkpoint(path, prefix)
+        if path is None:
+            raise FileNotFoundError(f"no {prefix}<step> file in {ckpt_dir_or_file}")
+    with open(path, "rb") as f:
+        return msgpack.unpackb(f.read(), ext_hook=_unpack_ext, raw=False, strict_map_key=False)
+
+
+def write_checkpoint_tree(ckpt_dir: str, tree: dict, step: int, prefix: str = "checkpoint_") -> str:
+    """Writes `tree` (nested dicts of ndarrays / scalars) as <ckpt_dir>/<prefix><step> in the same msgpack layout."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    path = os.path.join(ckpt_dir, f"{prefix}{step}")
+    with open(path, "wb") as f:
+        f.write(msgpack.packb(tree, default=_pack_default, strict_types=True, use_bin_type=True))
+    return path
+
+
 def _find_adam_state(node):
     """The ScaleByAdamState {count, mu, nu} inside an InjectHyperparamsState / chain state dict (any nesting), or the
     node itself for the flat {count, mu, nu} layout written by earlier versions of this module."""

@@ -126,3 +126,30 @@ def init_theta(n_cam, H, W, S, A, seed=42, temperature_init=1e-2, **kw):
         else:
             out[name] = np.zeros(shp, np.float32)
     return out
+
+
+def init_classifier(n_cam, H, W, seed=42):
+    """Initial parameters of the reward classifier's trainable part (networks/reward_classifier.py:16-28 over
+    EncodingWrapper(use_proprio=False)): camera heads as in init_theta (SpatialLearnedEmbeddings lecun-normal, Dense
+    xavier-uniform, LayerNorm ones/zeros -- resnet_v1.py:94-104,363-374), Dense layers of the head with flax's default
+    lecun-normal kernels and zero biases.  Host-side numpy streams, not jax's threefry (as for the agents)."""
+    theta = init_theta(n_cam, H, W, 4, 2, seed=seed)
+    out = {k: v for k, v in theta.items() if k.startswith("enc/") and not k.startswith("enc/proprio")}
+    rng = np.random.default_rng(seed + 77)
+    E = 256 * n_cam
+
+    def lecun(fan_in, shape):   # jax.nn.initializers.lecun_normal: truncated normal, std = sqrt(1 / fan_in) / 0.8796
+        std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+        v = rng.standard_normal(shape)
+        bad = np.abs(v) > 2.0
+        while bad.any():
+            v[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(v) > 2.0
+        return (v * std).astype(np.float32)
+    out["head/dense0/kernel"] = lecun(E, (E, 256))
+    out["head/dense0/bias"] = np.zeros(256, np.float32)
+    out["head/ln/scale"] = np.ones(256, np.float32)
+    out["head/ln/bias"] = np.zeros(256, np.float32)
+    out["head/dense1/kernel"] = lecun(256, (256, 1))
+    out["head/dense1/bias"] = np.zeros(1, np.float32)
+    return out
