@@ -30,7 +30,8 @@ def load(d):
     return tot, disp
 
 
-FAMILIES = (("conv_dma_f16x3", ("conv_dma_f16x3_kernel",)), ("conv3x3_rowpatch_f16x3", ("conv3x3_rowpatch_f16x3_kernel",)),
+FAMILIES = (("conv_dma_f16x3", ("conv_dma_f16x3_kernel",)), ("conv3x3_rowslab_f16x3", ("conv3x3_rowslab_f16x3_kernel",)),
+            ("conv3x3_rowpatch_f16x3", ("conv3x3_rowpatch_f16x3_kernel",)),
             ("conv_igemm_f16x3", ("conv_igemm_f16x3_kernel",)), ("conv_init_u8", ("conv_init_u8_kernel",)),
             ("gemm_f32", ("gemm_f32_kernel",)), ("gather_crop_rgb", ("gather_crop_rgb_kernel",)))
 out = {"note": __doc__.split("Per kernel family:")[1].strip()}
