@@ -36,7 +36,8 @@ constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
 // workgroup only ever waits for workgroups that are already running, whatever order the hardware dispatches blocks in.
 struct FuseArgs {
   int mode;                 // 0 off; 1 relu(GN(y)); 2 relu(GN(y) + res_split); 3 relu(GN(y) + GN_res(res_raw))
-  int expected;             // arrivals per counter
+  int expected;             // arrivals per counter; 0 = LOCAL: a wave's 64 rows x 64 columns are exactly one (image, group), no
+                            // workgroup exchanges anything (P == 64 and Cout / 4 == 64: stage 2) -- no ticket, no wait
   int* sync;                // [image][tiles_n] arrival counters, zeroed with the statistics
   int* ticket;              // zeroed with the statistics
   GnRef gn;                 // this conv's statistics (being produced), scale, bias
@@ -162,7 +163,8 @@ __device__ __forceinline__ void fused_load_residual(const ConvArgsB& ab, FusedRe
 
 template <int TM, int TN>
 __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16 (&acc)[TM][TN],
-                                               const FusedResidual<TM, TN>& res, int n_img, int wrow0, int col0, int li, int lh) {
+                                               const FusedResidual<TM, TN>& res, int n_img, int wrow0, int col0, int li, int lh,
+                                               bool local = false, float local_mean = 0.f, float local_rstd = 0.f) {
   const FuseArgs& fz = ab.fz;
   const int Cout = ab.c.Cout;
   const bool odd = li & 1;
@@ -174,7 +176,12 @@ __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16
   for (int tn = 0; tn < TN; ++tn) {
     const int c = col0 + tn * 32 + li;
     float sc, sh, rs = 0.f, rh = 0.f;
-    gn_coef1<true>(fz.gn, n_img, c, sc, sh);
+    if (local) {   // statistics of this wave's own 64 x 64 block = the whole (image, group)
+      sc = fz.gn.gamma[c] * local_rstd;
+      sh = fz.gn.beta[c] - local_mean * sc;
+    } else {
+      gn_coef1<true>(fz.gn, n_img, c, sc, sh);
+    }
     if (fz.mode == 3) gn_coef1<false>(fz.res_gn, n_img, c, rs, rh);
     const int cbyte = (c & ~7) * 4 + (odd ? 16 : 0) + (c & 6) * 2;
     const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh}, rs2 = {rs, rs}, rh2 = {rh, rh};
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
+  const int id = xcd_remap((ab.fz.mode && ab.fz.expected) ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int ntaps = a.KH * a.KW;
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
         }
       }
   }
-  if (PMODE != 3) {
+  if (PMODE != 3 && !(ab.fz.mode && !ab.fz.expected)) {   // (LOCAL fused mode keeps its statistics in the wave)
     const int gsize = a.Cout / kGnGroups;
     constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
     constexpr int NSLOT = WROWS / ROWS;
@@ -652,10 +659,26 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
       }
     }
   }
-  if (PMODE == 0 && ab.fz.mode) {   // the launcher guarantees P % BM == 0: the whole tile lies in one image
+  if (PMODE == 0 && ab.fz.mode && ab.fz.expected) {   // the launcher guarantees P % BM == 0: the whole tile lies in one image
     const int n_img = m0 / a.P;
     fused_arrive_and_wait(ab.fz.sync + n_img * a.tiles_n + bn, ab.fz.expected);
     fused_gn_store<TM, TN>(ab, acc, fres, n_img, wrow0, n0 + wn * WCOLS, li, lh);
+  } else if (PMODE == 0 && ab.fz.mode) {              // LOCAL: this wave's block is one whole (image, group)
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float ps = 0.f, pq = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; ps += v; pq += v * v; }
+      s += (double)ps; q += (double)pq;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    const double mean = s * ab.fz.gn.inv_count, m2 = q * ab.fz.gn.inv_count;
+    const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+    fused_gn_store<TM, TN>(ab, acc, fres, wrow0 / a.P, wrow0, n0 + wn * WCOLS, li, lh, true, (float)mean, rsqrtf(var + 1e-5f));
   }
 }
 
@@ -1885,6 +1908,9 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       if (pmode == 1 && cfg == 4) pmode = 3;
       if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage) {
         ab.fz = *fuse; ab.fz.expected = a.P / 128; fused = true;
+      } else if (fuse && fuse->mode && pmode == 0 && a.P == 64 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 64) {
+        static const bool local_on = []() { const char* e = getenv("SERL_GN_FUSE_LOCAL"); return !(e && e[0] == '0'); }();
+        if (local_on) { ab.fz = *fuse; ab.fz.expected = 0; fused = true; }   // a wave = one (image, group): no exchange
       }
 #define SERL_LAUNCH_DMA(TN_, NS_)                                                                                        \
   do {                                                                                                                   \
