@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--prio", choices=["auto", "update", "trunk", "none"], default="auto",
                     help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
+    ap.add_argument("--update-after-stage", type=int, default=None,
+                    help="start update(i) only when the trunk pass of batch i+1 has finished this residual stage (0..2); "
+                         "default: SERL_UPDATE_AFTER_STAGE or off")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
     ap.add_argument("--force-launcher", action="store_true",
@@ -154,9 +157,14 @@ def main():
         return dbs[slot]
 
     from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
+    uas = args.update_after_stage if args.update_after_stage is not None else (
+        int(os.environ["SERL_UPDATE_AFTER_STAGE"]) if os.environ.get("SERL_UPDATE_AFTER_STAGE", "") != "" else None)
+    if uas is not None and (uas < 0 or uas > 2 or args.trunk != "f16x3"):
+        uas = None
     prio = args.prio if args.prio != "auto" else ("trunk" if Bl >= 128 else "update")
     sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank), prioritise_update=prio == "update",
-                                                                            prioritise_trunk=prio == "trunk")
+                                                                            prioritise_trunk=prio == "trunk",
+                                                                            update_after_stage=uas)
     # gradient all-reduce (common.py:213-214 pmean made real), HIP events around every 4th call on the stream it runs on
     coll = {"calls": 0, "bytes": 0, "timed": [], "on": False}
 

@@ -235,6 +235,10 @@ int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream); /* 
  * caller orders the streams with events; serl_agent_select_slot picks the batch the following
  * *_grads calls consume.  serl_agent_encode == encode_slot(0) + select_slot(0). */
 int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, void* stream);
+/* The same pass issued in consecutive pieces: stages [stage_begin, stage_end] with -1 = conv_init + max-pool and 0..3 = the
+ * residual stages (split-fp16 trunk, full-size batch).  The caller may record an event between two pieces, e.g. to start
+ * the update of the previous batch only once this pass has left its first stages. */
+int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slot, int stage_begin, int stage_end, void* stream);
 int serl_agent_select_slot(serl_agent* a, int slot);
 int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
                             const serl_noise* noise, int redq_row, void* stream);

@@ -55,6 +55,7 @@ def declare(lib):
         "serl_agent_read_info": [vp, P(SerlInfo), vp],
         "serl_agent_encode": [vp, P(SerlBatch), vp],
         "serl_agent_encode_slot": [vp, P(SerlBatch), i32, vp],
+        "serl_agent_encode_slot_range": [vp, P(SerlBatch), i32, i32, i32, vp],
         "serl_agent_select_slot": [vp, i32],
         "serl_agent_critic_grads": [vp, i32, i32, i32, P(SerlNoise), i32, vp],
         "serl_agent_actor_grads": [vp, i32, P(SerlNoise), vp],

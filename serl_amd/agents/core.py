@@ -153,6 +153,10 @@ class AgentCore:
     def encode_slot(self, batch, slot):
         _lib.check(self.L.serl_agent_encode_slot(self._h, C.byref(batch.cstruct), slot, self._stream()))
 
+    def encode_slot_range(self, batch, slot, stage_begin, stage_end):
+        """A piece of encode_slot: stages [stage_begin, stage_end], -1 = conv_init + max-pool, 0..3 = residual stages."""
+        _lib.check(self.L.serl_agent_encode_slot_range(self._h, C.byref(batch.cstruct), slot, stage_begin, stage_end, self._stream()))
+
     def select_slot(self, slot):
         _lib.check(self.L.serl_agent_select_slot(self._h, slot))
 

@@ -889,8 +889,13 @@ static int check_batch(serl_agent* a, const serl_batch* b) {
 }
 
 int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, void* stream) {
+  return serl_agent_encode_slot_range(a, batch, slot, -1, kTrunkStages - 1, stream);
+}
+
+int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slot, int stage_begin, int stage_end, void* stream) {
   SERL_REQUIRE(a, "NULL agent");
   SERL_REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
+  SERL_REQUIRE(stage_begin >= -1 && stage_begin <= stage_end && stage_end < kTrunkStages, "bad stage range [%d, %d]", stage_begin, stage_end);
   int rc = check_batch(a, batch);
   if (rc) return rc;
   SERL_HIP(hipSetDevice(a->cfg.device));
@@ -904,8 +909,9 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
   if (a->state_only || a->small) return SERL_OK;  // no frozen encoder: nothing to precompute
   if (B == c.batch) {  // frames [2][n_cam][B] are one contiguous run of 2*n_cam*B images
     // (sub-batching the run to keep activations in the Infinity Cache was measured: slower -- DESIGN.md)
-    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr);
+    return trunk_forward(a->tw, a->tws, batch->frames, 2 * c.n_cam * B, feats, st, a->trunk_mode ? &a->tpk : nullptr, stage_begin, stage_end);
   }
+  SERL_REQUIRE(stage_begin < 0 && stage_end == kTrunkStages - 1, "partial trunk passes need a full-size batch");
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < c.n_cam; ++k)
       RC(trunk_forward(a->tw, a->tws, batch->frames + ((size_t)(w * c.n_cam + k) * B) * fbytes, B,

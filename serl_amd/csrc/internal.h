@@ -55,8 +55,10 @@ size_t trunk_packed_bytes();
 int trunk_packed_bind(TrunkPacked& p, void* mem);
 // frames: u8 [n][H][W][3] (device) -> feats: f32 [n][h5][w5][512] (device).
 // packed == nullptr: exact fp32 MFMA convs; otherwise the split-fp16 (f16x3) convs for the blocks.
+// [stage_begin, stage_end] (split-fp16 path only): -1 = conv_init + pool, 0..3 = residual stages
 int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n,
-                  float* feats_out, hipStream_t stream, TrunkPacked* packed = nullptr);
+                  float* feats_out, hipStream_t stream, TrunkPacked* packed = nullptr, int stage_begin = -1,
+                  int stage_end = kTrunkStages - 1);
 
 // --------------------------------------------------------------------------------------------
 // small dense building blocks (heads.hip)

@@ -600,15 +600,16 @@ static int trunk_pack(const TrunkWeights& w, TrunkPacked& p, hipStream_t stream)
 }
 
 int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* frames, int n, float* feats_out,
-                  hipStream_t stream, TrunkPacked* packed) {
+                  hipStream_t stream, TrunkPacked* packed, int stage_begin, int stage_end) {
   if (packed && packed->dirty) {
     int prc = trunk_pack(w, *packed, stream);
     if (prc) return prc;
   }
   if (packed) {
     SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
-    return trunk_forward_f16x3(w, ws, *packed, frames, n, feats_out, stream);
+    return trunk_forward_f16x3(w, ws, *packed, frames, n, feats_out, stream, stage_begin, stage_end);
   }
+  SERL_REQUIRE(stage_begin < 0 && stage_end == kTrunkStages - 1, "the exact-fp32 trunk runs whole passes only");
   SERL_REQUIRE(n > 0 && n <= ws.max_images, "trunk_forward: %d images exceeds workspace (%d)", n, ws.max_images);
   const TrunkDims& d = ws.d;
   const int N = n;

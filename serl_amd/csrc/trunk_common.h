@@ -92,7 +92,7 @@ struct PackedConvWeights {
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream);
 // whole trunk in split-fp16 arithmetic (trunk_f16x3.hip)
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
-                        float* feats_out, hipStream_t stream);
+                        float* feats_out, hipStream_t stream, int stage_begin = -1, int stage_end = kTrunkStages - 1);
 
 // conv_init in split-fp16 (weights re-indexed and padded to [64][176])
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream);

@@ -1967,10 +1967,12 @@ static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta
 // Trunk forward in split-fp16 arithmetic.  Activations between kernels live in the split16 layout;
 // raw conv outputs (pre-GroupNorm) and the final features stay fp32.
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
-                        float* feats_out, hipStream_t stream) {
+                        float* feats_out, hipStream_t stream, int stage_begin, int stage_end) {
+  // [stage_begin, stage_end]: -1 = conv_init + pool, 0..3 = residual stages; a pass may be issued in consecutive pieces
+  // (the intermediate activations live in the workspace), which lets the caller put an event between them
   const TrunkDims& d = ws.d;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
-  SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
+  if (stage_begin < 0) SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
   auto fuse_of = [&](int layer, int mode) {
     FuseArgs f{};
     const char* e = getenv("SERL_GN_FUSE");   // read per pass: tests flip it inside one process
@@ -1980,28 +1982,30 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     return f;
   };
   int rc;
-  static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
-  const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
-  if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
-                                   d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket))) return rc;
-  if (fuse_pool) {
-    const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
-    const int ty = d.h[0] / 16, tx = d.w[0] / 16;
-    const float* pooled = ws.raw_init;
-    const float* frows = pooled + (size_t)N * d.h[1] * d.w[1] * 64;
-    const float* fcols = frows + (size_t)N * ty * d.w[0] * 64;
-    ProfScope prof("gn_relu_maxpool", stream);
-    hipLaunchKernelGGL(pool_finish_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, pooled, frows, fcols,
-                       gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
-                       reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], ty, tx);
-    SERL_HIP(hipGetLastError());
-  } else {
-    const long tot = (long)N * d.h[1] * d.w[1] * 16;
-    ProfScope prof("gn_relu_maxpool", stream);
-    hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init,
-                       gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
-                       reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
-    SERL_HIP(hipGetLastError());
+  if (stage_begin < 0) {
+    static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
+    const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
+    if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
+                                     d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket))) return rc;
+    if (fuse_pool) {
+      const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
+      const int ty = d.h[0] / 16, tx = d.w[0] / 16;
+      const float* pooled = ws.raw_init;
+      const float* frows = pooled + (size_t)N * d.h[1] * d.w[1] * 64;
+      const float* fcols = frows + (size_t)N * ty * d.w[0] * 64;
+      ProfScope prof("gn_relu_maxpool", stream);
+      hipLaunchKernelGGL(pool_finish_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, pooled, frows, fcols,
+                         gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+                         reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], ty, tx);
+      SERL_HIP(hipGetLastError());
+    } else {
+      const long tot = (long)N * d.h[1] * d.w[1] * 16;
+      ProfScope prof("gn_relu_maxpool", stream);
+      hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init,
+                         gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+                         reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
+      SERL_HIP(hipGetLastError());
+    }
   }
   const float* x = ws.pool;  // split16
   int cin = 64;
@@ -2010,6 +2014,8 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
                                                 {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
                                                 {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
   for (int i = 0; i < kTrunkStages; ++i) {
+    if (i >= 1) { x = ws.blk[i - 1].out; cin = kStageFilters[i - 1]; }
+    if (i < stage_begin || i > stage_end) continue;
     const int f = kStageFilters[i], s = kStageStride[i];
     const int Hi = d.h[1 + i], Wi = d.w[1 + i], Ho = d.h[2 + i], Wo = d.w[2 + i], P = Ho * Wo;
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;

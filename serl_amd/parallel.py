@@ -72,10 +72,15 @@ class TorchPipelineSchedule:
     """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream."""
     slots = 2
 
-    def __init__(self, device, prioritise_update=True, prioritise_trunk=False):
+    def __init__(self, device, prioritise_update=True, prioritise_trunk=False, update_after_stage=None):
+        """update_after_stage = s (0..2): the update of batch i starts only when the trunk pass of batch i+1 has finished
+        its stage s (the pass is issued in two pieces with an event between them), so the update chain's small kernels
+        co-run with the later, register-lighter conv kernels instead of conv_init / stage 0."""
         import torch
         self.torch = torch
         self.device = device
+        self.update_after_stage = update_after_stage
+        self.ev_mid = [torch.cuda.Event() for _ in range(2)]
         # the update's long chain of small dependent kernels gets the high-priority queue so that it is
         # not starved by the (throughput-bound) trunk kernels of the next batch
         self.side_stream = torch.cuda.Stream(device=device, priority=-1 if prioritise_trunk else 0)
@@ -92,6 +97,12 @@ class TorchPipelineSchedule:
 
     def produced(self, slot):
         self.ev_prod[slot].record(self.side_stream)
+
+    def mid_produced(self, slot):
+        self.ev_mid[slot].record(self.side_stream)
+
+    def wait_mid(self, slot):
+        self.torch.cuda.current_stream(self.device).wait_event(self.ev_mid[slot])
 
     def wait_produced(self, slot):
         self.torch.cuda.current_stream(self.device).wait_event(self.ev_prod[slot])
@@ -149,9 +160,15 @@ class DataParallelLearner:
         cn = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
         local, (lo, hi) = shard_parts(parts, self.rank, self.world)
         self.sched.wait_consumed(slot)
+        split = getattr(self.sched, "update_after_stage", None)
         with self.sched.side():
             db = self.gather(local, co[lo:hi], cn[lo:hi], slot)
-            self.core.encode_slot(db, slot)
+            if split is None or not hasattr(self.core, "encode_slot_range"):
+                self.core.encode_slot(db, slot)
+            else:   # two pieces with an event between them (see TorchPipelineSchedule)
+                self.core.encode_slot_range(db, slot, -1, split)
+                self.sched.mid_produced(slot)
+                self.core.encode_slot_range(db, slot, split + 1, 3)
         self.sched.produced(slot)
         return slot
 
@@ -160,6 +177,8 @@ class DataParallelLearner:
         self._pending = None
         if self.sched.slots > 1:
             self._pending = self._produce()      # batch i+1 overlaps the update of batch i
+            if getattr(self.sched, "update_after_stage", None) is not None:
+                self.sched.wait_mid(self._pending)
         self.sched.wait_produced(slot)
         self.core.select_slot(slot)
         return slot

@@ -319,7 +319,8 @@ def test_grad_view_aliases_library_memory(gpu):
 
 
 def test_pipelined_schedule_matches_serial(gpu):
-    """trunk(i+1) overlapped with update(i) on a second stream gives bit-identical parameters."""
+    """trunk(i+1) overlapped with update(i) on a second stream gives bit-identical parameters -- also when the trunk pass
+    is issued in two pieces and the update waits for the first piece of the NEXT pass (update_after_stage)."""
     import itertools
     from helpers import make_spaces
     from serl_amd.agents.batch import DeviceBatch
@@ -328,7 +329,7 @@ def test_pipelined_schedule_matches_serial(gpu):
     from serl_amd.utils.synthetic import transition_stream
     cfg = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
     outs = []
-    for sched_cls in (SerialSchedule, TorchPipelineSchedule):
+    for sched_cls in (SerialSchedule, TorchPipelineSchedule, "split"):
         _, core = AH.make_pair(cfg, 8, agent_seed=5)
         osp, asp = make_spaces(cfg.image_keys, 64, 64, 3, 1, 5, 3)
         rb = MemoryEfficientReplayBufferDataStore(osp, asp, 200, image_keys=cfg.image_keys)
@@ -341,7 +342,8 @@ def test_pipelined_schedule_matches_serial(gpu):
             gather_crop(parts, co, cn, dbs[slot])
             return dbs[slot]
 
-        sched = sched_cls() if sched_cls is SerialSchedule else sched_cls(torch.device("cuda", 0))
+        sched = sched_cls() if sched_cls is SerialSchedule else (
+            TorchPipelineSchedule(torch.device("cuda", 0), update_after_stage=1) if sched_cls == "split" else sched_cls(torch.device("cuda", 0)))
         lr = DataParallelLearner(core, gather, [rb], [8], schedule=sched, seed=3)
         for _ in range(4):
             lr.iteration(critic_actor_ratio=2)
@@ -349,6 +351,7 @@ def test_pipelined_schedule_matches_serial(gpu):
         outs.append({k: core.get("params", k) for k in ("critic/w1", "actor/w2", "enc/0/dense/kernel", "temp/lagrange")})
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k], outs[2][k]), ("split pass", k)
 
 
 def test_full_size_properties(gpu):
