@@ -54,6 +54,8 @@ struct ConvArgsB {
   const uint16_t* wlo;
   const float* winv;    // [Cout] 1 / (per-output-channel weight scale)
   int K;
+  int ksplit;           // register-staged kernel only: K-split factor (1 = off)
+  size_t slab_stride;   // elements between the partial-sum slabs of a K-split launch
   int dbg;              // timing experiments only (SERL_CONV_DBG): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no LDS reads
 };
 
@@ -238,7 +240,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  // K-split (ab.ksplit > 1, small M): `ksplit` neighbouring workgroups share a tile and take consecutive chunk ranges;
+  // each writes its partial sums into its own slab (deterministic), splitk_reduce_stats_kernel adds the slabs
+  const int ksplit = ab.ksplit > 1 ? ab.ksplit : 1;
+  const int id_s = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id_s % ksplit, id = id_s / ksplit;
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   // per-thread im2col rows: element offset of the always-valid centre tap (pixel (oy*s, ox*s)) and a
@@ -262,11 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       }
     }
   }
-  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
+  const int nchunks_all = a.KH * a.KW * (a.Cin >> 5);
+  const int cb = (int)((long)nchunks_all * split / ksplit);           // this workgroup's chunks: [cb, nchunks)
+  const int nchunks = (int)((long)nchunks_all * (split + 1) / ksplit);
   // (native vector types: HIP's uint4 struct copies lower to memcpy and keep the arrays out of registers)
   u32x4 ra[AI], rb[BI], ra2[DEEP >= 2 ? AI : 1], rb2[DEEP >= 2 ? BI : 1], ra3[DEEP >= 3 ? AI : 1], rb3[DEEP >= 3 ? BI : 1];
   unsigned okmask = 0, okmask2 = 0, okmask3 = 0;
-  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0;  // chunk counters (chunks are visited strictly in order)
+  // chunk counters (chunks are visited strictly in order), started at chunk cb
+  const int cpt = a.Cin >> 5;
+  int l_tap = cb / cpt, l_ci0 = (cb - l_tap * cpt) << 5, l_ky = l_tap / a.KW, l_kx = l_tap - l_ky * a.KW;
 
 #define SERL_LOAD_CHUNK_(CIDX, RA, RB, OK)                                                                                \
   {                                                                                                            \
@@ -349,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   }
   const int li = lane & 31, lh = lane >> 5;
   if (!DEEP) {
-    SERL_LOAD_CHUNK(0);
-    SERL_STORE_CHUNK(0);
+    SERL_LOAD_CHUNK(cb);
+    SERL_STORE_CHUNK(cb & 1);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = cb; c < nchunks; ++c) {
       const int buf = c & 1;
       SERL_LOAD_CHUNK(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
       SERL_COMPUTE_CHUNK(buf);
@@ -361,11 +371,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     }
   } else {
     // register set (c mod DEEP) holds chunk c+1 while chunk c is computed; its loads were issued DEEP iterations ago
-    SERL_LOAD_CHUNK(0);
-    SERL_STORE_CHUNK(0);
-    SERL_LOAD_CHUNK(1);
-    SERL_LOAD_CHUNK_(2, ra2, rb2, okmask2);
-    if (DEEP >= 3) SERL_LOAD_CHUNK_(3, ra3, rb3, okmask3);
+    SERL_LOAD_CHUNK(cb);
+    SERL_STORE_CHUNK(cb & 1);
+    SERL_LOAD_CHUNK(cb + 1);
+    SERL_LOAD_CHUNK_(cb + 2, ra2, rb2, okmask2);
+    if (DEEP >= 3) SERL_LOAD_CHUNK_(cb + 3, ra3, rb3, okmask3);
     __syncthreads();
 #define SERL_DEEP_STEP(C, RA, RB, OK)                    \
   {                                                      \
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     SERL_LOAD_CHUNK_((C) + 1 + DEEP, RA, RB, OK);        \
     __syncthreads();                                     \
   }
-    for (int c = 0; c < nchunks; c += DEEP) {
+    for (int c = cb; c < nchunks; c += DEEP) {
       SERL_DEEP_STEP(c, ra, rb, okmask);
       if (c + 1 < nchunks) SERL_DEEP_STEP(c + 1, ra2, rb2, okmask2);
       if (DEEP >= 3 && c + 2 < nchunks) SERL_DEEP_STEP(c + 2, ra3, rb3, okmask3);
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     for (int r = 0; r < 16; ++r) {
       const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m < a.M) {
-        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+        float* o = a.out + (size_t)split * ab.slab_stride + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
       }
@@ -1631,14 +1641,20 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   return SERL_OK;
 }
 
-__global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc) {
+// GroupNorm statistics of a raw conv output, one workgroup per (image, group).  S > 1: `x` holds S partial-sum slabs of a
+// K-split conv (slab stride `slab_stride` elements); they are added in slab order (deterministic), the total is written
+// to `out` and the statistics are those of the total.
+__global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc, int S, size_t slab_stride, float* out) {
   const int n = blockIdx.x / kGnGroups, g = blockIdx.x % kGnGroups;
   const int gs = Cc / kGnGroups;
-  const float* xb = x + (size_t)n * P * Cc + g * gs;
+  const size_t base = (size_t)n * P * Cc + g * gs;
   double s = 0.0, q = 0.0;
   for (int e = threadIdx.x; e < P * gs; e += 256) {
     const int p = e / gs, c = e - p * gs;
-    const float v = xb[(size_t)p * Cc + c];
+    const size_t at = base + (size_t)p * Cc + c;
+    float v = x[at];
+    for (int k = 1; k < S; ++k) v += x[at + (size_t)k * slab_stride];
+    if (S > 1) out[at] = v;
     s += v;
     q += (double)v * v;
   }
@@ -1841,7 +1857,8 @@ __global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, 
 
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr) {
+                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
+                             float* splitk_scratch = nullptr, size_t splitk_bytes = 0) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -1869,6 +1886,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   if (cfg == 2 && pmode == 1) pmode = 3;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  int ksplit = 1;
   {
     ProfScope prof(tag, stream);
 #define SERL_LAUNCH_CONV(WM, WN, TM, TN)                                                                               \
@@ -1933,6 +1951,24 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 3, 3>), grid, block, lds, stream, ab);
     } else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
       static const int deep = []() { const char* e = getenv("SERL_CONV_DEEP"); return e ? atoi(e) : 3; }();
+      // small M (one rank's share of a data-parallel batch): fewer than ~512 tiles whose K loops (up to 144 chunks) run at
+      // global-load latency.  SERL_CONV_KSPLIT=8 splits K over 2..8 workgroups per tile (>= 12 chunks each): partial sums go
+      // to slabs, the statistics kernel adds them.  OFF by default: at a per-rank batch of 32 it halves b3_conv1 (109 -> 55 us)
+      // and b3_conv0 (57 -> 37 us), but the statistics then need their own launch per conv (they ride in the conv epilogue
+      // otherwise) and the step got slower (0.733 -> 0.781 ms); neutral at 64 and 128.
+      static const int ks_max = []() { const char* e = getenv("SERL_CONV_KSPLIT"); return e ? atoi(e) : 0; }();
+      const long tiles = (long)a.tiles_m * a.tiles_n;
+      const int nch = ksz * ksz * (Cin >> 5);
+      int S = 1;
+      while (S * 2 <= ks_max && tiles * S * 2 <= 1024 && nch / (S * 2) >= 12 &&
+             (size_t)(S * 2) * a.M * Cout * sizeof(float) <= splitk_bytes) S *= 2;
+      if (S > 1 && splitk_scratch && pmode != 3) {
+        ksplit = S;
+        ab.ksplit = S; ab.slab_stride = (size_t)a.M * Cout;
+        a.out = splitk_scratch;
+        pmode = 3;            // no statistics in the conv: gn_stats_kernel_b below reduces the slabs and takes them
+        grid = dim3((unsigned)(tiles * S));
+      }
 #define SERL_LAUNCH_DEEP(D)                                                                                                      \
   do {                                                                                                                           \
     if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 0, D>), grid, block, lds, stream, ab);                \
@@ -1950,7 +1986,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {
-    hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
+    hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, ksplit > 1 ? splitk_scratch : out, stats, a.P,
+                       Cout, ksplit, (size_t)a.M * Cout, out);
     SERL_HIP(hipGetLastError());
   }
   return SERL_OK;
@@ -2027,7 +2064,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     FuseArgs fz0 = fuse_of(l0, 1);
     fz0.gn = gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f);
     fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0, ws.splitk, ws.splitk_bytes))) return rc;
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
     const long tot = (long)N * P * (f / 4);
@@ -2047,7 +2084,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     } else {
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1, ws.splitk, ws.splitk_bytes))) return rc;
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
       hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,
