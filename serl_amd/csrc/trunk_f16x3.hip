@@ -892,6 +892,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowslabPix = 340;   // (8 + 2) x 34 (Wo = 32); (16 + 2) x 18 = 324 (Wo = 16)
 constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (64 * 16 + 64);
+template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
@@ -925,26 +926,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
     }
   const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
   const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
-  u32x4 ra[AJ], rb[3];
+  u32x4 ra[AJ], rb[3], ra2[DEEP ? AJ : 1], rb2[DEEP ? 3 : 1];
 
 // fetch into registers: part PART of the slab of channel group CG (activations), the 3 taps of (channel group BG, row BKY)
-#define SERL_RS_LOAD_A(PART, CG)                                                                   \
+#define SERL_RS_LOAD_A(RA, PART, CG)                                                               \
   _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                   \
-    ra[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[PART][j] + ((CG) << 4));
-#define SERL_RS_LOAD_B(BG, BKY)                                                                    \
+    RA[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[PART][j] + ((CG) << 4));
+#define SERL_RS_LOAD_B(RB, BG, BKY)                                                                \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
-    rb[kx] = *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
-#define SERL_RS_STORE_A(PART, ABUF)                                                                \
+    RB[kx] = *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
+#define SERL_RS_STORE_A(RA, PART, ABUF)                                                            \
   _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                 \
     const int u_ = ((PART) * AJ + j) * 256 + tid;                                                  \
-    u32x4 v = ra[j];                                                                               \
+    u32x4 v = RA[j];                                                                               \
     if (!((okbits >> ((PART) * AJ + j)) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                        \
     if (u_ < kRowslabPix * 4)                                                                      \
       *reinterpret_cast<u32x4*>(smA + (ABUF) * A_BYTES + (u_ & 3) * A_REGION + (u_ >> 2) * 16) = v; \
   }
-#define SERL_RS_STORE_B(BBUF)                                                                      \
+#define SERL_RS_STORE_B(RB, BBUF)                                                                  \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
-    *reinterpret_cast<u32x4*>(smB + (BBUF) * B_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = rb[kx];
+    *reinterpret_cast<u32x4*>(smB + (BBUF) * B_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = RB[kx];
+// what is fetched while sub-chunk (CG, KY) computes: the weights of the NEXT sub-chunk and part KY of the NEXT slab (the
+// last slab re-fetches itself: harmless, keeps the loop uniform) -- and where it goes when that sub-chunk is done
+#define SERL_RS_LOADS(CG, KY, RA, RB)                                                              \
+  {                                                                                                \
+    const int ncg_ = (KY) == 2 ? (CG) + 1 : (CG), nky_ = (KY) == 2 ? 0 : (KY) + 1;                 \
+    const int ncgc_ = min(ncg_, c16n - 1), sn_ = min((CG) + 1, c16n - 1);                          \
+    SERL_RS_LOAD_B(RB, ncgc_, nky_);                                                               \
+    if ((KY) == 0) { SERL_RS_LOAD_A(RA, 0, sn_); } else if ((KY) == 1) { SERL_RS_LOAD_A(RA, 1, sn_); } else { SERL_RS_LOAD_A(RA, 2, sn_); } \
+  }
+#define SERL_RS_STORES(C, CG, KY, RA, RB)                                                          \
+  {                                                                                                \
+    SERL_RS_STORE_B(RB, ((C) + 1) & 1);                                                            \
+    if ((KY) == 0) { SERL_RS_STORE_A(RA, 0, ((CG) + 1) & 1); } else if ((KY) == 1) { SERL_RS_STORE_A(RA, 1, ((CG) + 1) & 1); } \
+    else { SERL_RS_STORE_A(RA, 2, ((CG) + 1) & 1); }                                               \
+  }
+#define SERL_RS_COMPUTE(C, CG, KY)                                                                 \
+  {                                                                                                \
+    const uint8_t* sa = smA + ((CG) & 1) * A_BYTES + (KY) * pw * 16;                               \
+    const uint8_t* sb = smB + ((C) & 1) * B_BYTES;                                                 \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                             \
+      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];                                                    \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                          \
+        ahi[tm] = *reinterpret_cast<const f16x8*>(sa + arow[tm] + kx * 16);                        \
+        alo[tm] = *reinterpret_cast<const f16x8*>(sa + A_REGION + arow[tm] + kx * 16);             \
+      }                                                                                            \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                          \
+        bhi[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + tn * 32 * 16);          \
+        blo[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + B_PLANE + tn * 32 * 16); \
+      }                                                                                            \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                            \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                        \
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0); \
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0); \
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0); \
+        }                                                                                          \
+    }                                                                                              \
+  }
 
   f32x16 acc[TM][TN], accx[TM][TN];
 #pragma unroll
@@ -964,55 +1002,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   }
   const int boff = lh * B_HALF + li * 16;
   // prologue: slab 0 (three parts) and the weights of sub-chunk 0
-  SERL_RS_LOAD_B(0, 0);
+  SERL_RS_LOAD_B(rb, 0, 0);
 #pragma unroll
   for (int part = 0; part < 3; ++part) {
-    SERL_RS_LOAD_A(part, 0);
-    SERL_RS_STORE_A(part, 0);
+    SERL_RS_LOAD_A(ra, part, 0);
+    SERL_RS_STORE_A(ra, part, 0);
   }
-  SERL_RS_STORE_B(0);
+  SERL_RS_STORE_B(rb, 0);
   __syncthreads();
   int cg = 0, ky = 0;   // channel group and kernel row of sub-chunk c
-  for (int c = 0; c < nchunks; ++c) {
-    // next sub-chunk's weights; part ky of the next slab (the last slab re-fetches itself: harmless, keeps the loop uniform)
-    const int ncg = ky == 2 ? cg + 1 : cg, nky = ky == 2 ? 0 : ky + 1;
-    const int ncg_c = min(ncg, c16n - 1), slab_next = min(cg + 1, c16n - 1);
-    SERL_RS_LOAD_B(ncg_c, nky);
-    if (ky == 0) { SERL_RS_LOAD_A(0, slab_next); } else if (ky == 1) { SERL_RS_LOAD_A(1, slab_next); } else { SERL_RS_LOAD_A(2, slab_next); }
-    const uint8_t* sa = smA + (cg & 1) * A_BYTES + ky * pw * 16;
-    const uint8_t* sb = smB + (c & 1) * B_BYTES;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        ahi[tm] = *reinterpret_cast<const f16x8*>(sa + arow[tm] + kx * 16);
-        alo[tm] = *reinterpret_cast<const f16x8*>(sa + A_REGION + arow[tm] + kx * 16);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        bhi[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + tn * 32 * 16);
-        blo[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + B_PLANE + tn * 32 * 16);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-        }
+  if (!DEEP) {
+    for (int c = 0; c < nchunks; ++c) {
+      SERL_RS_LOADS(cg, ky, ra, rb);
+      SERL_RS_COMPUTE(c, cg, ky);
+      // the other weight buffer was last read in sub-chunk c - 1, the other slab buffer during the previous channel group
+      SERL_RS_STORES(c, cg, ky, ra, rb);
+      __syncthreads();
+      if (++ky == 3) { ky = 0; ++cg; }
     }
-    // the other weight buffer was last read in sub-chunk c - 1, the other slab buffer during the previous channel group
-    SERL_RS_STORE_B((c + 1) & 1);
-    if (ky == 0) { SERL_RS_STORE_A(0, (cg + 1) & 1); } else if (ky == 1) { SERL_RS_STORE_A(1, (cg + 1) & 1); } else { SERL_RS_STORE_A(2, (cg + 1) & 1); }
-    __syncthreads();
-    cg = ncg; ky = nky;
+  } else {
+    // the fetches a sub-chunk's stores need are issued ONE SUB-CHUNK EARLIER, into the other register set: a sub-chunk is
+    // only 36 MFMAs per wave (~0.5 us), shorter than a loaded L2 / HBM round trip, so with one sub-chunk of distance the
+    // stores waited on their loads every time; two sets of 5 staging registers fit (242 VGPRs)
+    SERL_RS_LOADS(0, 0, ra, rb);
+    for (int c = 0; c < nchunks; c += 2) {   // nchunks is even (the launcher checks)
+      const int cg1 = ky == 2 ? cg + 1 : cg, ky1 = ky == 2 ? 0 : ky + 1;
+      SERL_RS_LOADS(cg1, ky1, ra2, rb2);
+      SERL_RS_COMPUTE(c, cg, ky);
+      SERL_RS_STORES(c, cg, ky, ra, rb);
+      __syncthreads();
+      const int cg2 = ky1 == 2 ? cg1 + 1 : cg1, ky2 = ky1 == 2 ? 0 : ky1 + 1;
+      SERL_RS_LOADS(cg2, ky2, ra, rb);
+      SERL_RS_COMPUTE(c + 1, cg1, ky1);
+      SERL_RS_STORES(c + 1, cg1, ky1, ra2, rb2);
+      __syncthreads();
+      cg = cg2; ky = ky2;
+    }
   }
 #undef SERL_RS_LOAD_A
 #undef SERL_RS_LOAD_B
 #undef SERL_RS_STORE_A
 #undef SERL_RS_STORE_B
+#undef SERL_RS_LOADS
+#undef SERL_RS_STORES
+#undef SERL_RS_COMPUTE
   rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
 }
 
@@ -1914,7 +1947,12 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
         ab.fz = *fuse; ab.fz.expected = a.P / 256; fused = true;
       }
       a.tiles_m = a.M / 256; a.tiles_n = slab ? Cout / 64 : 1;
-      if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      // SERL_CONV_ROWSLAB_DEEP=1: fetches issued two sub-chunks ahead (second staging register set); measured neutral
+      // (b0 convs 318 / 360 -> 312 / 355 us), so the simpler schedule stays the default
+      static const bool slab_deep = []() { const char* e = getenv("SERL_CONV_ROWSLAB_DEEP"); return e && e[0] == '1'; }();
+      if (slab && slab_deep && (3 * (Cin >> 4)) % 2 == 0)
+        hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      else if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       else hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowpatchLds, stream, ab);
     } else if (dma_ok) {
       static const int force_tn = []() { const char* e = getenv("SERL_CONV_DMA_TN"); return e ? atoi(e) : 0; }();
