@@ -1050,143 +1050,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA version of the row-slab kernel: the slab parts and the weights go L2 -> LDS by global_load_lds_dwordx4 (no staging
-// registers, no ds_write pass), issued between the MFMA groups of the current sub-chunk, counted in with s_waitcnt vmcnt(0)
-// + one raw s_barrier per sub-chunk (as in conv_dma_f16x3_kernel).  A piece = 64 lanes x 16 B written lane-linearly:
-// 64 consecutive pixels (or output channels) of one (plane, k-half) region, which is exactly the conflict-free fragment
-// layout -- no swizzle needed here.  Out-of-image pixels fetch from the zero page.  Per sub-chunk a wave issues 2 slab
-// pieces + 3 weight pieces.  Regions are 6 pieces (384 pixels >= 340) / 1 piece (64 output channels).
-// ---------------------------------------------------------------------------------------------
-constexpr int kSlabDmaLds = 2 * 4 * 6 * 1024 + 2 * 3 * 4 * 1024;
-__global__ __launch_bounds__(256, 2) void conv3x3_slabdma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
-  const ConvArgs& a = ab.c;
-  constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
-  constexpr int A_REGION = 6 * 1024, A_BYTES = 4 * A_REGION;     // region q = plane + 2 * k-half: [pixel][16 B]
-  constexpr int B_REGION = 1024, B_TAP = 4 * B_REGION, B_BYTES = 3 * B_TAP;   // per tap, region r = 2 * plane + k-half: [cout][16 B]
-  static_assert(2 * A_BYTES + 2 * B_BYTES == kSlabDmaLds, "LDS size of the launch");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  uint8_t* const smA = smemb;
-  uint8_t* const smB = smemb + 2 * A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
-  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
-  const int pw = a.Wo + 2, npix = (BM / a.Wo + 2) * pw;
-  const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
-  const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(a.in);
-  const uint8_t* zp = zero_page + (lane & 15) * 16;
-  // slab pieces of this wave: sub-chunk part p (= ky) carries pieces p*8 + wave*2 + {0, 1} of the 24 of a slab;
-  // piece idx -> region idx / 6, pixels (idx % 6) * 64 + lane
-  unsigned abase[3][2];     // byte offset of this lane's unit at channel group 0
-  unsigned aok = 0;         // bit p*2 + j: inside the image
-  int adst[3][2];           // LDS byte offset of the piece inside a slab buffer
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = p * 8 + wave * 2 + j, q = idx / 6, seg = idx - q * 6;
-      const int pix = seg * 64 + lane;
-      const int sy = pix / pw, sx = pix - sy * pw;
-      const int iy = oy0 - 1 + sy, ix = sx - 1;
-      const int iyc = min(max(iy, 0), a.Hi - 1), ixc = min(max(ix, 0), a.Wi - 1);
-      abase[p][j] = (unsigned)((((n_img * a.Hi + iyc) * a.Wi + ixc) * a.Cin + 4 * q) * 4);
-      if (pix < npix && iy == iyc && ix == ixc) aok |= 1u << (p * 2 + j);
-      adst[p][j] = q * A_REGION + seg * 1024;
-    }
-  // weight pieces of this wave: idx = wave*3 + j in [0, 12): tap kx = idx / 4, region r = idx % 4 (plane r >> 1, k-half r & 1)
-  const uint8_t* wsrc[3];
-  int bdst[3], bkx[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int idx = wave * 3 + j, kx = idx >> 2, r = idx & 3;
-    wsrc[j] = reinterpret_cast<const uint8_t*>((r >> 1) ? ab.wlo : ab.whi) + ((size_t)(n0 + lane) * ab.K + (r & 1) * 8) * 2;
-    bdst[j] = kx * B_TAP + r * B_REGION;
-    bkx[j] = kx;
-  }
-#define SERL_SD_A(P, J, CG, ABUF)                                                                              \
-  {                                                                                                            \
-    const uint8_t* src_ = ((aok >> ((P) * 2 + (J))) & 1u) ? in_bytes + abase[P][J] + ((CG) << 6) : zp;         \
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(smA + (ABUF) * A_BYTES + adst[P][J]), 16, 0, 0); \
-  }
-#define SERL_SD_B(J, BG, BKY, BBUF)                                                                            \
-  __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[J] + ((size_t)(((BKY) * 3 + bkx[J]) * a.Cin + ((BG) << 4))) * 2), \
-                                   (lds_void_t*)(smB + (BBUF) * B_BYTES + bdst[J]), 16, 0, 0);
-// piece PI (0..4) of what sub-chunk (C, CG, KY) fetches: weights of the next sub-chunk, part KY of the next slab
-#define SERL_SD_PIECE(PI, C, CG, KY)                                                                           \
-  {                                                                                                            \
-    const int ncg_ = (KY) == 2 ? (CG) + 1 : (CG), nky_ = (KY) == 2 ? 0 : (KY) + 1;                             \
-    const int ncgc_ = min(ncg_, c16n - 1), sn_ = min((CG) + 1, c16n - 1);                                      \
-    if ((PI) < 3) { SERL_SD_B((PI) < 3 ? (PI) : 0, ncgc_, nky_, ((C) + 1) & 1); }                              \
-    else if ((KY) == 0) { SERL_SD_A(0, (PI) == 3 ? 0 : 1, sn_, ((CG) + 1) & 1); }                              \
-    else if ((KY) == 1) { SERL_SD_A(1, (PI) == 3 ? 0 : 1, sn_, ((CG) + 1) & 1); }                              \
-    else { SERL_SD_A(2, (PI) == 3 ? 0 : 1, sn_, ((CG) + 1) & 1); }                                             \
-  }
-
-  f32x16 acc[TM][TN], accx[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
-  const int li = lane & 31, lh = lane >> 5;
-  int arow[TM];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int r = wave * WROWS + tm * 32 + li;
-    const int y = r / a.Wo, x = r - y * a.Wo;
-    arow[tm] = 2 * lh * A_REGION + (y * pw + x) * 16;
-  }
-  const int boff = lh * B_REGION + li * 16;
-  // prologue: the whole slab 0 and the weights of sub-chunk 0
-#pragma unroll
-  for (int j = 0; j < 3; ++j) SERL_SD_B(j, 0, 0, 0);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) { SERL_SD_A(p, 0, 0, 0); SERL_SD_A(p, 1, 0, 0); }
-  int cg = 0, ky = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");   // sub-chunk c's weights (and, at ky = 0, its slab) are in LDS; the buffers read in c - 1 are free
-    const uint8_t* sa = smA + (cg & 1) * A_BYTES + ky * pw * 16;
-    const uint8_t* sb = smB + (c & 1) * B_BYTES;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        ahi[tm] = *reinterpret_cast<const f16x8*>(sa + arow[tm] + kx * 16);
-        alo[tm] = *reinterpret_cast<const f16x8*>(sa + A_REGION + arow[tm] + kx * 16);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        bhi[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + tn * 32 * 16);
-        blo[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + 2 * B_REGION + tn * 32 * 16);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-          // the five DMA pieces of this sub-chunk ride behind MFMA groups 0, 2, 4, 6, 8 of its 12
-          const int g = (kx * TM + tm) * TN + tn;
-#pragma unroll
-          for (int pi = 0; pi < 5; ++pi)
-            if (g == 2 * pi) SERL_SD_PIECE(pi, c, cg, ky)
-        }
-    }
-    if (++ky == 3) { ky = 0; ++cg; }
-  }
-#undef SERL_SD_A
-#undef SERL_SD_B
-#undef SERL_SD_PIECE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
-}
-
-// ---------------------------------------------------------------------------------------------
 // conv_init in split-fp16: u8 image -> normalise -> conv 7x7 stride 2 pad 3, 3 -> 64.
 // K is re-indexed as k' = ky*24 + (kx*3 + c) (21 real taps per kernel row + 3 zero-weight pads, 7 rows
 // -> 168, padded to 176 = 11 MFMA k-steps) so that every 8-wide MFMA k-block is a contiguous run of
@@ -2086,12 +1949,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       a.tiles_m = a.M / 256; a.tiles_n = slab ? Cout / 64 : 1;
       // SERL_CONV_ROWSLAB_DEEP=1: fetches issued two sub-chunks ahead (second staging register set); measured neutral
       // (b0 convs 318 / 360 -> 312 / 355 us), so the simpler schedule stays the default
-      // SERL_CONV_SLABDMA=0: register-staged row-slab kernel instead of its LDS-DMA version
-      static const bool slab_dma = []() { const char* e = getenv("SERL_CONV_SLABDMA"); return !(e && e[0] == '0'); }();
       static const bool slab_deep = []() { const char* e = getenv("SERL_CONV_ROWSLAB_DEEP"); return e && e[0] == '1'; }();
-      if (slab && slab_dma && zero_page != nullptr && (long)N * Hi * Wi * Cin * 4 < (1L << 32))
-        hipLaunchKernelGGL(conv3x3_slabdma_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kSlabDmaLds, stream, ab, zero_page);
-      else if (slab && slab_deep && (3 * (Cin >> 4)) % 2 == 0)
+      if (slab && slab_deep && (3 * (Cin >> 4)) % 2 == 0)
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       else if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       else hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowpatchLds, stream, ab);
