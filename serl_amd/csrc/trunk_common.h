@@ -87,9 +87,12 @@ struct PackedConvWeights {
   const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous) of w * s_n
   const uint16_t* lo;  // fp16 [Cout][K]  (w * s_n - float(hi)) * 2^11
   const float* inv;    // [Cout] 1 / s_n
+  const uint16_t* slab = nullptr;  // optional copy in the row-slab kernel's fetch order (pack_slab_order_f16x3)
 };
 // w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K], inv [Cout]
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream);
+// hi / lo' planes [Cout][9*Cin] -> [Cout/64][Cin/16][9 taps][plane][64 cout][2 k-halves][8] (4 KB per (tile, group, tap))
+int pack_slab_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* slab, int Cin, int Cout, hipStream_t stream);
 // whole trunk in split-fp16 arithmetic (trunk_f16x3.hip)
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
                         float* feats_out, hipStream_t stream, int stage_begin = -1, int stage_end = kTrunkStages - 1);

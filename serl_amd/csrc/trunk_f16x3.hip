@@ -53,6 +53,7 @@ struct ConvArgsB {
   const uint16_t* whi;  // [Cout][K]
   const uint16_t* wlo;
   const float* winv;    // [Cout] 1 / (per-output-channel weight scale)
+  const uint16_t* wslab; // row-slab kernel: the planes in its fetch order (pack_slab_order_f16x3) or nullptr
   int K;
   int ksplit;           // register-staged kernel only: K-split factor (1 = off)
   size_t slab_stride;   // elements between the partial-sum slabs of a K-split launch
@@ -926,6 +927,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
     }
   const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
   const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
+  // fetch-order copy: block (column tile bn, group, tap) of 2048 halfs, this thread's unit at tid * 8
+  const uint16_t* wslab = ab.wslab ? ab.wslab + ((size_t)bn * c16n * 9 << 11) + tid * 8 : nullptr;
   u32x4 ra[AJ], rb[3], ra2[DEEP ? AJ : 1], rb2[DEEP ? 3 : 1];
 
 // fetch into registers: part PART of the slab of channel group CG (activations), the 3 taps of (channel group BG, row BKY)
@@ -934,7 +937,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
     RA[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[PART][j] + ((CG) << 4));
 #define SERL_RS_LOAD_B(RB, BG, BKY)                                                                \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
-    RB[kx] = *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
+    RB[kx] = wslab ? *reinterpret_cast<const u32x4*>(wslab + ((size_t)(((BG) * 3 + (BKY)) * 3 + kx) << 11)) \
+                   : *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
 #define SERL_RS_STORE_A(RA, PART, ABUF)                                                            \
   _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                 \
     const int u_ = ((PART) * AJ + j) * 256 + tid;                                                  \
@@ -1725,6 +1729,31 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, uint1
   }
 }
 
+// Second copy of the packed planes of a 3x3 conv in the order the row-slab kernel fetches them: per (64-channel column
+// tile, group of 16 input channels, tap) one contiguous 4 KB block [plane][cout][k-half][8 halfs], which thread t of the
+// 256 reads as 16 bytes at t * 16 -- fully coalesced, where the [Cout][K] planes give every pair of lanes its own row.
+__global__ __launch_bounds__(256) void pack_slab_order_kernel(const uint16_t* hi, const uint16_t* lo, uint16_t* slab, int Cin, int Cout) {
+  const int K = 9 * Cin, c16n = Cin >> 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 16-byte unit
+  if (e >= (long)2 * Cout * K / 8) return;
+  const int t = (int)(e & 255);
+  long blk = e >> 8;
+  const int tap = (int)(blk % 9); blk /= 9;
+  const int cg = (int)(blk % c16n);
+  const int nt = (int)(blk / c16n);
+  const int plane = t >> 7, cout = (t >> 1) & 63, half = t & 1;
+  const uint16_t* src = (plane ? lo : hi) + (size_t)(nt * 64 + cout) * K + tap * Cin + cg * 16 + half * 8;
+  reinterpret_cast<uint4*>(slab)[e] = *reinterpret_cast<const uint4*>(src);
+}
+
+int pack_slab_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* slab, int Cin, int Cout, hipStream_t stream) {
+  SERL_REQUIRE(Cin % 16 == 0 && Cout % 64 == 0, "slab order needs Cin %% 16 == 0 and Cout %% 64 == 0");
+  const long units = (long)2 * Cout * 9 * Cin / 8;
+  hipLaunchKernelGGL(pack_slab_order_kernel, dim3(cdiv(units, 256)), dim3(256), 0, stream, hi, lo, slab, Cin, Cout);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream) {
   hipLaunchKernelGGL(pack_weights_kernel, dim3(Cout), dim3(256), 0, stream, w, hi, lo, inv, K, Cout);
   SERL_HIP(hipGetLastError());
@@ -1904,6 +1933,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
   ab.whi = w.hi; ab.wlo = w.lo; ab.winv = w.inv; ab.K = ksz * ksz * Cin;
+  static const bool slab_w = []() { const char* e = getenv("SERL_CONV_SLAB_WEIGHTS"); return !(e && e[0] == '0'); }();
+  ab.wslab = slab_w ? w.slab : nullptr;
   static const int conv_dbg = []() { const char* e = getenv("SERL_CONV_DBG"); return e ? atoi(e) : 0; }();
   ab.dbg = conv_dbg;
   int cfg = Cout >= 128 ? 0 : 1;
@@ -2096,7 +2127,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
-    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv}; };
+    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv, pk.blk[i][which].slab}; };
     // GroupNorm + ReLU (+ residual) + split8 in the conv epilogue where the kernel for this shape supports it
     // (fz.mode comes back 0 otherwise and the elementwise pass below runs instead)
     FuseArgs fz0 = fuse_of(l0, 1);
