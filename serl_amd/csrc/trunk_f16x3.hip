@@ -54,6 +54,7 @@ struct ConvArgsB {
   const uint16_t* wlo;
   const float* winv;    // [Cout] 1 / (per-output-channel weight scale)
   const uint16_t* wslab; // row-slab kernel: the planes in its fetch order (pack_slab_order_f16x3) or nullptr
+  const uint16_t* wdma;  // LDS-DMA kernel: the planes in its piece order (pack_dma_order_f16x3) or nullptr
   int K;
   int ksplit;           // register-staged kernel only: K-split factor (1 = off)
   size_t slab_stride;   // elements between the partial-sum slabs of a K-split launch
@@ -508,8 +509,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     const int pb = q * 4 + wave, plane = pb / (BN / 16), prow = (pb % (BN / 16)) * 16 + (lane >> 2);
     const int su = (lane & 3) ^ ((prow >> 2) & 3);
     wsrc[q] = reinterpret_cast<const uint8_t*>(plane ? ab.wlo : ab.whi) + ((size_t)(n0 + prow) * ab.K) * 2 + su * 16;
+    if (ab.wdma)   // piece-order copy: block (row block, chunk, plane) of 4 KB, this lane at (row % 64) * 64 + (lane & 3) * 16
+      wsrc[q] = reinterpret_cast<const uint8_t*>(ab.wdma) +
+                ((size_t)((n0 + prow) >> 6) * (a.KH * a.KW * (a.Cin >> 5)) * 2 + plane) * 4096 + ((prow & 63) << 6) + ((lane & 3) << 4);
   }
   const int nchunks = a.KH * a.KW * (a.Cin >> 5);
+  const size_t wchunk_stride = ab.wdma ? 8192 : 64;   // bytes between consecutive K chunks of a weight piece's source
   int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_chunk = 0;   // counters of the next chunk to latch (strictly in order)
   const uint8_t* zp = zero_page + (lane & 7) * 16;
 
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     } else {                                                                                                   \
       const int q = (PI) >= A_PIECES ? (PI) - A_PIECES : 0;                                                    \
       const int pb = q * 4 + wave, plane = pb / (BN / 16), prow0 = (pb % (BN / 16)) * 16;                      \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[q] + (size_t)nx_chunk * 64),                         \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[q] + (size_t)nx_chunk * wchunk_stride),                         \
                                        (lds_void_t*)(st_ + A_BYTES + plane * B_PLANE + prow0 * 64), 16, 0, 0); \
     }                                                                                                          \
   }
@@ -1746,6 +1751,30 @@ __global__ __launch_bounds__(256) void pack_slab_order_kernel(const uint16_t* hi
   reinterpret_cast<uint4*>(slab)[e] = *reinterpret_cast<const uint4*>(src);
 }
 
+// Copy of the packed planes in the LDS-DMA kernel's piece order: per (64-row block, 32-wide K chunk, plane) one contiguous
+// 4 KB block [row][slot], slot s of row r holding the 16-byte unit s ^ ((r >> 2) & 3) -- the swizzle the kernel applies on
+// the source side -- so that lane l of a 16-row piece reads 16 bytes at l * 16.
+__global__ __launch_bounds__(256) void pack_dma_order_kernel(const uint16_t* hi, const uint16_t* lo, uint16_t* dma, int K, int Cout) {
+  const int nch = K >> 5;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 16-byte unit
+  if (e >= (long)2 * Cout * K / 8) return;
+  const int t = (int)(e & 255), r64 = t >> 2, slot = t & 3;
+  long blk = e >> 8;
+  const int plane = (int)(blk & 1); blk >>= 1;
+  const int chunk = (int)(blk % nch);
+  const int j = (int)(blk / nch);
+  const uint16_t* src = (plane ? lo : hi) + (size_t)(j * 64 + r64) * K + chunk * 32 + ((slot ^ ((r64 >> 2) & 3)) << 3);
+  reinterpret_cast<uint4*>(dma)[e] = *reinterpret_cast<const uint4*>(src);
+}
+
+int pack_dma_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* dma, int K, int Cout, hipStream_t stream) {
+  SERL_REQUIRE(K % 32 == 0 && Cout % 64 == 0, "DMA order needs K %% 32 == 0 and Cout %% 64 == 0");
+  const long units = (long)2 * Cout * K / 8;
+  hipLaunchKernelGGL(pack_dma_order_kernel, dim3(cdiv(units, 256)), dim3(256), 0, stream, hi, lo, dma, K, Cout);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
 int pack_slab_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* slab, int Cin, int Cout, hipStream_t stream) {
   SERL_REQUIRE(Cin % 16 == 0 && Cout % 64 == 0, "slab order needs Cin %% 16 == 0 and Cout %% 64 == 0");
   const long units = (long)2 * Cout * 9 * Cin / 8;
@@ -1935,6 +1964,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   ab.whi = w.hi; ab.wlo = w.lo; ab.winv = w.inv; ab.K = ksz * ksz * Cin;
   static const bool slab_w = []() { const char* e = getenv("SERL_CONV_SLAB_WEIGHTS"); return !(e && e[0] == '0'); }();
   ab.wslab = slab_w ? w.slab : nullptr;
+  static const bool dma_w = []() { const char* e = getenv("SERL_CONV_DMA_WEIGHTS"); return !(e && e[0] == '0'); }();
+  ab.wdma = dma_w ? w.dma : nullptr;
   static const int conv_dbg = []() { const char* e = getenv("SERL_CONV_DBG"); return e ? atoi(e) : 0; }();
   ab.dbg = conv_dbg;
   int cfg = Cout >= 128 ? 0 : 1;
@@ -2127,7 +2158,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
-    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv, pk.blk[i][which].slab}; };
+    auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv, pk.blk[i][which].slab, pk.blk[i][which].dma}; };
     // GroupNorm + ReLU (+ residual) + split8 in the conv epilogue where the kernel for this shape supports it
     // (fz.mode comes back 0 otherwise and the elementwise pass below runs instead)
     FuseArgs fz0 = fuse_of(l0, 1);
