@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
-      const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (min(c_, nchunks - 1) << 5) + s_ * 8; \
+      const int cc_ = min(c_, nchunks - 1);                                                                    \
+      /* piece-order copy (pack_dma_order_f16x3): slot s_ of row r_ already holds the unit that belongs at LDS slot s_ */ \
+      const uint16_t* wp_ = ab.wdma ? ab.wdma + ((((size_t)((n0 + r_) >> 6) * nchunks_all + cc_) * 2 + plane_) << 11) + ((r_ & 63) << 5) + s_ * 8 \
+                                    : (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (cc_ << 5) + s_ * 8;      \
       RB[i] = *reinterpret_cast<const u32x4*>(wp_);                                                            \
     }                                                                                                          \
     }                                                                                                          \
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
-      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = RB[i];                   \
+      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + (ab.wdma ? r_ * 64 + s_ * 16 : swz(r_, s_))) = RB[i]; \
     }                                                                                                          \
     }                                                                                                          \
   }
