@@ -171,6 +171,8 @@ typedef struct serl_agent_cfg {
    * (32,64,128,256), 3x3 stride-2 VALID convs + ReLU, average pool, Dense(256)+LayerNorm+tanh), gradients of the
    * critic loss flow into its conv kernels */
   int encoder_type;
+  int critic_subsample_size; /* sac.py:150-161: 0 = 2 (utils/launcher.py), -1 = None (minimum over all members), else 1..16 */
+  int backup_entropy;        /* sac.py:174-176: target_q -= alpha * log pi(a'|s') */
 } serl_agent_cfg;
 #define SERL_ENCODER_RESNET_PRETRAINED 0
 #define SERL_ENCODER_SMALL 1
@@ -198,7 +200,7 @@ int64_t serl_agent_get_step(serl_agent* a);
 /* Explicit randomness (parity mode).  All pointers are DEVICE addresses; NULL members (or a NULL
  * struct) are generated on the device from cfg.seed.  Shapes use the batch of the call:
  *   eps_*  f32[batch][act_dim];  mask_* u8[n_cam][batch][512*sle_features] keep-masks (1 = keep)
- * redq_idx is a HOST pointer: int32[utd_ratio][2] (sac.py:150-157). */
+ * redq_idx is a HOST pointer: int32[utd_ratio][critic_subsample_size] (sac.py:150-157; unused when the size is None). */
 typedef struct serl_noise {
   const float* eps_next;          /* critic loss: policy sample at next_obs (sac.py:118-132) */
   const uint8_t* mask_next;       /* Dropout(0.1) masks of that policy forward */

@@ -135,8 +135,10 @@ def _parse_noise(cfg, B, recs, kind, utd, nets=()):
 
     def critic_draws(rows):      # critic_loss_fn: policy forward at next_obs (dropout), sample, REDQ subsample
         m, e = masks(rows), eps(rows)
+        if cfg.subsample is None:        # sac.py:150: no subsampling, no draw
+            return m, e, np.zeros((0,), np.int32)
         (r,) = t.take("randint")
-        assert r["value"].shape == (2,) and r["maxval"] == cfg.ensemble
+        assert r["value"].shape == (cfg.subsample,) and r["maxval"] == cfg.ensemble
         return m, e, r["value"].astype(np.int32)
 
     if kind == "update":         # ONE apply_loss_fns: loss functions run in sorted-key order actor, critic, temperature
@@ -180,6 +182,9 @@ def _make_reference_agent(jax, jnp, cfg, trunk):
     from serl_launcher.utils.launcher import make_drq_agent, make_sac_agent
     st = O.TrainState(cfg, {}, {}, None) if False else None
     extra = {}
+    if cfg.subsample != 2 or cfg.backup_entropy:   # not arguments of the launcher factories either
+        extra["critic_subsample_size"] = cfg.subsample
+        extra["backup_entropy"] = bool(cfg.backup_entropy)
     if cfg.opt or cfg.state_only:
         tmp = O.TrainState.__new__(O.TrainState)
         tmp.cfg = cfg

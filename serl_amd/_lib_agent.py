@@ -17,6 +17,8 @@ class SerlAgentCfg(C.Structure):
         ("tx_lr", C.c_float * 3), ("tx_warmup", C.c_int * 3), ("tx_cosine_steps", C.c_int * 3),
         ("tx_weight_decay_on", C.c_int * 3), ("tx_weight_decay", C.c_float * 3), ("tx_clip_norm", C.c_float * 3),
         ("encoder_type", C.c_int),   # 0 = resnet-pretrained (frozen trunk), 1 = small (trainable SmallEncoder)
+        ("critic_subsample_size", C.c_int),   # 0 = 2, -1 = None (all members), else 1..16
+        ("backup_entropy", C.c_int),
     ]
 
 

@@ -18,7 +18,8 @@ class AgentCore:
     def __init__(self, *, device=0, n_cam, H, W, state_dim, act_dim, batch, ensemble=10, hidden=256,
                  bottleneck=256, sle_features=8, proprio_dim=64, warmup_steps=0, discount=0.96,
                  tau=0.005, lr=3e-4, dropout=0.1, std_min=1e-5, std_max=5.0, target_entropy=None,
-                 seed=0, temp_warmup_steps=-1, optimizers=None, encoder_type="resnet-pretrained"):
+                 seed=0, temp_warmup_steps=-1, optimizers=None, encoder_type="resnet-pretrained",
+                 critic_subsample_size=2, backup_entropy=False):
         """optimizers: optional {"actor"|"critic"|"temperature": make_optimizer kwargs (common/optimizers.py:6-13:
         learning_rate, warmup_steps, cosine_decay_steps, weight_decay, clip_grad_norm)} overriding lr / warmup_steps."""
         if target_entropy is None:
@@ -27,6 +28,11 @@ class AgentCore:
                                 bottleneck, sle_features, proprio_dim, warmup_steps, temp_warmup_steps, discount, tau,
                                 lr, dropout, std_min, std_max, target_entropy, seed)
         self.cfg.encoder_type = {"resnet-pretrained": 0, "small": 1}[encoder_type]
+        # sac.py:150-161: None = the minimum runs over the whole target ensemble
+        if critic_subsample_size is not None and not (1 <= int(critic_subsample_size) <= 16):
+            raise ValueError(f"critic_subsample_size must be None or in [1, 16] (got {critic_subsample_size})")
+        self.cfg.critic_subsample_size = -1 if critic_subsample_size is None else int(critic_subsample_size)
+        self.cfg.backup_entropy = 1 if backup_entropy else 0
         for name, kw in (optimizers or {}).items():
             i = TX_INDEX[name]
             bad = set(kw) - {"learning_rate", "warmup_steps", "cosine_decay_steps", "weight_decay", "clip_grad_norm"}

@@ -169,8 +169,8 @@ class DrQAgent:
         if encoder_type not in ("resnet-pretrained", "small"):
             # drq.py:155-167 also has "resnet" (trainable ResNet-10, never selected by an example: not built)
             raise NotImplementedError(f"Unknown encoder type: {encoder_type}")
-        if not use_proprio or backup_entropy or critic_subsample_size != 2:
-            raise NotImplementedError("only use_proprio=True, backup_entropy=False, critic_subsample_size=2")
+        if not use_proprio:
+            raise NotImplementedError("only use_proprio=True")
         pk = policy_kwargs or {}
         if pk.get("std_parameterization", "exp") != "exp" or not pk.get("tanh_squash_distribution", True):
             raise NotImplementedError("policy must be tanh-squashed with std_parameterization='exp'")
@@ -193,7 +193,8 @@ class DrQAgent:
                          batch=batch_size, ensemble=critic_ensemble_size, discount=discount,
                          tau=soft_target_update_rate, lr=learning_rate, std_min=pk.get("std_min", 1e-5),
                          std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed,
-                         optimizers={k: {"warmup_steps": 0, **v} for k, v in opts.items()}, encoder_type=encoder_type)
+                         optimizers={k: {"warmup_steps": 0, **v} for k, v in opts.items()}, encoder_type=encoder_type,
+                         critic_subsample_size=critic_subsample_size, backup_entropy=backup_entropy)
         theta = pinit.init_theta(len(image_keys), H, W, S, A, seed=seed, temperature_init=temperature_init,
                                  ensemble=critic_ensemble_size, encoder_type=encoder_type)
         trunk = pinit.init_trunk(seed=seed) if encoder_type == "resnet-pretrained" else {}

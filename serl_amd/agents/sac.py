@@ -31,8 +31,6 @@ class SACAgent(DrQAgent):
                       temperature_optimizer_kwargs: dict = None, batch_size: int = 256, device: int = 0, **kwargs):
         """sac.py:486-542 -> create (:323-400).  Built natively: the configuration of utils/launcher.py:50-76
         (REDQ subsample 2, tanh-squashed exp-parameterised policy, LayerNorm+tanh 256x256 MLPs)."""
-        if backup_entropy or critic_subsample_size != 2:
-            raise NotImplementedError("only backup_entropy=False, critic_subsample_size=2")
         pk = policy_kwargs or {}
         if pk.get("std_parameterization", "exp") != "exp" or not pk.get("tanh_squash_distribution", True):
             raise NotImplementedError("policy must be tanh-squashed with std_parameterization='exp'")
@@ -52,7 +50,8 @@ class SACAgent(DrQAgent):
                          lr=ao["learning_rate"], warmup_steps=int(ao["warmup_steps"]),
                          temp_warmup_steps=int(to.get("warmup_steps", 0)), std_min=pk.get("std_min", 1e-5),
                          std_max=pk.get("std_max", 10.0), target_entropy=target_entropy, seed=seed,
-                         optimizers={"actor": ao, "critic": co, "temperature": {"warmup_steps": 0, **to}})
+                         optimizers={"actor": ao, "critic": co, "temperature": {"warmup_steps": 0, **to}},
+                         critic_subsample_size=critic_subsample_size, backup_entropy=backup_entropy)
         theta = pinit.init_theta(0, 0, 0, S, A, seed=seed, temperature_init=temperature_init, ensemble=critic_ensemble_size)
         for sec in ("params", "target_params"):
             core.load_flat(sec, theta)

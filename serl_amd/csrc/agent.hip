@@ -958,17 +958,23 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
   const Offs& o = a->o;
   hipStream_t st = (hipStream_t)stream;
   SERL_HIP(hipSetDevice(c.device));
-  int i0, i1;
+  // REDQ subsample (sac.py:150-157): critic_subsample_size members drawn with replacement; cfg 0 = the launcher's 2,
+  // -1 = None (the minimum runs over the whole ensemble and nothing is drawn)
+  const int m_sub = c.critic_subsample_size == 0 ? 2 : (c.critic_subsample_size < 0 ? 0 : c.critic_subsample_size);
+  SERL_REQUIRE(m_sub <= 16, "critic_subsample_size %d exceeds 16", m_sub);
+  RedqSel sel{};
+  sel.n = m_sub;
   if (noise && noise->redq_idx) {
-    i0 = noise->redq_idx[2 * redq_row];
-    i1 = noise->redq_idx[2 * redq_row + 1];
-  } else {  // sac.py:150-157 randint(0, ensemble) x2, with replacement
+    for (int k = 0; k < m_sub; ++k) sel.idx[k] = noise->redq_idx[m_sub * redq_row + k];
+  } else {  // randint(0, ensemble) with replacement
     uint64_t r = c.seed * 0x9E3779B97F4A7C15ull + (++a->noise_ctr) * 0xBF58476D1CE4E5B9ull;
-    r ^= r >> 29; r *= 0x94D049BB133111EBull; r ^= r >> 32;
-    i0 = (int)(r % c.ensemble);
-    i1 = (int)((r >> 32) % c.ensemble);
+    for (int k = 0; k < m_sub; ++k) {
+      r ^= r >> 29; r *= 0x94D049BB133111EBull; r ^= r >> 32;
+      sel.idx[k] = (int)(r % c.ensemble);
+      r += 0x9E3779B97F4A7C15ull;
+    }
   }
-  SERL_REQUIRE(i0 >= 0 && i0 < c.ensemble && i1 >= 0 && i1 < c.ensemble, "REDQ index out of range");
+  for (int k = 0; k < m_sub; ++k) SERL_REQUIRE(sel.idx[k] >= 0 && sel.idx[k] < c.ensemble, "REDQ index out of range");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = cnt <= kPgDeferMaxRows;
   const float* eps; const uint8_t* mask;
@@ -983,13 +989,16 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
                         {a->theta_t, 1, nullptr, &a->encT, nullptr, nullptr},
                         {a->theta, 0, nullptr, &a->encO, a->cur.action + (long)off * A, a->crit.x + a->E}};
   RC(encode_multi(a, ej, 3, off, cnt, st));
-  const PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr, nullptr};
+  // backup_entropy (sac.py:174-176) needs alpha = softplus(lagrange) of the online parameters next to the per-sample log-probs
+  const PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, eps + (long)off * A, a->critT.x + a->E, a->XA, nullptr,
+                  c.backup_entropy ? a->aux + X_ALPHA : nullptr};
   RC(policy_fwd_multi(a, &pj, 1, cnt, st));
   const CritJob cj[2] = {{a->theta_t, &a->critT}, {a->theta, &a->crit}};  // target and online ensembles together
   RC(critic_fwd_multi(a, cj, 2, cnt, st));
   const float inv_norm = 1.0f / ((float)c.ensemble * (float)global_count);
-  RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, i0, i1, c.ensemble, cnt, c.discount,
-                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st, a->state_only));
+  RC(critic_loss(a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, sel, c.ensemble, cnt, c.discount,
+                 inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st, a->state_only,
+                 c.backup_entropy ? a->pol.logp : nullptr, c.backup_entropy ? a->aux + X_ALPHA : nullptr));
   RC(critic_bwd(a, a->theta, a->crit, cnt, true, st, a->dq, 0.f));
   if (!a->state_only) {
     RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,

@@ -61,10 +61,13 @@ int sle_fwd_multi(const SleFwdArgs* v, int n, float keep_scale, int N, int HW, i
                   long mask_gs, long f_gs, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
             long x_gs, long df_gs, long part_gs, hipStream_t stream);
-// dbias: gradient of the head bias -- one scalar (shared head) or, with per_member_bias, one per ensemble member
-int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
+// dbias: gradient of the head bias -- one scalar (shared head) or, with per_member_bias, one per ensemble member.
+// sel: the target ensemble members whose minimum backs up (sac.py:150-161: critic_subsample_size random members, n = 0: all).
+// logp_next / alpha != nullptr: backup_entropy (sac.py:174-176): y -= alpha[0] * logp_next[b]
+struct RedqSel { int n; int idx[16]; };
+int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, RedqSel sel, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
-                hipStream_t stream, bool per_member_bias = false);
+                hipStream_t stream, bool per_member_bias = false, const float* logp_next = nullptr, const float* alpha = nullptr);
 // tanh-Gaussian policy head: slabs = raw head GEMM outputs (mean, log_std); biases added here, result kept in `pre`
 struct PolicyDistArgs {
   const float* slabs; int S;  // head GEMM output [mean | log_std][S K-splits][B][A]

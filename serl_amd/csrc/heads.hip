@@ -551,16 +551,26 @@ int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int 
 //   dhead_b = sum dQ  (gradient of the shared head bias)
 // =============================================================================================
 __global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const float* q, const float* reward,
-                                                         const float* mask, int i0, int i1, int E, int B,
+                                                         const float* mask, RedqSel sel, int E, int B,
                                                          float discount, float inv_norm, float* y_out,
-                                                         float* dq, float* scalars, float* dbias, int per_member) {
+                                                         float* dq, float* scalars, float* dbias, int per_member,
+                                                         const float* logp_next, const float* alpha) {
   __shared__ float red[4][256];
   float s_d2 = 0.f, s_q = 0.f, s_y = 0.f, s_dq = 0.f;
   float s_e[16];  // per-member sums of dQ (per_member: E <= 16)
 #pragma unroll
   for (int e = 0; e < 16; ++e) s_e[e] = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
-    const float y = reward[b] + discount * mask[b] * fminf(qt[(long)i0 * B + b], qt[(long)i1 * B + b]);
+    float mq;   // minimum over the selected (or all) target members (sac.py:150-161)
+    if (sel.n > 0) {
+      mq = qt[(long)sel.idx[0] * B + b];
+      for (int k = 1; k < sel.n; ++k) mq = fminf(mq, qt[(long)sel.idx[k] * B + b]);
+    } else {
+      mq = qt[b];
+      for (int e = 1; e < E; ++e) mq = fminf(mq, qt[(long)e * B + b]);
+    }
+    float y = reward[b] + discount * mask[b] * mq;
+    if (logp_next) y -= alpha[0] * logp_next[b];   // backup_entropy: outside the discount, as sac.py:174-176 has it
     y_out[b] = y;
     s_y += y;
     for (int e = 0; e < E; ++e) {
@@ -606,12 +616,13 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const
   }
 }
 
-int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, int i0, int i1, int E,
+int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, RedqSel sel, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
-                hipStream_t stream, bool per_member_bias) {
+                hipStream_t stream, bool per_member_bias, const float* logp_next, const float* alpha) {
   SERL_REQUIRE(!per_member_bias || E <= 16, "per-member head bias supports ensembles of at most 16 (got %d)", E);
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, stream, qt, q, reward, mask, i0, i1, E, B,
-                     discount, inv_norm, y_out, dq, scalars, dbias, per_member_bias ? 1 : 0);
+  SERL_REQUIRE(sel.n >= 0 && sel.n <= 16, "critic_subsample_size %d not in [0, 16]", sel.n);
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, stream, qt, q, reward, mask, sel, E, B,
+                     discount, inv_norm, y_out, dq, scalars, dbias, per_member_bias ? 1 : 0, logp_next, alpha);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -12,24 +12,26 @@ def make_drq_agent(seed, sample_obs, sample_action, image_keys=("image",), encod
                    discount=0.96, batch_size=256, device=0, **create_kwargs):
     """launcher.py:79-116 (hyper-parameters copied from there).  `create_kwargs` (e.g. critic_optimizer_kwargs) are
     passed on to DrQAgent.create_drq, whose signature has them in the reference too (drq.py:34-43)."""
+    kw = dict(backup_entropy=False, critic_ensemble_size=10, critic_subsample_size=2)   # launcher.py:111-114
+    kw.update(create_kwargs)
     return DrQAgent.create_drq(
         seed, sample_obs, sample_action, encoder_type=encoder_type, use_proprio=True, image_keys=image_keys,
         policy_kwargs={"tanh_squash_distribution": True, "std_parameterization": "exp", "std_min": 1e-5, "std_max": 5},
         critic_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
         policy_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
-        temperature_init=1e-2, discount=discount, backup_entropy=False, critic_ensemble_size=10,
-        critic_subsample_size=2, batch_size=batch_size, device=device, **create_kwargs)
+        temperature_init=1e-2, discount=discount, batch_size=batch_size, device=device, **kw)
 
 
 def make_sac_agent(seed, sample_obs, sample_action, discount=0.99, batch_size=256, device=0, **create_kwargs):
     """launcher.py:50-76 (hyper-parameters copied from there; optimizer defaults from sac.py:333-343)."""
+    kw = dict(backup_entropy=False, critic_ensemble_size=10, critic_subsample_size=2)   # launcher.py:70-73
+    kw.update(create_kwargs)
     return SACAgent.create_states(
         seed, sample_obs, sample_action,
         policy_kwargs={"tanh_squash_distribution": True, "std_parameterization": "exp", "std_min": 1e-5, "std_max": 5},
         critic_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
         policy_network_kwargs={"activations": "tanh", "use_layer_norm": True, "hidden_dims": [256, 256]},
-        temperature_init=1e-2, discount=discount, backup_entropy=False, critic_ensemble_size=10,
-        critic_subsample_size=2, batch_size=batch_size, device=device, **create_kwargs)
+        temperature_init=1e-2, discount=discount, batch_size=batch_size, device=device, **kw)
 
 
 def make_replay_buffer(env, capacity: int = 1000000, rlds_logger_path: Optional[str] = None,

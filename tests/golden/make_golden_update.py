@@ -49,12 +49,21 @@ CASES = {
                                       "critic": {"weight_decay": 0.003, "warmup_steps": 0, "clip_grad_norm": 1.0},
                                       "temperature": {"cosine_decay_steps": 5}}), 8,
                         [("high_utd", 2), ("update", ("actor", "critic", "temperature")), ("high_utd", 1), ("update", ("critic",))]),
+    # create_drq / create_states options the launcher factories fix (sac.py:150-161,174-176): no REDQ subsampling (minimum
+    # over all ten target members) with the entropy backup; a subsample of three
+    "drq_backup_entropy_all": (O.Config(image_keys=("front",), H=64, W=64, S=5, A=3, subsample=None, backup_entropy=True), 6,
+                               [("critics",), ("high_utd", 2), ("update", ("actor", "critic", "temperature"))]),
+    "sac_state_subsample3": (O.Config(image_keys=(), S=10, A=4, discount=0.99, subsample=3, backup_entropy=True), 8,
+                             [("high_utd", 2), ("update", ("critic",)), ("high_utd", 1)]),
 }
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]
 
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name, (cfg, B, sched) in CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         res = RR.run_reference(cfg, B, sched, PARAM_SEED, BATCH_SEED)
         rec = G.pack(res, PARAM_SEED, BATCH_SEED)
         path = os.path.join(out_dir, f"update_{name}.npz")
