@@ -2096,10 +2096,6 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   return SERL_OK;
 }
 
-__global__ __launch_bounds__(256) void zero16_kernel(uint4* p, long n16) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta, int P, int Cc) {
   GnRef g{};
   g.stats = stats; g.gamma = gamma; g.beta = beta;
@@ -2116,12 +2112,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   // (the intermediate activations live in the workspace), which lets the caller put an event between them
   const TrunkDims& d = ws.d;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
-  if (stage_begin < 0) {   // statistics + arrival counters + tickets (own kernel: hipMemsetAsync's blit took 19 us for these 1.3 MB)
-    const long n16 = (long)(ws.stats_sync_bytes / 16);
-    hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)std::min<long>(cdiv(n16, 256), 1024)), dim3(256), 0, stream,
-                       reinterpret_cast<uint4*>(ws.stats), n16);
-    SERL_HIP(hipGetLastError());
-  }
+  if (stage_begin < 0) SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
   auto fuse_of = [&](int layer, int mode) {
     FuseArgs f{};
     const char* e = getenv("SERL_GN_FUSE");   // read per pass: tests flip it inside one process
