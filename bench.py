@@ -28,6 +28,23 @@ sys.path.insert(0, ROOT)
 KEYS = ("front", "wrist")
 H = W = 128
 S, A, B = 24, 6, 256
+# BASELINE.json configs restated as synthetic workloads.  buffers: (capacity, fill, seed,
+# samples per batch) in concat order -- online first, then demos (examples/async_drq_sim/async_drq_sim.py:238
+# `concat_batches(batch, demo_batch, axis=0)`).  The state is the bench's 24-d vector for every config (8(d): "bench: 24").
+WORKLOADS = {
+    # C2 async_drq_sim, the headline: one online buffer, batch 256, CAR=1 ("UTD=1")
+    "drq": dict(name="async_drq_sim (DrQ, ResNet-10 frozen trunk, REDQ-10 critic)", keys=("front", "wrist"), A=6, car=1,
+                buffers=[(200000, 20000, 0, 256)]),
+    # C3 async_drq_sim + 20 demo trajectories (RLPD 50/50), CAR=8: 7 x update_critics + 1 x update_high_utd(1)
+    "drq_demos": dict(name="async_drq_sim + 20 demo trajectories (RLPD 50/50 online+demo)", keys=("front", "wrist"), A=4, car=8,
+                      buffers=[(200000, 20000, 0, 128), (2000, 2000, 1, 128)]),
+    # C4 async_peg_insert_drq (examples/async_peg_insert_drq/async_peg_insert_drq.py:355-366): online 200k + demo 10k
+    "peg": dict(name="async_peg_insert_drq (2 wrist cameras + proprio, RLPD 50/50)", keys=("wrist_1", "wrist_2"), A=6, car=8,
+                buffers=[(200000, 20000, 0, 128), (10000, 2000, 1, 128)]),
+    # C5 async_bin_relocation_fwbw_drq (:508-519): ONE of the two independent fw/bw learners, batch 512 = 256 + 256, CAR=4
+    "fwbw": dict(name="async_bin_relocation_fwbw_drq (one of the two fw/bw learners, batch 512)", keys=("front", "wrist_1"), A=7,
+                 car=4, buffers=[(200000, 20000, 0, 256), (5000, 2000, 1, 256)]),
+}
 PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (256 CU x 256 FLOP/clk x 2.4 GHz)
 PEAK_F16_MFMA = 2500.0  # TFLOP/s dense fp16/bf16 MFMA (spec, MI355X_MICROARCH.md)
 PEAK_HBM = 8.0         # TB/s spec
@@ -63,20 +80,27 @@ PROFILE_EVERY = 4   # HIP events around every 4th launch of each kernel tag insi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--car", type=int, default=1, help="critic_actor_ratio (grad-steps per iteration)")
-    ap.add_argument("--capacity", type=int, default=200000)
-    ap.add_argument("--fill", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed repetitions of --steps iterations (each bracketed by barrier + synchronize); the MEDIAN is reported")
+    ap.add_argument("--car", type=int, default=None, help="critic_actor_ratio (grad-steps per iteration); default: the workload's")
+    ap.add_argument("--capacity", type=int, default=None, help="online buffer capacity (default 200000)")
+    ap.add_argument("--fill", type=int, default=None, help="online buffer fill (default 20000)")
+    ap.add_argument("--state-dim", type=int, default=24)
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the post-run check that the features the pipelined trunk produced (fused GroupNorm epilogues, update "
+                         "chain co-running) equal a serial re-encode with the un-fused elementwise passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--trunk", choices=["f16x3", "f32"], default="f16x3",
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
-    ap.add_argument("--workload", choices=["drq", "sac_state", "actor_latency"], default="drq",
-                    help="drq: the official bench line; sac_state: side measurement of configs[0] (state-only SAC); "
-                         "actor_latency: side measurement of the actor-side policy forward (sample_actions, batch 1)")
+    ap.add_argument("--workload", choices=list(WORKLOADS) + ["sac_state", "actor_latency"], default="drq",
+                    help="drq: the official bench line (BASELINE configs[1]); drq_demos / peg / fwbw: configs[2..4] (two HBM "
+                         "buffers, RLPD 50/50, CAR 8 / 8 / 4, batch 256 / 256 / 512); sac_state: side measurement of configs[0] "
+                         "(state-only SAC); actor_latency: side measurement of the actor-side policy forward (sample_actions, batch 1)")
     ap.add_argument("--prio", choices=["auto", "update", "trunk", "none"], default="auto",
                     help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
@@ -121,6 +145,15 @@ def main():
         probe = torch.tensor([float(rank + 1)], device="cuda")
         dist.all_reduce(probe)
         assert int(probe.item()) == world * (world + 1) // 2, f"RCCL all-reduce saw {probe.item()}, expected {world} ranks"
+    wl = WORKLOADS[args.workload]
+    KEYS, A, S = wl["keys"], wl["A"], args.state_dim
+    car = args.car if args.car is not None else wl["car"]
+    bufspec = [list(b) for b in wl["buffers"]]
+    if args.capacity is not None:
+        bufspec[0][0] = args.capacity
+    if args.fill is not None:
+        bufspec[0][1] = args.fill
+    B = sum(b[3] for b in bufspec)
     assert B % world == 0
     Bl = B // world
     emu = args.emulate_world
@@ -136,16 +169,21 @@ def main():
     from serl_amd.utils.synthetic import transition_stream
 
     # ---- replay buffer resident in HBM (replicated on every rank; same content, same seed)
-    osp = _DictSp({"front": _Sp((1, H, W, 3)), "state": _Sp((1, S)), "wrist": _Sp((1, H, W, 3))})
-    rb = MemoryEfficientReplayBufferDataStore(osp, _Sp((A,)), args.capacity, image_keys=KEYS, device=local_rank)
-    rb.seed(0)
+    spaces = {k: _Sp((1, H, W, 3)) for k in KEYS}
+    spaces["state"] = _Sp((1, S))
+    osp = _DictSp({k: spaces[k] for k in sorted(spaces)})
+    rbs = []
     t0 = time.time()
-    for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 100, 1234), args.fill):
-        rb.insert(tr)
+    for bi, (cap, fill, rseed, _) in enumerate(bufspec):
+        rb = MemoryEfficientReplayBufferDataStore(osp, _Sp((A,)), cap, image_keys=KEYS, device=local_rank)
+        rb.seed(rseed)   # online seed(0), demo seed(1)
+        for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 100, 1234 + bi), fill):
+            rb.insert(tr)
+        rbs.append(rb)
     fill_s = time.time() - t0
 
-    sample_obs = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8),
-                  "state": np.zeros((1, S), np.float32)}
+    sample_obs = {k: np.zeros((1, H, W, 3), np.uint8) for k in KEYS}
+    sample_obs["state"] = np.zeros((1, S), np.float32)
     agent = make_drq_agent(42, sample_obs, np.zeros((A,), np.float32), image_keys=KEYS,
                            encoder_type="resnet-pretrained", batch_size=Bl, device=local_rank)
     core = agent.core
@@ -186,13 +224,13 @@ def main():
         else:
             dist.all_reduce(t)
 
-    learner = DataParallelLearner(core, gather, [rb], [B], rank, emu if emu else world, all_reduce=all_reduce,
-                                  seed=7, schedule=sched)
+    learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
+                                  all_reduce=all_reduce, seed=7, schedule=sched)
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
 
     def iteration():
-        learner.iteration(args.car)
+        learner.iteration(car)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,13 +244,15 @@ def main():
     # (SERL_BENCH_NOPROF=1: diagnostic run without the per-kernel HIP events -- measures their overhead)
     _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else PROFILE_EVERY))
     _lib.check(_lib.lib().serl_profile_reset())
-    barrier()
     coll["on"] = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iteration()
-    barrier()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, args.repeats)):   # each repetition times EXACTLY --steps iterations
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            iteration()
+        barrier()
+        dts.append(time.perf_counter() - t0)
     coll["on"] = False
     prof = _lib.profile_read()
     _lib.check(_lib.lib().serl_profile_enable(0))
@@ -227,12 +267,14 @@ def main():
     torch.cuda.synchronize()
     info = core.read_info()
     assert all(np.isfinite(v) for v in info.values()), info
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:   # max over ranks, per repetition
+        t = torch.tensor(dts, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    grad_steps = args.steps * args.car
+        dts = [float(x) for x in t.tolist()]
+    dt = float(np.median(dts))
+    grad_steps = args.steps * car
     value = grad_steps / dt
+    verify = None if (args.no_verify or args.no_pipeline or args.trunk != "f16x3") else verify_features(learner, core, dbs, car)
 
     # ---- roofline of the dominant kernel family (implicit-GEMM convs of the frozen trunk)
     macs = conv_macs_per_image()
@@ -297,19 +339,21 @@ def main():
                                       "peak": PEAK_HBM, "unit": "TB/s", "frac": per_kernel["gather_crop"]["frac_hbm"]}
 
     out = {
-        "metric": "learner grad-steps/sec (DrQ, bs256, 2x128x128 img)", "value": round(value, 3),
+        "metric": f"learner grad-steps/sec (DrQ, bs{B}, {len(KEYS)}x128x128 img)", "value": round(value, 3),
         "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32 (trunk convs as split-fp16 MFMA x3, fp32 accumulate; <=1e-6 vs fp64)" if args.trunk == "f16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": "async_drq_sim (DrQ, ResNet-10 frozen trunk, REDQ-10 critic)", "global_batch": B,
-                   "per_gpu_batch": Bl, "cameras": len(KEYS), "image": [H, W, 3], "state_dim": S, "act_dim": A,
-                   "critic_actor_ratio": args.car, "utd_ratio": 1, "replay_capacity": args.capacity,
-                   "replay_fill": args.fill, "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": args.car,
+        "config": {"workload": wl["name"], "workload_key": args.workload, "global_batch": B,
+                   "per_gpu_batch": Bl, "cameras": len(KEYS), "image_keys": list(KEYS), "image": [H, W, 3], "state_dim": S, "act_dim": A,
+                   "critic_actor_ratio": car, "utd_ratio": 1,
+                   "buffers": [{"capacity": c_, "fill": f_, "seed": s_, "samples_per_batch": n_} for c_, f_, s_, n_ in bufspec],
+                   "replay_capacity": bufspec[0][0], "replay_fill": bufspec[0][1], "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": car,
                    "trunk_passes_per_grad_step": 2, "trunk_arithmetic": args.trunk,
                    "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
         "roofline": roofline,
+        "repeats": len(dts), "ms_per_step_runs": [round(1e3 * x / args.steps, 4) for x in dts],
         "last_info": {k: round(float(v), 6) for k, v in info.items()},
         "host_enqueue_ms_per_iteration": round(min(host_ms), 4), "setup": {"replay_fill_s": round(fill_s, 2)},
     }
@@ -323,8 +367,10 @@ def main():
             "avg_us_by_bytes": {str(k): round(float(np.mean(v)), 2) for k, v in sorted(by_size.items())},
             "note": "one all-reduce(SUM) of [critic grads | loss scalars] per critic update and one of [scalars | actor grads] "
                     "per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
+    if verify is not None:
+        out["verify"] = verify
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, KEYS, S, A, B)
     # the JSON line must be the last thing on stdout: librccl prints its version banner through C stdio, which is
     # block-buffered when stdout is a pipe/file and would otherwise surface after this line at exit -- every rank
     # flushes before the final barrier, rank 0 prints after it
@@ -339,6 +385,50 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def verify_features(learner, core, dbs, car, iters=12, tol=2e-6):
+    """A racy build must not produce a bench line: after the timed region, run `iters` more pipelined iterations and, after
+    each, compare the features of the batch the side stream has just encoded (fused GroupNorm epilogues, update chain
+    co-running on the other stream) with a serial re-encode of the same device batch through the separate elementwise
+    GroupNorm passes (SERL_GN_FUSE=0).  Raises SystemExit on a mismatch above `tol` of the features' max-abs."""
+    cfg = core.cfg
+    hf = cfg.H
+    for _ in range(5):
+        hf = (hf + 1) // 2
+    wf = cfg.W
+    for _ in range(5):
+        wf = (wf + 1) // 2
+    n = 2 * cfg.n_cam * cfg.batch * hf * wf * 512
+    worst, checked = 0.0, 0
+    old = os.environ.get("SERL_GN_FUSE")
+    for _ in range(iters):
+        learner.iteration(car)
+        torch.cuda.synchronize()
+        slot = learner._pending
+        if slot is None:
+            return None
+        core.select_slot(slot)
+        got = core.debug("feats", n).copy()
+        os.environ["SERL_GN_FUSE"] = "0"
+        try:
+            core.encode_slot(dbs[slot], slot)
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                del os.environ["SERL_GN_FUSE"]
+            else:
+                os.environ["SERL_GN_FUSE"] = old
+        ref = core.debug("feats", n)
+        scale = float(np.abs(ref).max())
+        worst = max(worst, float(np.abs(got - ref).max()) / max(scale, 1e-30))
+        checked += 1
+        if not np.isfinite(worst) or worst > tol:
+            raise SystemExit(f"bench.py --verify: pipelined features differ from the serial re-encode by {worst:.3e} of max "
+                             f"(tolerance {tol:.1e}) -- refusing to print a bench line")
+    return {"batches_checked": checked, "worst_rel_diff": worst, "tol": tol,
+            "what": "features of the side-stream trunk pass (fused GroupNorm epilogues, update chain co-running) vs a serial "
+                    "re-encode with SERL_GN_FUSE=0"}
 
 
 def self_launch(n):
@@ -460,7 +550,7 @@ def sac_state_main(iters):
 
 
 
-def cpu_baseline(budget_s):
+def cpu_baseline(budget_s, KEYS=KEYS, S=S, A=A, B=B):
     """The oracle (CPU restatement of the reference, PyTorch-CPU fp32, all host cores) timed on a
     bounded sample of the SAME workload: full-size update_high_utd(utd_ratio=1) steps incl. NumPy
     replay sampling.  kind = "port": jax/flax are not installable, so the reference itself cannot run."""
@@ -499,7 +589,7 @@ def cpu_baseline(budget_s):
             if el >= budget_s or n >= 8:
                 break
     return {"value": round(n / el, 4), "unit": "grad-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full-size update_high_utd(utd=1) steps (B=256, 2x128x128x3; 2 trunk passes per update = algorithmic minimum, the reference does 3-5) "
+            "sample": f"{n} full-size update_high_utd(utd=1) steps (B={B}, {len(KEYS)}x128x128x3; 2 trunk passes per update = algorithmic minimum, the reference does 3-5) "
                       f"incl. NumPy replay sampling, PyTorch-CPU fp32, {el:.1f} s",
             "cpu": _cpu_name()}
 

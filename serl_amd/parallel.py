@@ -4,7 +4,9 @@ dormant `jax.lax.pmean(grads_and_aux, pmap_axis)` (serl_launcher/common/common.p
 
 Sharding contract (DESIGN.md "multi-GPU"):
   * every rank holds a full replica of the replay buffer(s) with the same contents and the same
-    seed, so all ranks draw the IDENTICAL global index stream (bit-exact with 1 GPU);
+    seed, so all ranks draw the IDENTICAL global index stream (bit-exact with 1 GPU); transitions that
+    arrive from the actor while training are replicated by serl_amd/data/replicated.py (rank 0 fans them
+    out, every rank applies them at the same batch boundary);
   * rank r owns samples [r*B/P, (r+1)*B/P) of the (concatenated online+demo) global batch;
   * losses are normalised by the GLOBAL batch, so all-reduce(SUM) of [gradients | loss scalars]
     equals the single-device gradient; every rank then applies the identical Adam/EMA update
@@ -155,6 +157,11 @@ class DataParallelLearner:
         slice and run the frozen trunk on it -- on the side stream when pipelining."""
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.sched.slots
+        # replicated stores (serl_amd/data/replicated.py): every rank applies the same actor transitions here, i.e. at
+        # the same point of its insert / index-draw sequence, so the global index stream stays identical on all ranks
+        for buf in self.buffers:
+            if hasattr(buf, "step_barrier"):
+                buf.step_barrier()
         parts = [(b, b.sample_indices(n)) for b, n in zip(self.buffers, self.batch_sizes)]
         co = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
         cn = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)

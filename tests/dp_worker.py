@@ -1,7 +1,9 @@
 """Worker of tests/test_dp_two_process_gpu.py: one rank of a batch-sharded data-parallel learner on the REAL HIP path.
 Both ranks share the single GPU of the test box; the collective is gloo (RCCL needs one GPU per rank), staged through
 host memory -- everything else (replicated replay buffers, identical index/crop/REDQ streams, per-rank shard, device
-noise indexed by the global sample, gradient all-reduce between *_grads and apply) is the production code path."""
+noise indexed by the global sample, gradient all-reduce between *_grads and apply) is the production code path.
+Transitions keep arriving at rank 0 between the steps (ReplicatedDataStore fans them out): every rank must apply them at
+the same batch boundary, or the index streams -- and with them the parameters -- diverge."""
 import itertools
 import os
 import sys
@@ -33,10 +35,15 @@ def main():
     from serl_amd.parallel import DataParallelLearner, SerialSchedule
     from serl_amd.utils.launcher import make_drq_agent
     from serl_amd.utils.synthetic import transition_stream
-    rb = MemoryEfficientReplayBufferDataStore(_Obs(), _Sp((A,)), 300, image_keys=KEYS)
+    from serl_amd.data.replicated import ReplicatedDataStore
+    rb = ReplicatedDataStore(MemoryEfficientReplayBufferDataStore(_Obs(), _Sp((A,)), 300, image_keys=KEYS), rank, world, lag=2)
     rb.seed(0)
-    for tr in itertools.islice(transition_stream(KEYS, H, W, 3, 1, S, A, 20, 5), 150):
-        rb.insert(tr)
+    stream = transition_stream(KEYS, H, W, 3, 1, S, A, 20, 5)
+    if rank == 0:                           # the actor talks to rank 0 only
+        for tr in itertools.islice(stream, 150):
+            rb.insert(tr)
+    rb.flush()                              # collective: the initial fill is in every replica
+    assert len(rb) > 150
     Bl = B // world
     obs = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8), "state": np.zeros((1, S), np.float32)}
     agent = make_drq_agent(3, obs, np.zeros((A,), np.float32), image_keys=KEYS, encoder_type="resnet-pretrained", batch_size=Bl)
@@ -53,14 +60,22 @@ def main():
         t.copy_(h)
 
     learner = DataParallelLearner(core, gather, [rb], [B], rank, world, all_reduce=all_reduce, seed=7, schedule=SerialSchedule())
+    drawn = []
+    orig = rb.replica.sample_indices
+    rb.replica.sample_indices = lambda n: (drawn.append(orig(n)) or drawn[-1])
     for _ in range(iters):
+        if rank == 0:                       # 7 new transitions per iteration (an episode boundary every 20)
+            for tr in itertools.islice(stream, 7):
+                rb.insert(tr)
         learner.iteration(2)                # update_critics, then update_high_utd: production (device) noise
+    rb.flush()
     torch.cuda.synchronize()
-    if rank == 0:
-        leaves = ["critic/w1", "critic/head/kernel", "actor/w2", "actor/mean/kernel", "enc/0/dense/kernel", "enc/proprio/dense/kernel",
-                  "temp/lagrange"]
-        np.savez(out_path, step=core.step, info=np.array(list(core.read_info().values()), np.float64),
-                 **{k.replace("/", "__"): core.get("params", k) for k in leaves})
+    leaves = ["critic/w1", "critic/head/kernel", "actor/w2", "actor/mean/kernel", "enc/0/dense/kernel", "enc/proprio/dense/kernel",
+              "temp/lagrange"]
+    np.savez(out_path if rank == 0 else out_path.replace(".npz", f".rank{rank}.npz"), step=core.step,
+             info=np.array(list(core.read_info().values()), np.float64), valid=rb.valid_mask(), insert_index=rb.latest_data_id(),
+             size=len(rb), idx=np.stack(drawn), **{k.replace("/", "__"): core.get("params", k) for k in leaves})
+    rb.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

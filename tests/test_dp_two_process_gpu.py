@@ -28,10 +28,20 @@ def _run(tmp_path, world, iters=3):
 def test_two_ranks_reproduce_one(gpu, tmp_path):
     one, two = _run(tmp_path, 1), _run(tmp_path, 2)
     assert int(one["step"]) == int(two["step"]) == 9
+    # replicated inserts: both ranks of the 2-rank job hold the identical buffer and drew the identical index stream,
+    # and it is the stream the single process drew (same transitions applied at the same batch boundaries)
+    two_r1 = np.load(str(tmp_path / "w2.rank1.npz"))
+    for other in (two_r1, one):
+        assert np.array_equal(two["valid"], other["valid"]) and int(two["insert_index"]) == int(other["insert_index"])
+        assert int(two["size"]) == int(other["size"]) and np.array_equal(two["idx"], other["idx"])
+    assert int(two["size"]) == 150 + 3 * 7 + 9          # + one first-frame slot per episode begun (t = 0, 20, ..., 160)
+    for k in two.files:                                  # the two ranks applied bit-identical updates
+        if k.startswith(("critic", "actor", "enc", "temp")):
+            assert np.array_equal(two[k], two_r1[k]), k
     assert np.allclose(one["info"], two["info"], rtol=2e-4, atol=1e-6), (one["info"], two["info"])
     lr = 3e-4
     for k in one.files:
-        if k in ("step", "info"):
+        if not k.startswith(("critic", "actor", "enc", "temp")):
             continue
         a, b = one[k].astype(np.float64), two[k].astype(np.float64)
         err = np.abs(a - b)
