@@ -153,7 +153,8 @@ typedef struct serl_agent_cfg {
   uint64_t seed;           /* device noise stream (production mode) */
   /* Per-optimizer options of make_optimizer (common/optimizers.py:6-56), indexed by SERL_TX_*.  All zero (the
    * default, what every example uses) = adam + the warm-up -> constant schedule above.
-   *   tx_lr            > 0: learning rate of this optimizer (else `lr`)
+   *   tx_lr            > 0: learning rate of this optimizer (else `lr`); with tx_lr_set[t] != 0 the value is taken as
+   *                    given, 0 included (optax accepts learning_rate=0.0, e.g. to freeze the temperature)
    *   tx_warmup       >= 0: warm-up steps of this optimizer, given as steps + 1 (0 = use warmup_steps / temp_warmup_steps)
    *   tx_cosine_steps  > 0: warmup_cosine_decay_schedule(0, lr, warmup, decay_steps = this, end 0) (optimizers.py:14-21)
    *   tx_weight_decay_on != 0: optax.adamw with tx_weight_decay (optimizers.py:39-42); it decays the WHOLE tree, as the
@@ -173,6 +174,7 @@ typedef struct serl_agent_cfg {
   int encoder_type;
   int critic_subsample_size; /* sac.py:150-161: 0 = 2 (utils/launcher.py), -1 = None (minimum over all members), else 1..16 */
   int backup_entropy;        /* sac.py:174-176: target_q -= alpha * log pi(a'|s') */
+  int tx_lr_set[3];          /* != 0: tx_lr[t] was given explicitly and is honoured even when it is 0 */
 } serl_agent_cfg;
 #define SERL_ENCODER_RESNET_PRETRAINED 0
 #define SERL_ENCODER_SMALL 1

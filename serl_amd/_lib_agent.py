@@ -19,6 +19,7 @@ class SerlAgentCfg(C.Structure):
         ("encoder_type", C.c_int),   # 0 = resnet-pretrained (frozen trunk), 1 = small (trainable SmallEncoder)
         ("critic_subsample_size", C.c_int),   # 0 = 2, -1 = None (all members), else 1..16
         ("backup_entropy", C.c_int),
+        ("tx_lr_set", C.c_int * 3),   # != 0: tx_lr[t] given explicitly (0.0 is a valid optax learning rate)
     ]
 
 

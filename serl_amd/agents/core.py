@@ -39,7 +39,7 @@ class AgentCore:
             if bad:
                 raise TypeError(f"make_optimizer() got unexpected keyword arguments {sorted(bad)}")
             if kw.get("learning_rate") is not None:
-                self.cfg.tx_lr[i] = float(kw["learning_rate"])
+                self.cfg.tx_lr[i], self.cfg.tx_lr_set[i] = float(kw["learning_rate"]), 1
             if kw.get("warmup_steps") is not None:
                 self.cfg.tx_warmup[i] = int(kw["warmup_steps"]) + 1
             if kw.get("cosine_decay_steps") is not None:

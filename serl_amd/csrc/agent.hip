@@ -719,7 +719,7 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
 
 // learning rate of optimizer `tx` at `count` (optimizers.py:14-30): warm-up -> constant, or warm-up -> cosine decay
 float lr_at(const serl_agent_cfg& c, int64_t count, int tx) {
-  const float peak = c.tx_lr[tx] > 0.f ? c.tx_lr[tx] : c.lr;
+  const float peak = (c.tx_lr_set[tx] || c.tx_lr[tx] > 0.f) ? c.tx_lr[tx] : c.lr;
   int warm = (tx == SERL_TX_TEMPERATURE && c.temp_warmup_steps >= 0) ? c.temp_warmup_steps : c.warmup_steps;
   if (c.tx_warmup[tx] > 0) warm = c.tx_warmup[tx] - 1;
   if (count < warm) return (float)((double)peak * (double)count / (double)warm);   // linear_schedule(0, peak, warm)

@@ -133,8 +133,17 @@ def load_state_dict(agent, sd: dict):
             continue
         for leaf, paths in tp.items():
             core.set(section, leaf, _walk(tree, paths[0]))
-        for leaf, sub in trunk.items():
-            core.set(section, leaf, _walk(tree, ("modules_actor", "encoder", f"encoder_{trunk_owner(keys)}", "pretrained_encoder") + sub))
+        if trunk:
+            # Where flax puts the ONE shared frozen trunk is derived from its adoption rule (first camera in sorted-key
+            # order) and unverified against a real flax install: accept it under any camera, like
+            # reward_classifier.load_params and the reference's own `if "pretrained_encoder" in ...` guard do
+            enc = _walk(tree, ("modules_actor", "encoder"))
+            owners = [k for k in [trunk_owner(keys)] + sorted(keys) if "pretrained_encoder" in enc.get(f"encoder_{k}", {})]
+            if not owners:
+                raise KeyError(f"'{section}' holds no pretrained_encoder under any of encoder_{{{', '.join(sorted(keys))}}}")
+            root = enc[f"encoder_{owners[0]}"]["pretrained_encoder"]
+            for leaf, sub in trunk.items():
+                core.set(section, leaf, _walk(root, sub))
     if sd.get("opt_states") is not None:
         for tx in TX_NAMES:
             adam = _find_adam_state(sd["opt_states"][tx])

@@ -236,3 +236,22 @@ def test_load_resnet10_params_from_a_synthetic_pickle(gpu, tmp_path):
     other = _setup(B=8)[2]
     other.load_trunk_params(tree)
     assert np.array_equal(other.core.trunk_forward(frames).cpu().numpy(), feat1)
+
+
+def test_zero_learning_rate_is_honoured(gpu):
+    """optax accepts learning_rate=0.0 (e.g. to freeze the temperature, common/optimizers.py:23-30): the kernel must train
+    that optimizer's leaves at 0, not fall back to the default 3e-4, and the info dict / exported hyperparams say 0 too."""
+    from serl_amd.utils.launcher import make_drq_agent
+    env, rb, _ = _setup(B=8)
+    obs = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8), "state": np.zeros((1, S), np.float32)}
+    agent = make_drq_agent(3, obs, np.zeros((A,), np.float32), image_keys=KEYS, encoder_type="resnet-pretrained", batch_size=8,
+                           temperature_optimizer_kwargs={"learning_rate": 0.0})
+    lam0 = agent.core.get("params", "temp/lagrange").copy()
+    w0 = agent.core.get("params", "actor/w2").copy()
+    for _ in range(3):
+        agent, info = agent.update_high_utd(rb.sample(8, pack_obs_and_next_obs=True, lazy=True), utd_ratio=1)
+    d = info.resolve()
+    assert d["temperature_lr"] == 0.0 and abs(d["actor_lr"] - 3e-4) < 1e-9
+    assert np.array_equal(agent.core.get("params", "temp/lagrange"), lam0)
+    assert not np.array_equal(agent.core.get("params", "actor/w2"), w0)
+    assert float(agent.state.opt_states["temperature"]["hyperparams"]["learning_rate"]) == 0.0

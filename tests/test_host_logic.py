@@ -155,3 +155,44 @@ def test_pretrained_pickle_maps_onto_the_trunk_leaves(tmp_path):
     np.testing.assert_array_equal(a.got["trunk/block2/conv1"], trunk["trunk/block2/conv1"])
     with pytest.raises(FileNotFoundError):
         load_resnet10_params(FakeAgent(), ("front",), file_path=str(tmp_path / "absent.pkl"))
+
+
+def test_restore_finds_the_trunk_under_any_camera():
+    """load_state_dict (N1): the shared frozen trunk may sit under any camera of a real-flax checkpoint (layout unverified
+    without a flax install) -- it is found wherever `pretrained_encoder` is, and a tree without one is a KeyError."""
+    from types import SimpleNamespace
+    from serl_amd.agents.flax_tree import _trunk_paths, theta_paths
+    from serl_amd.utils.checkpoint import load_state_dict
+    keys = ("front", "wrist")
+    theta = pinit.init_theta(2, 32, 32, 4, 2, seed=2)
+    trunk = pinit.init_trunk(seed=2)
+
+    def tree(owner):
+        t = {}
+        def put(path, v):
+            d = t
+            for p in path[:-1]:
+                d = d.setdefault(p, {})
+            d[path[-1]] = v
+        for leaf, paths in theta_paths(keys).items():
+            put(paths[0], theta[leaf])
+        for leaf, sub in _trunk_paths().items():
+            if owner is not None:
+                put(("modules_actor", "encoder", f"encoder_{owner}", "pretrained_encoder") + sub, trunk[leaf])
+        return t
+
+    class Core:
+        cfg = SimpleNamespace(encoder_type=0)
+        def __init__(self):
+            self.got = {}
+        def set(self, section, leaf, v):
+            self.got[(section, leaf)] = np.asarray(v)
+
+    for owner in keys:
+        core = Core()
+        load_state_dict(SimpleNamespace(core=core, image_keys=keys), {"params": tree(owner)})
+        for leaf in trunk:
+            np.testing.assert_array_equal(core.got[("params", leaf)], trunk[leaf])
+        np.testing.assert_array_equal(core.got[("params", "enc/1/sle")], theta["enc/1/sle"])
+    with pytest.raises(KeyError, match="pretrained_encoder"):
+        load_state_dict(SimpleNamespace(core=Core(), image_keys=keys), {"params": tree(None)})
