@@ -246,6 +246,16 @@ int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slo
 int serl_agent_select_slot(serl_agent* a, int slot);
 int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
                             const serl_noise* noise, int redq_row, void* stream);
+/* The same critic phase with its gradients published in two BUCKETS so the caller can all-reduce the first while the
+ * second is still being computed (the pmean of common.py:213-214 overlapped with the backward pass, as DDP-style bucketing
+ * does): `event_bucket0` (a hipEvent_t, may be NULL) is recorded on `stream` as soon as bucket 0 is final -- before the
+ * encoder-head backward (Dense 4096->256 weight gradient, SpatialLearnedEmbeddings / SmallEncoder gradients) is issued.
+ *   bucket 0 = [critic ensemble | Q head | proprio branch | loss scalars]   (contiguous; ~8.7 MB at the headline shape)
+ *   bucket 1 = [per-camera encoder heads]                                    (contiguous; ~8.9 MB; empty for state-only SAC)
+ * Both are final when the call's work on `stream` has completed.  serl_agent_grad_bucket returns their device ranges. */
+int serl_agent_critic_grads_bucketed(serl_agent* a, int offset, int count, int global_count, const serl_noise* noise,
+                                     int redq_row, void* stream, void* event_bucket0);
+int serl_agent_grad_bucket(serl_agent* a, int bucket, float** dev_ptr, int64_t* count);
 int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* noise, void* stream);
 /* `which` = networks_to_update of SACAgent.update (sac.py:243-299) as a bit set; optimizers whose bit is clear still
  * step with a zero gradient (sac.py:276-277).  The target EMA runs iff SERL_NET_CRITIC is set (sac.py:284-285). */

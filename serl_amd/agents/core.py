@@ -170,6 +170,23 @@ class AgentCore:
         _lib.check(self.L.serl_agent_critic_grads(self._h, offset, count, global_count, self._noise(noise),
                                                   redq_row, self._stream()))
 
+    def critic_grads_bucketed(self, offset, count, global_count, noise=None, redq_row=0, event=None):
+        """critic_grads with bucket 0 ([ensemble | head | proprio | scalars]) published early: `event` (torch.cuda.Event) is
+        recorded on the current stream once that bucket is final, before the encoder-head backward is issued."""
+        ev = None
+        if event is not None:
+            if not event.cuda_event:        # lazily created by torch: materialise the hipEvent_t handle
+                event.record(torch.cuda.current_stream(self.device))
+            ev = C.c_void_p(event.cuda_event)
+        _lib.check(self.L.serl_agent_critic_grads_bucketed(self._h, offset, count, global_count, self._noise(noise),
+                                                           redq_row, self._stream(), ev))
+
+    def grad_bucket(self, bucket) -> torch.Tensor:
+        """Zero-copy view of gradient bucket 0 / 1 (see critic_grads_bucketed); bucket 1 is empty for state-only agents."""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.L.serl_agent_grad_bucket(self._h, bucket, C.byref(p), C.byref(n)))
+        return _wrap_device_f32(p.value, int(n.value), self.device) if n.value else torch.empty(0, device=self.device)
+
     def actor_grads(self, global_count, noise=None):
         _lib.check(self.L.serl_agent_actor_grads(self._h, global_count, self._noise(noise), self._stream()))
 

@@ -952,6 +952,20 @@ int serl_agent_set_shard(serl_agent* a, int64_t global_offset, int64_t global_ba
 
 int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, const serl_noise* noise,
                             int redq_row, void* stream) {
+  return serl_agent_critic_grads_bucketed(a, off, cnt, global_count, noise, redq_row, stream, nullptr);
+}
+
+int serl_agent_grad_bucket(serl_agent* a, int bucket, float** dev_ptr, int64_t* count) {
+  SERL_REQUIRE(a && dev_ptr && count, "NULL argument");
+  SERL_REQUIRE(bucket == 0 || bucket == 1, "bucket must be 0 or 1");
+  const Offs& o = a->o;
+  if (bucket == 0) { *dev_ptr = a->Gc + o.c_w1; *count = (o.Pc - o.c_w1) + kScalars; }
+  else { *dev_ptr = a->Gc; *count = o.c_w1; }
+  return SERL_OK;
+}
+
+int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global_count, const serl_noise* noise,
+                                     int redq_row, void* stream, void* event_bucket0) {
   SERL_REQUIRE(a && a->has_batch, "serl_agent_encode must run first");
   SERL_REQUIRE(off >= 0 && cnt >= 1 && off + cnt <= a->cur.batch && global_count >= cnt, "bad minibatch range");
   const serl_agent_cfg& c = a->cfg;
@@ -1000,11 +1014,14 @@ int serl_agent_critic_grads(serl_agent* a, int off, int cnt, int global_count, c
                  inv_norm, a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, st, a->state_only,
                  c.backup_entropy ? a->pol.logp : nullptr, c.backup_entropy ? a->aux + X_ALPHA : nullptr));
   RC(critic_bwd(a, a->theta, a->crit, cnt, true, st, a->dq, 0.f));
-  if (!a->state_only) {
+  if (!a->state_only)
     RC(proprio_bwd(a, a->theta, a->dx + (long)c.n_cam * c.bottleneck, a->XA, a->crit.x + (long)c.n_cam * c.bottleneck,
                    a->XA, a->encO, 0, off, cnt, a->Gc, 0, st));
-    RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
+  if (event_bucket0) {   // bucket 0 (ensemble | head | proprio | scalars) is final here: publish it before the encoder heads
+    RC(flush_param_grads(a, st));
+    SERL_HIP(hipEventRecord((hipEvent_t)event_bucket0, st));
   }
+  if (!a->state_only) RC(encode_bwd_critic(a, a->theta, a->encO, off, cnt, st));
   RC(flush_param_grads(a, st));
   a->last_global = global_count;
   return SERL_OK;

@@ -19,13 +19,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // workgroup frees.  The kernel is therefore built lean -- ~60 VGPRs, 18 KB LDS (single-buffered, next chunk
 // prefetched in registers) -- so that several of its workgroups fit into one freed conv slot.
 // Operands are read with 16-byte vectors along whichever dimension is contiguous (transposes are free:
-// A may be k- or m-contiguous, B k- or n-contiguous) and stored k-contiguous in LDS, [row][k] with a
-// 36-float pitch, so one conflict-free ds_read_b128 per operand feeds four MFMAs: inside each block of 8
-// k's, lanes 0-31 take k = 0..3 and lanes 32-63 k = 4..7 (the K order of a sum is free).
+// A may be k- or m-contiguous, B k- or n-contiguous).  A k-contiguous operand is stored [row][k] with a
+// 36-float pitch, so one conflict-free ds_read_b128 feeds four MFMAs: inside each block of 8 k's, lanes 0-31
+// take k = 0..3 and lanes 32-63 k = 4..7 (the K order of a sum is free).  A row-contiguous operand keeps its
+// orientation in LDS, [k][row] with a 68-float pitch: its 16-byte global vectors become single conflict-free
+// ds_write_b128 and a fragment is four conflict-free ds_read_b32 (consecutive lanes = consecutive rows).  Round 2
+// transposed such operands on the way into LDS with scalar stores at a 36-float row pitch: 8 lanes per bank,
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.62 for gemm_f32_kernel<true, false> (profiles/r02_mfma_counters.json).
 // Edges are zero-filled; slabs are summed by the consumer (reduce_slabs / ln_tanh_fwd), which keeps the
 // K-split deterministic.  Arbitrary element strides fall back to gemm_f32_strided_kernel.
 // =============================================================================================
-constexpr int kGBM = 64, kGBN = 64, kGBK = 32, kGP = 36;
+constexpr int kGBM = 64, kGBN = 64, kGBK = 32, kGP = 36, kGPT = 68;
+constexpr int kGTile = kGBM * kGP;   // floats per operand tile in LDS (>= kGBK * kGPT)
+static_assert(kGBK * kGPT <= kGTile, "the [k][row] layout must fit the tile");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // global loads need only 4-byte alignment
 
@@ -79,18 +85,19 @@ struct OperandLoader {
       p[i] += step;
     }
   }
-  __device__ __forceinline__ void store(float (*S)[kGP], const f32x4 (&r)[2], int tid) const {
+  __device__ __forceinline__ void store(float* S, const f32x4 (&r)[2], int tid) const {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i;
-      if (KFAST) {
-        *reinterpret_cast<f32x4*>(&S[idx >> 3][4 * (idx & 7)]) = r[i];
-      } else {
-        const int rq = 4 * (idx & 15), k = idx >> 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[rq + j][k] = r[i][j];
-      }
+      if (KFAST) *reinterpret_cast<f32x4*>(S + (idx >> 3) * kGP + 4 * (idx & 7)) = r[i];      // [row][k]
+      else *reinterpret_cast<f32x4*>(S + (idx >> 4) * kGPT + 4 * (idx & 15)) = r[i];          // [k][row]
     }
+  }
+  // the four operand values of this lane for k = 8q + 4*lh + (0..3) of tile row `row`
+  __device__ __forceinline__ static f32x4 frag(const float* S, int row, int lh, int q) {
+    if (KFAST) return *reinterpret_cast<const f32x4*>(S + row * kGP + 8 * q + 4 * lh);
+    const float* p = S + (8 * q + 4 * lh) * kGPT + row;
+    return (f32x4){p[0], p[kGPT], p[2 * kGPT], p[3 * kGPT]};
   }
 };
 
@@ -104,8 +111,8 @@ struct GemmMulti {
 
 template <bool A_KFAST, bool B_KFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
-  __shared__ __attribute__((aligned(16))) float As[kGBM][kGP];  // [m][k]
-  __shared__ __attribute__((aligned(16))) float Bs[kGBN][kGP];  // [n][k]
+  __shared__ __attribute__((aligned(16))) float As[kGTile];  // [m][k] (pitch 36) or [k][m] (pitch 68)
+  __shared__ __attribute__((aligned(16))) float Bs[kGTile];  // [n][k]             or [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int grp = 0;
@@ -129,8 +136,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
     f32x4 ra[2], rb[2];
     la.load(ra, k_begin, k_end);
     lb.load(rb, k_begin, k_end);
-    const float* arow = &As[wm * 32 + li][4 * lh];
-    const float* brow = &Bs[wn * 32 + li][4 * lh];
     for (int k0 = k_begin; k0 < k_end; k0 += kGBK) {
       la.store(As, ra, tid);
       lb.store(Bs, rb, tid);
@@ -139,8 +144,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
       lb.load(rb, k0 + kGBK, k_end);
 #pragma unroll
       for (int q = 0; q < kGBK / 8; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(brow + 8 * q);
+        const f32x4 a = OperandLoader<A_KFAST>::frag(As, wm * 32 + li, lh, q);
+        const f32x4 b = OperandLoader<B_KFAST>::frag(Bs, wn * 32 + li, lh, q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
       }

@@ -29,17 +29,25 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
 
 // GroupNorm (+ residual) + ReLU + split8 re-layout in the PRODUCING conv's epilogue (mode != 0) instead of a separate
-// elementwise pass over the raw fp32 tensor.  GroupNorm needs the statistics of the whole image, which 2..8 workgroups
+// elementwise pass over the raw fp32 tensor.  GroupNorm needs the statistics of the whole image, which G = 2..8 workgroups
 // produce: each adds its partial sums (fp64 atomics, as before), then bumps an arrival counter of the image and waits
-// until all of the image's workgroups have arrived.  Tiles are handed out by an atomic TICKET taken when a workgroup
-// starts running, so every ticket below the newest one belongs to a workgroup that is resident (or done): a waiting
-// workgroup only ever waits for workgroups that are already running, whatever order the hardware dispatches blocks in.
+// until all of the image's workgroups have arrived.
+// FORWARD PROGRESS.  Tiles are handed out by atomic TICKETS taken when a workgroup starts running (fused_tile): one
+// counter per XCD, each covering a contiguous range of whole images, so the G tiles of an image carry CONSECUTIVE tickets
+// of one counter (and are fetched through one L2).  A waiting workgroup therefore waits (a) for tiles that running
+// workgroups already hold -- they finish without waiting for anybody -- or (b) for not-yet-taken tiles of the ONE image
+// per counter that straddles its next ticket; at most G - 1 workgroups per counter can wait in state (b), so as long as
+// more than 8 (G - 1) workgroups are resident, one of them is running or about to start and takes the missing tickets
+// (a workgroup whose own XCD's range is used up takes from the next XCD's counter).  The launcher checks that bound
+// against the CUs the stream may use (resident_workgroups) and falls back to the separate elementwise pass otherwise;
+// the spin itself is bounded (trap) so a protocol error aborts the kernel instead of hanging the GPU.
 struct FuseArgs {
   int mode;                 // 0 off; 1 relu(GN(y)); 2 relu(GN(y) + res_split); 3 relu(GN(y) + GN_res(res_raw))
   int expected;             // arrivals per counter; 0 = LOCAL: a wave's 64 rows x 64 columns are exactly one (image, group), no
                             // workgroup exchanges anything (P == 64 and Cout / 4 == 64: stage 2) -- no ticket, no wait
   int* sync;                // [image][tiles_n] arrival counters, zeroed with the statistics
-  int* ticket;              // zeroed with the statistics
+  int* ticket;              // [8] per-XCD tile counters, zeroed with the statistics
+  int group;                // G: tiles (workgroups) per image -- tickets of one image are consecutive
   GnRef gn;                 // this conv's statistics (being produced), scale, bias
   GnRef res_gn;             // mode 3: the projection's GroupNorm (complete: that conv ran before)
   const uint8_t* res_split; // mode 2: the block input (split8)
@@ -85,20 +93,47 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 // byte offset of 16-byte slot `slot` (0..3) of row `row` in a [rows][32] bf16 plane (64-byte rows)
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ int fused_ticket(const FuseArgs& fz) {
-  __shared__ int s_ticket;
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// Tile of this workgroup in a fused launch of `ntiles` = gridDim.x tiles, `group` tiles per image.  The images are
+// split into 8 contiguous ranges (one per XCD, as xcd_remap does for block ids); a workgroup draws from the counter of the
+// XCD it actually runs on (HW_REG_XCC_ID -- used for L2 affinity only, any value 0..7 is correct) and moves on to the next
+// XCD's counter when that range is used up.  #workgroups == #tiles and every valid ticket is unique, so every workgroup
+// finds a tile within one round over the 8 counters.
+__device__ __forceinline__ int fused_tile(const FuseArgs& fz, int ntiles) {
+  __shared__ int s_tile;
+  if (threadIdx.x == 0) {
+    const int G = fz.group, ngroups = ntiles / G, gq = ngroups >> 3, gr = ngroups & 7;
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 7u;
+    int tile = -1;
+    for (int k = 0; k < 8 && tile < 0; ++k, x = (x + 1) & 7u) {
+      const int g0 = (int)x < gr ? (int)x * (gq + 1) : gr * (gq + 1) + ((int)x - gr) * gq;
+      const int cnt = (gq + ((int)x < gr ? 1 : 0)) * G;
+      if (cnt == 0) continue;
+      const int t = __hip_atomic_fetch_add(fz.ticket + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (t < cnt) tile = g0 * G + t;
+    }
+    if (tile < 0) __builtin_trap();   // cannot happen: as many workgroups as tiles
+    s_tile = tile;
+  }
   __syncthreads();
-  return s_ticket;
+  return s_tile;
 }
 
-// Ordering without cache maintenance: the statistics, the counter and the ticket are only ever touched by SYSTEM-scope
-// atomics (sc1: performed at the memory side, past the 8 per-XCD L2s -- an image's workgroups can sit on different XCDs,
-// and agent-scope atomics performed in one XCD's L2 reached the others late: 1e-4 errors at 1024 images), so no L2
-// write-back / invalidate is needed (an agent-scope acquire in the polling loop invalidates the XCD's whole L2 on every
-// poll: measured 4x slower convs).  A wave's no-return atomics are complete when its vmcnt reaches 0 (workgroup-scope
-// release fence = s_waitcnt only), which is what the AMDGPU memory model itself relies on; the barrier then orders every
-// wave's statistics before thread 0's arrival; pollers read the statistics with atomic loads.
+// Ordering without cache maintenance: the statistics, the arrival counters and the tickets are only ever touched by
+// SYSTEM-scope atomics (sc1: performed at the memory side, past the 8 per-XCD L2s -- an image's workgroups can sit on
+// different XCDs, and agent-scope atomics performed in one XCD's L2 reached the others late: 1e-4 errors at 1024 images),
+// and pollers read the statistics with system-scope atomic loads, so there is no cached copy anywhere that an L2
+// write-back / L1 invalidate would have to refresh (an agent-scope ACQUIRE in the polling loop invalidates caches on every
+// poll: measured 4x slower convs).  What remains is the ORDER "statistics performed before the arrival is performed":
+//   * the statistics atomics are RETURNING atomics whose results are consumed (stats_flush): a wave passes the
+//     s_waitcnt in front of the barrier below only when the memory side has answered, i.e. performed, each of them.
+//     (A NO-RETURN atomic leaves vmcnt when the L2 has ACCEPTED it -- trunk_common.h -- which is why the round-2
+//     no-return variant lost sums at 1024 images.)
+//   * the barrier orders every wave's (performed) statistics before thread 0 issues the arrival atomic.
+// In HIP memory-model terms the arrival is the release and the poll that sees `expected` the acquire; relaxed atomics
+// are enough here because every location involved is accessed with memory-side atomics only -- this rests on the measured
+// gfx950 behaviour above (tests/test_agent_gpu.py::test_fused_groupnorm_epilogue_is_race_free_*), not on the language model.
 __device__ __forceinline__ void fused_arrive_and_wait(int* ctr, int expected) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
@@ -481,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int id = xcd_remap((ab.fz.mode && ab.fz.expected) ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
+  const int id = (ab.fz.mode && ab.fz.expected) ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   const int ntaps = a.KH * a.KW;
@@ -780,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
   constexpr int AI = (MAXPIX * 4 + 255) / 256;   // 16-byte activation records per thread per chunk
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
+  const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
   const int m0 = id * BM, n0 = 0;
   const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
   const int pw = a.Wo + 2, npix = (BM / a.Wo) * pw;
@@ -914,7 +949,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   uint8_t* const smA = smemb;
   uint8_t* const smB = smemb + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int id = xcd_remap(ab.fz.mode ? fused_ticket(ab.fz) : (int)blockIdx.x, gridDim.x);
+  const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;   // 64-channel column tiles of one row tile are neighbours (shared slab in L2)
   const int m0 = bm * BM, n0 = bn * BN;
   const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
@@ -1949,6 +1984,27 @@ __global__ __launch_bounds__(256) void block_out_split_kernel(const float* raw, 
   else store_split8(out_split, e, o);
 }
 
+// Workgroups of a 2-per-CU conv kernel that can be co-resident on `stream`, counted conservatively as ONE per compute unit
+// the stream may use (its CU mask if it has one; a CPX-partitioned device reports 32 CUs).  Cached per stream.
+static int resident_workgroups(hipStream_t stream) {
+  thread_local hipStream_t last = nullptr;
+  thread_local int last_n = -1;
+  if (last_n >= 0 && last == stream) return last_n;
+  int dev = 0, n = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+  uint32_t mask[16] = {0};
+  if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess) {
+    int m = 0;
+    for (uint32_t w : mask) m += __builtin_popcount(w);
+    if (m > 0 && (n == 0 || m < n)) n = m;
+  } else {
+    (void)hipGetLastError();
+  }
+  last = stream; last_n = n;
+  return n;
+}
+
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
                              hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
@@ -2007,11 +2063,14 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4 || (cfg == 1 && dma_c64)) && Cin % 32 == 0 && zero_page != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
     bool fused = false;
+    // the fused epilogue's wait needs more than 8 (G - 1) co-resident workgroups (see FuseArgs); demand twice that of the
+    // CUs this stream may use at ONE workgroup per CU, else run the separate elementwise pass
+    auto can_wait = [&](int G) { return resident_workgroups(stream) >= 16 * (G - 1) + 1; };
     if (rp_ok) {
-      if (fuse && fuse->mode && a.P % 256 == 0) {
-        ab.fz = *fuse; ab.fz.expected = a.P / 256; fused = true;
-      }
       a.tiles_m = a.M / 256; a.tiles_n = slab ? Cout / 64 : 1;
+      if (fuse && fuse->mode && a.P % 256 == 0 && can_wait(a.P / 256 * a.tiles_n)) {
+        ab.fz = *fuse; ab.fz.expected = a.P / 256; ab.fz.group = a.P / 256 * a.tiles_n; fused = true;
+      }
       // SERL_CONV_ROWSLAB_DEEP=1: fetches issued two sub-chunks ahead (second staging register set); measured neutral
       // (b0 convs 318 / 360 -> 312 / 355 us), so the simpler schedule stays the default
       static const bool slab_deep = []() { const char* e = getenv("SERL_CONV_ROWSLAB_DEEP"); return e && e[0] == '1'; }();
@@ -2027,8 +2086,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       const int nst = dma >= 3 ? 3 : 2;
       const size_t l = (size_t)nst * (128 * 128 + 2 * bn * 64);
       if (pmode == 1 && cfg == 4) pmode = 3;
-      if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage) {
-        ab.fz = *fuse; ab.fz.expected = a.P / 128; fused = true;
+      if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage && can_wait(a.P / 128 * a.tiles_n)) {
+        ab.fz = *fuse; ab.fz.expected = a.P / 128; ab.fz.group = a.P / 128 * a.tiles_n; fused = true;
       } else if (fuse && fuse->mode && pmode == 0 && a.P == 64 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 64) {
         static const bool local_on = []() { const char* e = getenv("SERL_GN_FUSE_LOCAL"); return !(e && e[0] == '0'); }();
         if (local_on) { ab.fz = *fuse; ab.fz.expected = 0; fused = true; }   // a wave = one (image, group): no exchange

@@ -124,7 +124,8 @@ class DataParallelLearner:
     (AgentCore); gather: callable(parts, crop_obs, crop_next, slot) -> device batch for that slot."""
 
     def __init__(self, core, gather, buffers: List[object], batch_sizes: List[int], rank: int = 0,
-                 world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10, schedule=None):
+                 world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10, schedule=None,
+                 overlap_reduce: bool = True):
         self.core, self.gather, self.buffers, self.batch_sizes = core, gather, buffers, batch_sizes
         self.rank, self.world = rank, world
         self.B = sum(batch_sizes)
@@ -142,6 +143,11 @@ class DataParallelLearner:
         if world > 1 and hasattr(core, "set_shard"):
             core.set_shard(rank * self.Bl, self.B)   # device noise indexed by the global sample id
         self._next_slot = 0
+        # Bucketed, overlapped gradient all-reduce (DDP-style): the critic phase publishes [ensemble | head | proprio |
+        # scalars] before it starts the encoder-head backward; that bucket is reduced on a communication stream while
+        # the encoder heads' weight gradients are still being computed, the second bucket follows, and only `apply` waits.
+        self._overlap = bool(overlap_reduce) and hasattr(core, "critic_grads_bucketed") and hasattr(core, "grad_bucket")
+        self._comm = None
 
     def _view(self, which):
         if which not in self._gv:
@@ -193,9 +199,31 @@ class DataParallelLearner:
     def _critic(self):
         noise = {"redq_idx": self._redq_rng.integers(0, self.ensemble, size=(1, 2)).astype(np.int32)}
         self.core.begin_update()
-        self.core.critic_grads(0, self.Bl, self.B, noise)
-        self._reduce(APPLY_CRITIC)
+        if self._overlap and (self.world > 1 or self.force_reduce):
+            self._critic_overlapped(noise)
+        else:
+            self.core.critic_grads(0, self.Bl, self.B, noise)
+            self._reduce(APPLY_CRITIC)
         self.core.apply(APPLY_CRITIC)
+
+    def _critic_overlapped(self, noise):
+        import torch
+        dev = self.core.device
+        if self._comm is None:
+            self._comm = dict(stream=torch.cuda.Stream(device=dev, priority=-1), ev0=torch.cuda.Event(), ev1=torch.cuda.Event(),
+                              b0=self.core.grad_bucket(0), b1=self.core.grad_bucket(1))
+        c = self._comm
+        cur = torch.cuda.current_stream(dev)
+        self.core.critic_grads_bucketed(0, self.Bl, self.B, noise, 0, c["ev0"])   # ev0: bucket 0 final, encoder heads still running
+        c["stream"].wait_event(c["ev0"])
+        with torch.cuda.stream(c["stream"]):
+            self.all_reduce(c["b0"])
+        if c["b1"].numel():
+            c["ev1"].record(cur)                                                   # the whole critic phase
+            c["stream"].wait_event(c["ev1"])
+            with torch.cuda.stream(c["stream"]):
+                self.all_reduce(c["b1"])
+        cur.wait_stream(c["stream"])
 
     def update_critics(self):
         """DrQAgent.update_critics over the global batch (one grad-step)."""
