@@ -363,10 +363,12 @@ def main():
             by_size.setdefault(nbytes, []).append(e0.elapsed_time(e1) * 1e3)
         out["collective"] = {
             "backend": "nccl (RCCL)", "world_size": dist.get_world_size(), "launcher": "torch.distributed.run",
-            "all_reduces_per_step": coll["calls"] / max(args.steps, 1), "bytes_per_step": coll["bytes"] / max(args.steps, 1),
+            "all_reduces_per_step": coll["calls"] / max(args.steps * len(dts), 1),
+            "bytes_per_step": coll["bytes"] / max(args.steps * len(dts), 1),
             "avg_us_by_bytes": {str(k): round(float(np.mean(v)), 2) for k, v in sorted(by_size.items())},
-            "note": "one all-reduce(SUM) of [critic grads | loss scalars] per critic update and one of [scalars | actor grads] "
-                    "per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
+            "note": "per critic update two overlapped all-reduce(SUM) buckets on a communication stream -- [ensemble | Q head | proprio | "
+                    "loss scalars] issued while the encoder-head backward still runs, then [encoder heads] -- and one of [scalars | "
+                    "actor grads] per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
     if verify is not None:
         out["verify"] = verify
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -48,6 +48,7 @@ struct FuseArgs {
   int* sync;                // [image][tiles_n] arrival counters, zeroed with the statistics
   int* ticket;              // [8] per-XCD tile counters, zeroed with the statistics
   int group;                // G: tiles (workgroups) per image -- tickets of one image are consecutive
+  int tmode;                // ticket -> tile map: 0 per-XCD counters (default), 1 one counter + xcd_remap(ticket) (round 2), 2 one counter, image-consecutive
   GnRef gn;                 // this conv's statistics (being produced), scale, bias
   GnRef res_gn;             // mode 3: the projection's GroupNorm (complete: that conv ran before)
   const uint8_t* res_split; // mode 2: the block input (split8)
@@ -100,7 +101,10 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot
 // finds a tile within one round over the 8 counters.
 __device__ __forceinline__ int fused_tile(const FuseArgs& fz, int ntiles) {
   __shared__ int s_tile;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && fz.tmode != 0) {   // measurement variants (SERL_TICKET_MODE)
+    const int t = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_tile = fz.tmode == 1 ? xcd_remap(t, ntiles) : xcd_remap(t / fz.group, ntiles / fz.group) * fz.group + t % fz.group;
+  } else if (threadIdx.x == 0) {
     const int G = fz.group, ngroups = ntiles / G, gq = ngroups >> 3, gr = ngroups & 7;
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -2178,6 +2182,8 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     f.mode = (e && e[0] == '0') ? 0 : mode;
     f.sync = ws.sync + (size_t)layer * ((size_t)ws.max_images * kSyncPerImage + kSyncTickets);
     f.ticket = f.sync + (size_t)ws.max_images * kSyncPerImage;
+    static const int tmode = []() { const char* e = getenv("SERL_TICKET_MODE"); return e ? atoi(e) : 0; }();
+    f.tmode = tmode;
     return f;
   };
   int rc;

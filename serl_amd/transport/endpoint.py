@@ -11,11 +11,24 @@ from collections import deque
 from dataclasses import dataclass, field
 from typing import Any, Callable, Dict, List, Optional
 
-try:  # real transport only where the reference's dependencies exist
-    import lz4.frame as _lz4
+# Sockets: pyzmq when it is installed, else this package's own implementation of the same wire protocol (ZMTP 3.0 over
+# TCP, serl_amd/transport/zmtp.py -- verified against a real libzmq in tests/test_zmtp_interop.py) behind the same API
+# subset.  Framing: the `lz4` package when installed, else liblz4 through ctypes (serl_amd/transport/lz4frame.py: real LZ4
+# frames), else zlib with a marker byte (only a peer running this package can read that).
+try:
     import zmq as _zmq
+    ZMQ_BACKEND = "pyzmq"
 except Exception:  # noqa: BLE001
-    _lz4 = _zmq = None
+    from . import zmtp as _zmq
+    ZMQ_BACKEND = "serl_amd.transport.zmtp"
+try:
+    import lz4.frame as _lz4
+    LZ4_BACKEND = "lz4"
+except Exception:  # noqa: BLE001
+    from . import lz4frame as _lz4
+    LZ4_BACKEND = "liblz4 (ctypes)"
+    if not _lz4.available():
+        _lz4, LZ4_BACKEND = None, "zlib (no lz4 on this host)"
 
 
 # ------------------------------------------------------------------------------------------------- data stores
@@ -62,6 +75,13 @@ class QueuedDataStore(DataStoreBase):
     def get_latest_data(self, from_id: int):
         with self._lock:
             return [d for i, d in self._q if i > from_id]
+
+    def latest_since(self, from_id: int):
+        """(id of the newest returned item, items newer than from_id) taken atomically, so that a concurrent insert is
+        neither shipped twice nor lost by TrainerClient.update."""
+        with self._lock:
+            items = [(i, d) for i, d in self._q if i > from_id]
+        return (items[-1][0] if items else from_id), [d for _, d in items]
 
     def __len__(self):
         return len(self._q)
@@ -151,11 +171,16 @@ class TrainerServer:
     `stop()`; `request_callback(type, payload) -> dict` answers the custom request types."""
 
     def __init__(self, config: TrainerConfig, request_callback: Optional[Callable[[str, dict], dict]] = None,
-                 transport: Optional[str] = None):
+                 transport: Optional[str] = None, bind_ip: str = "*"):
+        """transport: "zmq" (TCP sockets; default) or "loopback" (in-process queues).  bind_ip: interface the two sockets
+        listen on ("*" = all, like agentlace).  TRUST MODEL: messages are pickles -- whoever can reach the port can
+        execute code in the learner process (upstream agentlace has the same property); bind to a private interface or
+        "127.0.0.1" unless the network is trusted."""
         self.config, self.request_callback = config, request_callback
-        self.transport = transport or ("zmq" if _zmq is not None else "loopback")
-        if self.transport == "zmq" and _zmq is None:
-            raise RuntimeError("pyzmq / lz4 are not installed: only transport='loopback' is available")
+        self.transport = transport or "zmq"
+        if self.transport not in ("zmq", "loopback"):
+            raise ValueError(f"unknown transport {self.transport!r}")
+        self.bind_ip = bind_ip
         self.data_stores: Dict[str, DataStoreBase] = {}
         self._thread, self._stop = None, threading.Event()
         self.stats = {"datastore_msgs": 0, "transitions": 0, "requests": 0, "published": 0}
@@ -195,24 +220,33 @@ class TrainerServer:
             except Exception as e:  # noqa: BLE001
                 reply.put(encode({"success": False, "message": repr(e)}))
 
-    def _serve_zmq(self):  # pragma: no cover  (pyzmq is absent in the build image)
-        ctx = _zmq.Context.instance()
-        rep = ctx.socket(_zmq.REP)
-        rep.bind(f"tcp://*:{self.config.port_number}")
+    def _serve_zmq(self):
+        rep = self._rep
         poller = _zmq.Poller()
         poller.register(rep, _zmq.POLLIN)
         while not self._stop.is_set():
             if dict(poller.poll(50)).get(rep):
-                rep.send(encode(self.handle(decode(rep.recv()))))
+                frame = rep.recv()
+                # a REP socket that received a request MUST answer it, or every actor blocks in recv forever: a malformed
+                # frame or a failing handler becomes an error reply, the server thread keeps running
+                try:
+                    reply = self.handle(decode(frame))
+                except Exception as e:  # noqa: BLE001
+                    self.stats["errors"] = self.stats.get("errors", 0) + 1
+                    reply = {"success": False, "message": repr(e)}
+                rep.send(encode(reply))
         rep.close(0)
 
     def start(self, threaded: bool = False):
         if self.transport == "loopback":
             self._inbox = _Loopback.bind(self.config.port_number)
             target = self._serve_loopback
-        else:  # pragma: no cover
-            self._pub = _zmq.Context.instance().socket(_zmq.PUB)
-            self._pub.bind(f"tcp://*:{self.config.broadcast_port}")
+        else:
+            ctx = _zmq.Context.instance()
+            self._rep = ctx.socket(_zmq.REP)
+            self._rep.bind(f"tcp://{self.bind_ip}:{self.config.port_number}")
+            self._pub = ctx.socket(_zmq.PUB)
+            self._pub.bind(f"tcp://{self.bind_ip}:{self.config.broadcast_port}")
             target = self._serve_zmq
         if threaded:
             self._thread = threading.Thread(target=target, name="TrainerServer", daemon=True)
@@ -225,7 +259,7 @@ class TrainerServer:
         frame = encode(params)
         if self.transport == "loopback":
             _Loopback.publish(self.config.broadcast_port, frame)
-        else:  # pragma: no cover
+        else:
             self._pub.send(frame)
         self.stats["published"] += 1
 
@@ -235,6 +269,9 @@ class TrainerServer:
             self._thread.join(timeout=5)
         if self.transport == "loopback":
             _Loopback.unbind(self.config.port_number, self.config.broadcast_port)
+        elif getattr(self, "_pub", None) is not None:
+            self._pub.close(0)
+            self._pub = None
 
 
 # ------------------------------------------------------------------------------------------------- client
@@ -245,16 +282,18 @@ class TrainerClient:
     def __init__(self, name: str, server_ip: str, config: TrainerConfig, data_store: Optional[DataStoreBase] = None,
                  log_level=None, wait_for_server: bool = False, transport: Optional[str] = None, timeout: float = 30.0):
         self.name, self.config, self.data_store = name, config, data_store
-        self.transport = transport or ("zmq" if _zmq is not None else "loopback")
+        self.transport = transport or "zmq"
         self.timeout = timeout
         self.last_sync_data_id = -1
         self._stop = threading.Event()
         self._sub_thread = None
         if self.transport == "loopback":
             self._outbox = _Loopback.connect(config.port_number, wait_for_server, timeout)
-        else:  # pragma: no cover
+        else:
             ctx = _zmq.Context.instance()
             self._req = ctx.socket(_zmq.REQ)
+            self._req.setsockopt(_zmq.RCVTIMEO, int(timeout * 1000))
+            self._req.setsockopt(_zmq.SNDTIMEO, int(timeout * 1000))
             self._req.connect(f"tcp://{server_ip}:{config.port_number}")
             self._ip = server_ip
         res = self._send({"type": "handshake", "config_hash": config.hash()})
@@ -270,15 +309,26 @@ class TrainerClient:
                 return decode(reply.get(timeout=self.timeout))
             except queue.Empty:
                 return None
-        self._req.send(frame)  # pragma: no cover
-        return decode(self._req.recv())  # pragma: no cover
+        try:
+            self._req.send(frame)
+            return decode(self._req.recv())
+        except Exception:  # noqa: BLE001  (timeout / peer gone): a REQ socket that missed its reply cannot be reused
+            self._req.close(0)
+            self._req = _zmq.Context.instance().socket(_zmq.REQ)
+            self._req.setsockopt(_zmq.RCVTIMEO, int(self.timeout * 1000))
+            self._req.setsockopt(_zmq.SNDTIMEO, int(self.timeout * 1000))
+            self._req.connect(f"tcp://{self._ip}:{self.config.port_number}")
+            return None
 
     def update(self) -> bool:
         """Send everything the local store received since the last successful update."""
         if self.data_store is None:
             return False
-        latest = self.data_store.latest_data_id()
-        batch = self.data_store.get_latest_data(self.last_sync_data_id)
+        if hasattr(self.data_store, "latest_since"):   # id and items taken atomically: nothing shipped twice, nothing lost
+            latest, batch = self.data_store.latest_since(self.last_sync_data_id)
+        else:   # a foreign DataStoreBase: read the id FIRST -- a concurrent insert is then re-sent, never dropped
+            latest = self.data_store.latest_data_id()
+            batch = self.data_store.get_latest_data(self.last_sync_data_id)
         if not batch:
             return True
         res = self._send({"type": "datastore", "store_name": self.name, "payload": batch})
@@ -303,7 +353,7 @@ class TrainerClient:
                         callback_fn(decode(q.get(timeout=0.05)))
                     except queue.Empty:
                         continue
-        else:  # pragma: no cover
+        else:
             sub = _zmq.Context.instance().socket(_zmq.SUB)
             sub.connect(f"tcp://{self._ip}:{self.config.broadcast_port}")
             sub.setsockopt(_zmq.SUBSCRIBE, b"")
@@ -314,6 +364,7 @@ class TrainerClient:
                 while not self._stop.is_set():
                     if dict(poller.poll(50)).get(sub):
                         callback_fn(decode(sub.recv()))
+                sub.close(0)
         self._sub_thread = threading.Thread(target=loop, name="TrainerClient-sub", daemon=True)
         self._sub_thread.start()
 
@@ -321,3 +372,6 @@ class TrainerClient:
         self._stop.set()
         if self._sub_thread is not None:
             self._sub_thread.join(timeout=5)
+        if self.transport != "loopback" and getattr(self, "_req", None) is not None:
+            self._req.close(0)
+            self._req = None

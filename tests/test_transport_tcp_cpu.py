@@ -1,0 +1,171 @@
+"""CPU: the actor <-> learner endpoint over REAL TCP sockets (transport="zmq"): REQ/REP datastore shipping + requests and
+the PUB/SUB network broadcast of examples/async_drq_sim/async_drq_sim.py:95-108,161-171,202-229,297, i.e. the code path
+that runs between an actor machine and the learner (reference wiring: utils/launcher.py:171-177, data_store.py:83-144).
+The socket layer is pyzmq when installed, else serl_amd/transport/zmtp.py (ZeroMQ's wire protocol in pure Python)."""
+import pickle
+import socket
+import threading
+import time
+
+import numpy as np
+
+from serl_amd.transport import DataStoreBase, QueuedDataStore, TrainerClient, TrainerServer, make_trainer_config
+from serl_amd.transport import endpoint as E
+
+
+class ListStore(DataStoreBase):
+    def __init__(self, capacity):
+        super().__init__(capacity)
+        self.items, self.threads = [], set()
+
+    def insert(self, data):
+        self.items.append(data)
+        self.threads.add(threading.current_thread().name)
+
+    def latest_data_id(self):
+        return len(self.items)
+
+    def get_latest_data(self, from_id):
+        raise NotImplementedError
+
+    def __len__(self):
+        return len(self.items)
+
+
+def _tr(k):
+    return {"observations": {"state": np.full((1, 3), k, np.float32), "front": np.full((1, 128, 128, 3), k % 256, np.uint8)},
+            "actions": np.zeros(2, np.float32), "rewards": np.float32(k), "masks": np.float32(1), "dones": False}
+
+
+def _free_ports():
+    out = []
+    for _ in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        out.append((s, s.getsockname()[1]))
+    for s, _ in out:
+        s.close()
+    return out[0][1], out[1][1]
+
+
+def test_frames_are_real_lz4():
+    assert E.LZ4_BACKEND != "zlib (no lz4 on this host)", "neither the lz4 package nor liblz4 is loadable here"
+    frame = E.encode({"type": "datastore", "payload": [_tr(1)]})
+    assert frame[:4] == b"\x04\x22\x4d\x18"            # LZ4 frame magic number (little-endian 0x184D2204)
+    assert len(frame) < 5000                             # 49 KB of constant pixels compress
+    out = E.decode(frame)
+    assert np.array_equal(out["payload"][0]["observations"]["front"], _tr(1)["observations"]["front"])
+
+
+def test_actor_learner_flow_over_tcp():
+    port, bport = _free_ports()
+    cfg = make_trainer_config(port_number=port, broadcast_port=bport)
+    stats, nets = [], []
+    store = ListStore(1000)
+    server = TrainerServer(cfg, request_callback=lambda t, p: stats.append((t, p)) or {"ack": len(stats)}, transport="zmq",
+                           bind_ip="127.0.0.1")
+    server.register_data_store("actor_env", store)
+    server.start(threaded=True)
+    try:
+        local = QueuedDataStore(2000)
+        client = TrainerClient("actor_env", "127.0.0.1", cfg, local, wait_for_server=True, transport="zmq", timeout=10.0)
+        client.recv_network_callback(lambda p: nets.append(p))
+        for k in range(25):
+            local.insert(_tr(k))
+            if k % 10 == 9:
+                assert client.update()
+        assert len(store) == 20 and [float(d["rewards"]) for d in store.items] == list(range(20))
+        assert store.threads == {"TrainerServer"}       # inserted by the server thread, like agentlace does
+        assert np.array_equal(store.items[7]["observations"]["front"], _tr(7)["observations"]["front"])
+        assert client.request("send-stats", {"episode_return": 1.5}) == {"ack": 1}
+        assert stats == [("send-stats", {"episode_return": 1.5})]
+        assert client.request("no-such-type", {}) is None
+        params = {"modules_actor": {"Dense_0": {"kernel": np.arange(12, dtype=np.float32).reshape(3, 4)}}}
+        deadline = time.time() + 10
+        while not nets and time.time() < deadline:      # PUB/SUB: a subscriber only gets what is published after it joined
+            server.publish_network(params)
+            time.sleep(0.05)
+        assert nets and np.array_equal(nets[0]["modules_actor"]["Dense_0"]["kernel"], params["modules_actor"]["Dense_0"]["kernel"])
+        client.stop()
+    finally:
+        server.stop()
+    assert server.stats["transitions"] == 20 and server.stats["requests"] == 1
+
+
+def test_malformed_frame_gets_an_error_reply_and_the_server_survives():
+    """an exception in decode / handle must not kill the REP loop (every actor would block forever)."""
+    port, bport = _free_ports()
+    cfg = make_trainer_config(port_number=port, broadcast_port=bport)
+    store = ListStore(10)
+
+    class Bad(DataStoreBase):
+        def __init__(self):
+            super().__init__(1)
+
+        def insert(self, data):
+            raise RuntimeError("store exploded")
+
+    server = TrainerServer(cfg, transport="zmq", bind_ip="127.0.0.1")
+    server.register_data_store("ok", store)
+    server.register_data_store("bad", Bad())
+    server.start(threaded=True)
+    try:
+        req = E._zmq.Context.instance().socket(E._zmq.REQ)
+        req.setsockopt(E._zmq.RCVTIMEO, 5000)
+        req.connect(f"tcp://127.0.0.1:{port}")
+        req.send(b"this is not an lz4 frame")
+        r = E.decode(req.recv())
+        assert r["success"] is False and r["message"]
+        req.send(E.encode({"type": "datastore", "store_name": "bad", "payload": [1]}))
+        r = E.decode(req.recv())
+        assert r["success"] is False and "store exploded" in r["message"]
+        req.send(E.encode({"type": "datastore", "store_name": "ok", "payload": [_tr(0)]}))   # still alive
+        assert E.decode(req.recv())["success"] is True and len(store) == 1
+        req.close(0)
+        assert server.stats["errors"] == 2
+    finally:
+        server.stop()
+
+
+def test_update_ships_every_transition_exactly_once_under_concurrent_inserts():
+    port, bport = _free_ports()
+    cfg = make_trainer_config(port_number=port, broadcast_port=bport)
+    store = ListStore(100000)
+    server = TrainerServer(cfg, transport="zmq", bind_ip="127.0.0.1")
+    server.register_data_store("actor_env", store)
+    server.start(threaded=True)
+    try:
+        local = QueuedDataStore(100000)
+        client = TrainerClient("actor_env", "127.0.0.1", cfg, local, wait_for_server=True, transport="zmq", timeout=10.0)
+        stop = threading.Event()
+
+        def env_loop():
+            k = 0
+            while not stop.is_set() and k < 3000:
+                local.insert({"rewards": np.float32(k)})
+                k += 1
+        th = threading.Thread(target=env_loop)
+        th.start()
+        while th.is_alive():
+            assert client.update()
+        th.join()
+        assert client.update()
+        got = [int(d["rewards"]) for d in store.items]
+        assert got == list(range(len(got))) and len(got) == local.latest_data_id() + 1
+        client.stop()
+    finally:
+        stop.set()
+        server.stop()
+
+
+def test_client_without_a_server_times_out_cleanly():
+    port, bport = _free_ports()
+    cfg = make_trainer_config(port_number=port, broadcast_port=bport)
+    t0 = time.time()
+    try:
+        TrainerClient("actor_env", "127.0.0.1", cfg, QueuedDataStore(10), transport="zmq", timeout=0.5)
+    except ConnectionError:
+        pass
+    else:
+        raise AssertionError("handshake without a server must fail")
+    assert time.time() - t0 < 10
