@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--trunk", choices=["f16x3", "f32"], default="f16x3",
                     help="trunk conv arithmetic: split-fp16 MFMA (default, 1.3e-5 of fp64) or exact fp32 MFMA")
+    ap.add_argument("--encoder", choices=["resnet-pretrained", "small"], default="resnet-pretrained",
+                    help="resnet-pretrained: frozen ResNet-10 trunk (the official line); small: the trainable SmallEncoder "
+                         "(vision/small_encoders.py:9-55; the north star's 'small ConvNet') -- side measurement with its own roofline")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="serial order: do not overlap the trunk of batch i+1 with the update of batch i")
     ap.add_argument("--workload", choices=list(WORKLOADS) + ["sac_state", "actor_latency"], default="drq",
@@ -105,7 +108,7 @@ def main():
                     help="which stream gets the high-priority queue; auto: the trunk at large per-rank batches (the update "
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
     ap.add_argument("--update-after-stage", type=int, default=None,
-                    help="start update(i) only when the trunk pass of batch i+1 has finished this residual stage (0..2); "
+                    help="start update(i) only when the trunk pass of batch i+1 has finished this residual stage (0..2; -1 = conv_init + pool); "
                          "default: SERL_UPDATE_AFTER_STAGE or off")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
@@ -185,9 +188,11 @@ def main():
     sample_obs = {k: np.zeros((1, H, W, 3), np.uint8) for k in KEYS}
     sample_obs["state"] = np.zeros((1, S), np.float32)
     agent = make_drq_agent(42, sample_obs, np.zeros((A,), np.float32), image_keys=KEYS,
-                           encoder_type="resnet-pretrained", batch_size=Bl, device=local_rank)
+                           encoder_type=args.encoder, batch_size=Bl, device=local_rank)
     core = agent.core
-    core.set_trunk_mode(args.trunk)
+    small = args.encoder == "small"
+    if not small:
+        core.set_trunk_mode(args.trunk)
     dbs = [DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank) for _ in range(2)]
 
     def gather(parts, co, cn, slot):                     # fused K2+K3+K4 into the slot's device batch
@@ -197,7 +202,7 @@ def main():
     from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
     uas = args.update_after_stage if args.update_after_stage is not None else (
         int(os.environ["SERL_UPDATE_AFTER_STAGE"]) if os.environ.get("SERL_UPDATE_AFTER_STAGE", "") != "" else None)
-    if uas is not None and (uas < 0 or uas > 2 or args.trunk != "f16x3"):
+    if uas is not None and (uas < -1 or uas > 2 or args.trunk != "f16x3"):
         uas = None
     prio = args.prio if args.prio != "auto" else ("trunk" if Bl >= 128 else "update")
     sched = SerialSchedule() if args.no_pipeline else TorchPipelineSchedule(torch.device("cuda", local_rank), prioritise_update=prio == "update",
@@ -274,16 +279,23 @@ def main():
     dt = float(np.median(dts))
     grad_steps = args.steps * car
     value = grad_steps / dt
-    verify = None if (args.no_verify or args.no_pipeline or args.trunk != "f16x3") else verify_features(learner, core, dbs, car)
+    verify = None if (args.no_verify or args.no_pipeline or args.trunk != "f16x3" or small) else verify_features(learner, core, dbs, car)
 
     # ---- roofline of the dominant kernel family (implicit-GEMM convs of the frozen trunk)
     macs = conv_macs_per_image()
     n_img = 2 * len(KEYS) * Bl
     per_kernel, tot_flop, tot_ms = {}, 0.0, 0.0
+    # conv_init + pool finish run over sub-batches of the pass (Infinity-Cache-sized scratch): "conv_init" / "gn_relu_maxpool"
+    # are then per SUB-BATCH launches, "conv_init_pool" the whole pair over the pass
+    ci_parts = 1
+    if "conv_init_pool" in prof and "conv_init" in prof:
+        ci_parts = max(1, int(round(prof["conv_init"][1] / max(prof["conv_init_pool"][1], 1))))
     for tag, (ms, cnt) in sorted(prof.items()):
         ent = {"avg_us": 1e3 * ms / cnt, "timed_launches": cnt}
+        if tag in ("conv_init", "gn_relu_maxpool") and ci_parts > 1:
+            ent["launches_per_pass"] = ci_parts
         if tag in macs:
-            fl = 2.0 * macs[tag] * n_img
+            fl = 2.0 * macs[tag] * n_img / (ci_parts if tag == "conv_init" else 1)
             ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
             if tag.startswith("conv_igemm"):
                 tot_flop += fl * cnt
@@ -334,12 +346,14 @@ def main():
                     "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
                     "flop_per_launch_avg": tot_flop / n_launch, "per_kernel": per_kernel}
+    if small:
+        roofline = small_encoder_roofline(prof, per_kernel, Bl, len(KEYS))
     if "gather_crop" in per_kernel:
         roofline["sample_aug_hbm"] = {"bound": "hbm", "kernel": "gather_crop_rgb_kernel", "achieved": per_kernel["gather_crop"]["TBps"],
                                       "peak": PEAK_HBM, "unit": "TB/s", "frac": per_kernel["gather_crop"]["frac_hbm"]}
 
     out = {
-        "metric": f"learner grad-steps/sec (DrQ, bs{B}, {len(KEYS)}x128x128 img)", "value": round(value, 3),
+        "metric": f"learner grad-steps/sec (DrQ, bs{B}, {len(KEYS)}x128x128 img)" + (" [SmallEncoder]" if small else ""), "value": round(value, 3),
         "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
@@ -350,7 +364,7 @@ def main():
                    "critic_actor_ratio": car, "utd_ratio": 1,
                    "buffers": [{"capacity": c_, "fill": f_, "seed": s_, "samples_per_batch": n_} for c_, f_, s_, n_ in bufspec],
                    "replay_capacity": bufspec[0][0], "replay_fill": bufspec[0][1], "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": car,
-                   "trunk_passes_per_grad_step": 2, "trunk_arithmetic": args.trunk,
+                   "encoder": args.encoder, "trunk_passes_per_grad_step": 0 if small else 2, "trunk_arithmetic": "f32" if small else args.trunk,
                    "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
         "roofline": roofline,
         "repeats": len(dts), "ms_per_step_runs": [round(1e3 * x / args.steps, 4) for x in dts],
@@ -387,6 +401,39 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def small_encoder_flops_per_image(H=H, W=W):
+    """SmallEncoder (vision/small_encoders.py:9-55): 4 x (3x3, stride 2, VALID) convs 3 -> 32 -> 64 -> 128 -> 256 (+ bias column).
+    -> (forward FLOPs, backward FLOPs = weight gradient of every layer + input gradient of layers 1..3) per image."""
+    feat, h, w = (3, 32, 64, 128, 256), H, W
+    fwd = bwd = 0
+    for l in range(4):
+        h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        fl = 2 * h * w * 9 * feat[l] * feat[l + 1]
+        fwd += fl
+        bwd += fl * (2 if l > 0 else 1)
+    return fwd, bwd
+
+
+def small_encoder_roofline(prof, per_kernel, Bl, n_cam):
+    """Roofline of the trainable SmallEncoder's conv stack: every launch group `small_encoder_fwd` is one pass of
+    n_cam * Bl images through the four convs (im2col + fp32-MFMA GEMM + ReLU), `small_encoder_bwd` one backward pass."""
+    fwd, bwd = small_encoder_flops_per_image()
+    tot_fl = tot_ms = 0.0
+    for tag, fl in (("small_encoder_fwd", fwd), ("small_encoder_bwd", bwd)):
+        if tag in prof:
+            ms, cnt = prof[tag]
+            per_kernel[tag]["tflops"] = round(fl * n_cam * Bl / (ms / cnt * 1e-3) / 1e12, 3)
+            tot_fl += fl * n_cam * Bl * cnt
+            tot_ms += ms
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": "SmallEncoder conv stack: small_im2col + gemm_f32_kernel (exact fp32 MFMA 32x32x2) + ReLU / col2im, "
+            "forward x3 per critic step and x3 per actor step, backward x1 per critic step", "achieved": round(ach, 3),
+            "peak": PEAK_F32_MFMA, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+            "flop_per_image": {"forward": fwd, "backward": bwd}, "per_kernel": per_kernel,
+            "note": "durations are HIP events around the whole pass (im2col + GEMM + elementwise launches of the four layers); the im2col "
+                    "matrices are materialised in HBM, which is what bounds these passes, not the matrix pipe"}
 
 
 def verify_features(learner, core, dbs, car, iters=12, tol=2e-6):

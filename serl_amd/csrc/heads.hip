@@ -3,6 +3,7 @@
 // SpatialLearnedEmbeddings, tanh-Gaussian policy head, REDQ target, losses, 3x Adam + target EMA).
 // Reference semantics are cited per kernel (paths relative to serl_launcher/serl_launcher/).
 #include <algorithm>
+#include <cstdlib>
 
 #include "heads.h"
 #include "prof.h"
@@ -160,6 +161,185 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
   }
 }
 
+// =============================================================================================
+// The same GEMM on the bf16 matrix pipe: "bf16x3".  Every fp32 operand is split EXACTLY into three bf16 pieces
+//     x = x0 + x1 + x2,   x0 = trunc16(x), x1 = trunc16(x - x0), x2 = x - x0 - x1
+// (bf16 keeps fp32's exponent and 8 significant bits: three truncations peel off all 24 bits of the significand, and
+// each remainder is exact in fp32), and the product a*b is taken as the six piece products with i + j <= 2
+//     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)
+// on v_mfma_f32_32x32x16_bf16, accumulated in fp32; the three dropped products are below 3 * 2^-24 |a b|, i.e. at fp32
+// round-off.  Unlike the trunk's split-fp16 scheme this needs NO operand scaling (bf16 has the range of fp32), so it takes
+// activations, weights and back-propagated gradients (1e-3 .. 1e-9) alike: 6 MFMAs of 32 cycles per 32x32x16 block
+// instead of 8 of 64 -- 2.7x less time on the matrix pipe, which the update chain shares with the frozen trunk of the
+// next batch on the other stream.  Same descriptor, grid, K-split and epilogue as gemm_f32_kernel (drop-in).
+// LDS: per operand three planes [64 rows][32 k] bf16 (64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3:
+// conflict-free ds_read_b128 fragments, as in the trunk kernels).  A k-contiguous operand arrives as 16-byte global
+// vectors (4 k of one row -> one 8-byte store per plane); a row-contiguous operand as eight coalesced 4-byte loads per
+// thread (8 consecutive k of one row, 64 consecutive rows per wave instruction -> one 16-byte store per plane).
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// byte offset of 16-byte slot `slot` of tile row `row` in a bf16 plane with BK k's per row (BK = 32: 64-byte rows, slots
+// XOR-ed with (row >> 2) & 3; BK = 16: 32-byte rows, slots XOR-ed with (row >> 3) & 1) -- conflict-free ds_read_b128
+// fragments for the lane groups of MI355X_MICROARCH.md (rows {0-3, 12-15, 20-27} etc. land on 64 distinct banks)
+template <int BK>
+__device__ __forceinline__ int xswz(int row, int slot) {
+  return BK == 32 ? row * 64 + ((slot ^ ((row >> 2) & 3)) << 4) : row * 32 + ((slot ^ ((row >> 3) & 1)) << 4);
+}
+
+// two fp32 values -> their three bf16 pieces, packed (first value in the low half)
+__device__ __forceinline__ void split3(float v, float w, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned a0 = __builtin_bit_cast(unsigned, v) & 0xffff0000u, b0 = __builtin_bit_cast(unsigned, w) & 0xffff0000u;
+  const float r1 = v - __builtin_bit_cast(float, a0), s1 = w - __builtin_bit_cast(float, b0);
+  const unsigned a1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u, b1 = __builtin_bit_cast(unsigned, s1) & 0xffff0000u;
+  const float r2 = r1 - __builtin_bit_cast(float, a1), s2 = s1 - __builtin_bit_cast(float, b1);
+  p0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
+  p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+  p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, r2), 0x07060302u);
+}
+
+// One operand tile of 64 rows x BK k's per chunk.  KFAST: 16-byte global vectors along k (BK / 16 per thread); otherwise
+// BK / 4 coalesced 4-byte loads per thread: tile row tid & 63, k's (BK / 4) * (tid >> 6) + j.
+template <bool KFAST, int BK>
+struct XLoader {
+  static constexpr int NV = KFAST ? BK / 16 : 1;   // global vectors per thread (KFAST)
+  static constexpr int NE = BK / 4;                // floats per thread per chunk
+  static constexpr int kPlane = kGBM * BK * 2;     // bytes of one bf16 plane
+  const float* p[NV];
+  int ok[NV];   // this thread's row exists
+  long sK;
+  int row0, kq;   // !KFAST: tile row of this thread, first k of its group
+  __device__ __forceinline__ void init(const float* X, long sR, long sK_, int r0, int R, int k_begin, int tid) {
+    sK = sK_;
+    if (KFAST) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, r = idx / (BK / 4);
+        ok[i] = r0 + r < R;
+        p[i] = X + (long)(r0 + r) * sR + k_begin + 4 * (idx % (BK / 4));
+      }
+    } else {
+      row0 = tid & 63; kq = NE * (tid >> 6);
+      ok[0] = r0 + row0 < R;
+      p[0] = X + (long)(k_begin + kq) * sK + r0 + row0;
+    }
+  }
+  // the chunk starting at k0 (elements at k >= k_end are zero); advances to the next chunk
+  __device__ __forceinline__ void load(float (&r)[NE], int k0, int k_end) {
+    if (KFAST) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int krem = k_end - (k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4)));
+        const f32x4 v = ld4(p[i], ok[i] ? krem : 0);
+        r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+        p[i] += BK;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) r[j] = (ok[0] && k0 + kq + j < k_end) ? p[0][(long)j * sK] : 0.f;
+      p[0] += (long)BK * sK;
+    }
+  }
+  __device__ __forceinline__ void store(uint8_t* S, const float (&r)[NE], int tid) const {
+    if (KFAST) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, row = idx / (BK / 4), k4 = idx % (BK / 4);
+        unsigned q0[2], q1[2], q2[2];
+        split3(r[4 * i], r[4 * i + 1], q0[0], q1[0], q2[0]);
+        split3(r[4 * i + 2], r[4 * i + 3], q0[1], q1[1], q2[1]);
+        const int off = xswz<BK>(row, k4 >> 1) + (k4 & 1) * 8;
+        *reinterpret_cast<u32x2*>(S + off) = (u32x2){q0[0], q0[1]};
+        *reinterpret_cast<u32x2*>(S + kPlane + off) = (u32x2){q1[0], q1[1]};
+        *reinterpret_cast<u32x2*>(S + 2 * kPlane + off) = (u32x2){q2[0], q2[1]};
+      }
+    } else if (NE == 8) {
+      unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(r[2 * j], r[2 * j + 1], q0[j], q1[j], q2[j]);
+      const int off = xswz<BK>(row0, kq >> 3);
+      *reinterpret_cast<u32x4*>(S + off) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
+      *reinterpret_cast<u32x4*>(S + kPlane + off) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
+      *reinterpret_cast<u32x4*>(S + 2 * kPlane + off) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
+    } else {   // 4 k's: half a slot
+      unsigned q0[2], q1[2], q2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) split3(r[2 * j], r[2 * j + 1], q0[j], q1[j], q2[j]);
+      const int off = xswz<BK>(row0, kq >> 3) + ((kq >> 2) & 1) * 8;
+      *reinterpret_cast<u32x2*>(S + off) = (u32x2){q0[0], q0[1]};
+      *reinterpret_cast<u32x2*>(S + kPlane + off) = (u32x2){q1[0], q1[1]};
+      *reinterpret_cast<u32x2*>(S + 2 * kPlane + off) = (u32x2){q2[0], q2[1]};
+    }
+  }
+};
+
+// BK = 16: 12 KB of LDS per workgroup -- the update chain's GEMMs run BESIDE the frozen trunk of the next batch, whose
+// conv workgroups own 131-152 KB of a CU's 160 KB: a 12 KB workgroup fits next to two row-slab (140 KB) or two LDS-DMA
+// (131 KB) conv workgroups instead of waiting for one of them to retire and taking its place.
+template <bool A_KFAST, bool B_KFAST, int BK>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
+  constexpr int kPlane = kGBM * BK * 2;
+  __shared__ __attribute__((aligned(16))) uint8_t As[3 * kPlane];
+  __shared__ __attribute__((aligned(16))) uint8_t Bs[3 * kPlane];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int grp = 0;
+  while (grp + 1 < mm.n && (int)blockIdx.z >= mm.zend[grp]) ++grp;
+  const GemmDesc& g = mm.d[grp];
+  const int z = blockIdx.z - (grp ? mm.zend[grp - 1] : 0), batch = z / g.splitk, split = z - batch * g.splitk;
+  const int m0 = blockIdx.y * kGBM, n0 = blockIdx.x * kGBN;
+  if (m0 >= g.M || n0 >= g.N) return;
+  const int kper = ((g.K + g.splitk - 1) / g.splitk + kGBK - 1) / kGBK * kGBK;   // (same K partition as the fp32 kernel)
+  const int k_begin = split * kper, k_end = min(g.K, k_begin + kper);
+  float* C = g.C + (long)z * g.sCz;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, lh = lane >> 5;
+  if (k_begin < k_end) {
+    XLoader<A_KFAST, BK> la;
+    XLoader<B_KFAST, BK> lb;
+    la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
+    lb.init(g.B + (long)batch * g.sBb, g.sBn, g.sBk, n0, g.N, k_begin, tid);
+    float ra[BK / 4], rb[BK / 4];
+    la.load(ra, k_begin, k_end);
+    lb.load(rb, k_begin, k_end);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+      la.store(As, ra, tid);
+      lb.store(Bs, rb, tid);
+      __syncthreads();
+      la.load(ra, k0 + BK, k_end);  // past k_end: zeros, nothing is dereferenced
+      lb.load(rb, k0 + BK, k_end);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int ao = xswz<BK>(wm * 32 + li, 2 * ks + lh), bo = xswz<BK>(wn * 32 + li, 2 * ks + lh);
+        bf16x8 a[3], b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          a[pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + ao);
+          b[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + bo);
+        }
+        // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int n = n0 + wn * 32 + li;
+    if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[r];
+  }
+}
+
 // arbitrary element strides: scalar loads, [k][m] LDS tiles
 __global__ __launch_bounds__(256) void gemm_f32_strided_kernel(GemmDesc g) {
   constexpr int BK = 16, P = 68, LD = kGBM * BK / 256;
@@ -204,13 +384,17 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   GemmMulti mm{};
   mm.n = n;
   int gx = 0, gy = 0, z = 0;
-  const bool a_k = gs[0].sAk == 1, a_m = gs[0].sAm == 1, b_k = gs[0].sBk == 1, b_n = gs[0].sBn == 1;
+  // one kernel instantiation per launch: a layout every group supports (a one-row / one-column operand fits both)
+  bool a_k = true, a_m = true, b_k = true, b_n = true;
+  for (int i = 0; i < n; ++i) {
+    a_k = a_k && gs[i].sAk == 1; a_m = a_m && gs[i].sAm == 1;
+    b_k = b_k && gs[i].sBk == 1; b_n = b_n && gs[i].sBn == 1;
+  }
   const bool vec = (a_k || a_m) && (b_k || b_n);
+  SERL_REQUIRE(vec || n == 1, "mixed operand layouts in a GEMM group");
   for (int i = 0; i < n; ++i) {
     const GemmDesc& g = gs[i];
     SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
-    if (vec)  // one kernel instantiation per launch: every group must have the layout of the first
-      SERL_REQUIRE((a_k ? g.sAk == 1 : g.sAm == 1) && (b_k ? g.sBk == 1 : g.sBn == 1), "mixed operand layouts in a GEMM group");
     mm.d[i] = g;
     gx = std::max(gx, cdiv(g.N, kGBN));
     gy = std::max(gy, cdiv(g.M, kGBM));
@@ -218,7 +402,20 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
     mm.zend[i] = z;
   }
   dim3 grid(gx, gy, z);
-  if (vec) {
+  // SERL_GEMM=f32: the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) instead of bf16x3 -- A/B timing and parity runs
+  static const bool exact = []() { const char* e = getenv("SERL_GEMM"); return e && e[0] == 'f'; }();
+  static const bool bk32 = []() { const char* e = getenv("SERL_GEMM_BK"); return e && atoi(e) == 32; }();
+  if (vec && !exact && bk32) {
+    if (a_k && b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 32>), grid, dim3(256), 0, stream, mm);
+    else if (a_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, 32>), grid, dim3(256), 0, stream, mm);
+    else if (b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 32>), grid, dim3(256), 0, stream, mm);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 32>), grid, dim3(256), 0, stream, mm);
+  } else if (vec && !exact) {
+    if (a_k && b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
+    else if (a_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);
+    else if (b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 16>), grid, dim3(256), 0, stream, mm);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 16>), grid, dim3(256), 0, stream, mm);
+  } else if (vec) {
     if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
     else if (a_k) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
     else if (b_k) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);

@@ -1367,7 +1367,8 @@ constexpr int kC8K = 224;                    // 7 kernel rows x 8 pixel slots x 
 constexpr int kC8WP = 232;                   // LDS pitch of a weight row (halfs): 464 B -> conflict-free ds_read_b128
 constexpr int kC8Pitch = 384;                // LDS pitch of a patch row (bytes) = 48 pixel slots
 constexpr int kC8WBytes = 64 * kC8WP * 2;    // one weight plane
-constexpr int kC8PBytes = 16384;             // patch (37 x 384 = 14208 B) / pooling stage (16 KB)
+constexpr int kC8PBytes = 14336;             // patch (37 x 384 = 14208 B) / row-exchange buffer of the pooling stage (8 KB); two
+                                             // workgroups = 144 KB, which leaves room for one 12 KB update-chain GEMM workgroup
 constexpr int kC8Lds = 2 * kC8WBytes + kC8PBytes;
 static_assert(kCbPatch * kC8Pitch <= kC8PBytes, "patch does not fit");
 
@@ -2159,6 +2160,20 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   return SERL_OK;
 }
 
+// Zeroes the statistics / arrival counters / tickets of a pass with SYSTEM-scope (write-through, sc0 sc1) 16-byte stores.
+// Everything that touches these words afterwards is a memory-side atomic (stats_flush, fused_arrive_and_wait, fused_tile),
+// so the zeroes must be AT the memory side too and no cache may keep a copy: a plain-store zeroing kernel (round 2, reverted
+// after one unexplained parity failure) leaves the zeroed lines dirty in the L2 of whichever XCD ran the store until that
+// L2 writes them back -- ordered against the next kernel only by the launch boundary's cache maintenance, i.e. outside the
+// "memory-side accesses only" rule the fused epilogues rely on.  hipMemsetAsync (the blit kernel, 19 us for 1.3 MB) has the
+// same property; this kernel takes ~3 us and keeps the rule by construction.
+__global__ __launch_bounds__(256) void zero_sys_kernel(void* p, long n16) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7fffffff, 0x00020000);
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256)
+    __builtin_amdgcn_raw_buffer_store_b128(z, r, (int)(i * 16), 0, 17 /* sc0 | sc1 */);
+}
+
 static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta, int P, int Cc) {
   GnRef g{};
   g.stats = stats; g.gamma = gamma; g.beta = beta;
@@ -2175,7 +2190,16 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   // (the intermediate activations live in the workspace), which lets the caller put an event between them
   const TrunkDims& d = ws.d;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
-  if (stage_begin < 0) SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));   // statistics + arrival counters + tickets
+  if (stage_begin < 0) {   // statistics + arrival counters + tickets
+    static const bool zero_kernel = []() { const char* e = getenv("SERL_ZERO_KERNEL"); return !(e && e[0] == '0'); }();
+    if (zero_kernel && ws.stats_sync_bytes % 16 == 0 && ws.stats_sync_bytes < ((size_t)1 << 31)) {
+      const long n16 = (long)(ws.stats_sync_bytes / 16);
+      hipLaunchKernelGGL(zero_sys_kernel, dim3((unsigned)std::min<long>(cdiv(n16, 256), 512)), dim3(256), 0, stream, (void*)ws.stats, n16);
+      SERL_HIP(hipGetLastError());
+    } else {
+      SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));
+    }
+  }
   auto fuse_of = [&](int layer, int mode) {
     FuseArgs f{};
     const char* e = getenv("SERL_GN_FUSE");   // read per pass: tests flip it inside one process
