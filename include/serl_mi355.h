@@ -87,8 +87,10 @@ int serl_rb_sample_indices(serl_rb* rb, int batch, int64_t* host_idx_out);
 /* gather of sample(pack_obs_and_next_obs=True) (memory_efficient_replay_buffer.py:126-164,
  * dataset.py:40-51).  dev outputs:  frames_out[c] u8[batch][T+1][H][W][C];
  * state_out/next_state_out f32[batch][T*S]; action_out f32[batch][A]; reward_out, mask_out
- * f32[batch]; done_out u8[batch].  host_idx: int64[batch] (slot indices). */
-int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
+ * f32[batch]; done_out u8[batch].  host_idx: int64[batch] slot indices, IN/OUT: an index whose slot an insert has invalidated
+ * since it was drawn is re-drawn (from the buffer's generator) and written back, so the array always describes the batch
+ * that was gathered.  Gathers may be issued from several streams; an insert that overwrites a slot waits for all of them. */
+int serl_rb_gather_packed(serl_rb* rb, int64_t* host_idx, int batch,
                           uint8_t* const* dev_frames_out, float* dev_state_out,
                           float* dev_next_state_out, float* dev_action_out,
                           float* dev_reward_out, float* dev_mask_out, uint8_t* dev_done_out,
@@ -113,8 +115,9 @@ typedef struct serl_batch {
  * memory_efficient_replay_buffer.py:126-164 + utils/train_utils.py:16-31,44-66 +
  * vision/data_augmentations.py:7-36 + agents/continuous/drq.py:244-253 (same offsets for every
  * camera).  Samples [0,counts[0]) come from rbs[0], the next counts[1] from rbs[1] (RLPD 50/50).
- * host_crop_obs / host_crop_next: int32[batch][2] = (dy,dx) in [0,8]; NULL = no shift (4,4). */
-int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* host_idx,
+ * host_crop_obs / host_crop_next: int32[batch][2] = (dy,dx) in [0,8]; NULL = no shift (4,4).
+ * host_idx[b]: IN/OUT like serl_rb_gather_packed's (stale indices are re-drawn in place). */
+int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, int64_t* const* host_idx,
                         const int* counts, const int32_t* host_crop_obs,
                         const int32_t* host_crop_next, const serl_batch* out, void* stream);
 

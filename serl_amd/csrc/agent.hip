@@ -135,9 +135,8 @@ struct serl_agent {
 namespace {
 
 constexpr int kSleSplit = 8;
-// rows up to which the parameter-gradient kernels of a phase are deferred (default: always; SERL_PG_DEFER_ROWS=0 issues
-// them layer by layer: measured 3 % slower at a per-rank batch of 32, equal at 256)
-static const int kPgDeferMaxRows = []() { const char* e = getenv("SERL_PG_DEFER_ROWS"); return e ? atoi(e) : (1 << 30); }();
+// the parameter-gradient kernels of a phase are always deferred to the end of the phase (issuing them layer by layer was
+// measured 3 % slower at a per-rank batch of 32, equal at 256)
 
 size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -366,7 +365,7 @@ size_t carve(serl_agent* a, void* base) {
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
 int split_for(int M, int N, int groups, int smax) {
-  static const int budget = []() { const char* e = getenv("SERL_GEMM_BLOCKS"); return e ? std::max(atoi(e), 1) : 512; }();
+  constexpr long budget = 512;
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -990,7 +989,7 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   }
   for (int k = 0; k < m_sub; ++k) SERL_REQUIRE(sel.idx[k] >= 0 && sel.idx[k] < c.ensemble, "REDQ index out of range");
   a->pg_ncs = a->pg_nwg = 0;
-  a->pg_defer = cnt <= kPgDeferMaxRows;
+  a->pg_defer = true;
   const float* eps; const uint8_t* mask;
   NoiseBatch nb;
   fetch_noise(a, nb, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask);
@@ -1036,7 +1035,7 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   const int cnt = a->cur.batch, A = c.act_dim, Hd = c.hidden;
   SERL_REQUIRE(global_count >= cnt, "global_count < local batch");
   a->pg_ncs = a->pg_nwg = 0;
-  a->pg_defer = cnt <= kPgDeferMaxRows;
+  a->pg_defer = true;
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
   NoiseBatch nb;
   fetch_noise(a, nb, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi);

@@ -27,7 +27,6 @@ struct TrunkDims {
 TrunkDims trunk_dims(int H, int W);
 
 constexpr int kSyncPerImage = 8, kSyncTickets = 16;
-constexpr size_t kSplitKBytes = (size_t)48 << 20;
 struct TrunkWorkspace {
   int max_images = 0;
   TrunkDims d{};
@@ -39,8 +38,6 @@ struct TrunkWorkspace {
   double* stats = nullptr;  // 13 GN layers x [N][4][2]
   int* sync = nullptr;      // directly behind `stats` (one memset): 13 layers x (kSyncPerImage arrival counters per image + kSyncTickets ints)
   size_t stats_sync_bytes = 0;
-  float* splitk = nullptr;  // partial-sum slabs of K-split convs (small M only)
-  size_t splitk_bytes = 0;
   void* base = nullptr;     // single allocation backing everything above
   size_t bytes = 0;
 };

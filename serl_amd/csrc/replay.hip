@@ -90,7 +90,14 @@ struct serl_rb {
   std::mutex mu;
   // stream/event plumbing
   hipStream_t copy_stream = nullptr;
-  hipEvent_t last_gather = nullptr;
+  // one "last gather" event per stream that gathers from this buffer (the learner's update stream, its prefetch side
+  // stream, ...): an overwriting insert waits for ALL of them
+  static constexpr int kGatherStreams = 4;
+  hipEvent_t gather_ev[kGatherStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t gather_stream[kGatherStreams] = {nullptr, nullptr, nullptr, nullptr};
+  bool gather_used[kGatherStreams] = {false, false, false, false};
+  bool gather_pend[kGatherStreams] = {false, false, false, false};
+  int gather_rr = 0;
   bool gather_pending = false;
   // inserts are staged through a pinned ring and copied asynchronously on copy_stream: the caller's thread (the
   // actor-facing server thread of data_store.py:104-106) holds the mutex for a host memcpy only, never for a stream
@@ -384,9 +391,34 @@ __global__ __launch_bounds__(256) void gather_packed_kernel(PackedArgs a) {
 // for the last enqueued gather.  Caller holds rb->mu.
 static int order_after_gathers(serl_rb* rb) {
   if (rb->gather_pending) {
-    SERL_HIP(hipStreamWaitEvent(rb->copy_stream, rb->last_gather, 0));
+    for (int k = 0; k < serl_rb::kGatherStreams; ++k)
+      if (rb->gather_pend[k]) {
+        SERL_HIP(hipStreamWaitEvent(rb->copy_stream, rb->gather_ev[k], 0));
+        rb->gather_pend[k] = false;
+      }
     rb->gather_pending = false;
   }
+  return SERL_OK;
+}
+// records "a gather of this buffer was enqueued on `stream`".  Caller holds rb->mu.
+static int note_gather(serl_rb* rb, hipStream_t stream) {
+  int k = -1;
+  for (int i = 0; i < serl_rb::kGatherStreams && k < 0; ++i)
+    if (rb->gather_used[i] && rb->gather_stream[i] == stream) k = i;
+  if (k < 0) {   // a stream not seen before: take an entry with nothing pending, else recycle round-robin (the copy stream
+                 // first waits for the recycled entry's gather, so nothing is forgotten)
+    for (int i = 0; i < serl_rb::kGatherStreams && k < 0; ++i)
+      if (!rb->gather_pend[i]) k = i;
+    if (k < 0) {
+      k = rb->gather_rr = (rb->gather_rr + 1) % serl_rb::kGatherStreams;
+      SERL_HIP(hipStreamWaitEvent(rb->copy_stream, rb->gather_ev[k], 0));
+    }
+    rb->gather_stream[k] = stream;
+    rb->gather_used[k] = true;
+  }
+  SERL_HIP(hipEventRecord(rb->gather_ev[k], stream));
+  rb->gather_pend[k] = true;
+  rb->gather_pending = true;
   return SERL_OK;
 }
 // ... and a gather enqueued after an insert sees it: `stream` waits for the last insert's copies.  Caller holds rb->mu.
@@ -511,7 +543,7 @@ int serl_rb_create(int device, int64_t capacity, int n_cam, int H, int W, int C,
   }
   SERL_HIP(hipMalloc((void**)&rb->rec, (size_t)capacity * rb->rec_len * sizeof(float)));
   SERL_HIP(hipStreamCreateWithFlags(&rb->copy_stream, hipStreamNonBlocking));
-  SERL_HIP(hipEventCreateWithFlags(&rb->last_gather, hipEventDisableTiming));
+  for (int k = 0; k < serl_rb::kGatherStreams; ++k) SERL_HIP(hipEventCreateWithFlags(&rb->gather_ev[k], hipEventDisableTiming));
   SERL_HIP(hipEventCreateWithFlags(&rb->last_insert, hipEventDisableTiming));
   rb->ins_slot_bytes = ((sizeof(float) * rb->rec_len + 255) & ~(size_t)255) + (size_t)n_cam * rb->frame_bytes;
   SERL_HIP(hipHostMalloc((void**)&rb->ins_host, rb->ins_slot_bytes * kInsRing, hipHostMallocDefault));
@@ -536,7 +568,8 @@ int serl_rb_destroy(serl_rb* rb) {
   if (rb->stage_dev) (void)hipFree(rb->stage_dev);
   for (int s = 0; s < kRing; ++s)
     if (rb->stage_done[s]) (void)hipEventDestroy(rb->stage_done[s]);
-  if (rb->last_gather) (void)hipEventDestroy(rb->last_gather);
+  for (int k = 0; k < serl_rb::kGatherStreams; ++k)
+    if (rb->gather_ev[k]) (void)hipEventDestroy(rb->gather_ev[k]);
   if (rb->last_insert) (void)hipEventDestroy(rb->last_insert);
   if (rb->ins_host) (void)hipHostFree(rb->ins_host);
   for (int s = 0; s < kInsRing; ++s)
@@ -672,18 +705,19 @@ int serl_rb_sample_indices(serl_rb* rb, int batch, int64_t* host_idx_out) {
 // valid pairs with slot-1 consistently (writes are sequential), so validity is the whole check: stale indices are
 // re-drawn from the buffer's generator under the lock, exactly as the rejection loop would have.  `out` stays empty
 // when nothing changed.  Caller holds rb->mu.
-static int revalidate(serl_rb* rb, const int64_t* idx, int n, std::vector<int64_t>& out) {
+// An index drawn before an insert invalidated its slot is re-drawn here, IN PLACE: the caller's array then describes the
+// batch that is actually gathered (index-keyed bookkeeping and determinism checks stay valid).
+static int revalidate(serl_rb* rb, int64_t* idx, int n) {
   if (rb->n_cam == 0) return SERL_OK;   // plain ReplayBuffer: every slot below `size` is valid
   for (int i = 0; i < n; ++i) {
     if (rb->valid[idx[i]]) continue;
-    if (out.empty()) out.assign(idx, idx + n);
     SERL_REQUIRE(rb->rng.seeded, "replay buffer RNG not seeded");
     const uint32_t sz = (uint32_t)rb->size;
     int guard = 0;
     do {
-      out[i] = rb->rng.bounded(sz);
+      idx[i] = rb->rng.bounded(sz);
       SERL_REQUIRE(++guard < (1 << 24), "no valid slot found while re-drawing a stale index");
-    } while (!rb->valid[out[i]]);
+    } while (!rb->valid[idx[i]]);
   }
   return SERL_OK;
 }
@@ -698,7 +732,7 @@ static int check_indices(serl_rb* rb, const int64_t* idx, int n) {
   return SERL_OK;
 }
 
-int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
+int serl_rb_gather_packed(serl_rb* rb, int64_t* host_idx, int batch,
                           uint8_t* const* dev_frames_out, float* dev_state_out,
                           float* dev_next_state_out, float* dev_action_out, float* dev_reward_out,
                           float* dev_mask_out, uint8_t* dev_done_out, void* stream_) {
@@ -709,9 +743,7 @@ int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
   SERL_HIP(hipSetDevice(rb->device));
   int rc = check_indices(rb, host_idx, batch);
   if (rc) return rc;
-  std::vector<int64_t> fresh;
-  if ((rc = revalidate(rb, host_idx, batch, fresh))) return rc;
-  if (!fresh.empty()) host_idx = fresh.data();
+  if ((rc = revalidate(rb, host_idx, batch))) return rc;
   if ((rc = order_after_inserts(rb, stream))) return rc;
   const void* srcs[1] = {host_idx};
   size_t sizes[1] = {sizeof(int64_t) * (size_t)batch}, offs[1];
@@ -736,16 +768,13 @@ int serl_rb_gather_packed(serl_rb* rb, const int64_t* host_idx, int batch,
   hipLaunchKernelGGL(gather_packed_kernel, dim3(a.n_frame_blocks + rec_blocks), dim3(256), 0, stream, a);
   SERL_HIP(hipGetLastError());
   SERL_HIP(hipEventRecord(rb->stage_done[slot], stream));
-  SERL_HIP(hipEventRecord(rb->last_gather, stream));
-  rb->gather_pending = true;
-  return SERL_OK;
+  return note_gather(rb, stream);
 }
 
 static int launch_gather_crop(GatherArgs& a, hipStream_t stream) {
   const int rec_blocks = a.from_packed ? 0 : cdiv((long)a.batch * a.rec_len, 256);
   ProfScope prof("gather_crop", stream);
-  static const bool lds_path = [] { const char* e = getenv("SERL_GATHER_LDS"); return e && atoi(e) != 0; }();
-  if (a.C == 3 && (a.W * 3) % 16 == 0 && a.W * 3 >= 32 && !lds_path) {
+  if (a.C == 3 && (a.W * 3) % 16 == 0 && a.W * 3 >= 32) {   // RGB rows of whole 16-byte vectors: the LDS-free kernel
     const int nvec = a.H * (a.W * 3 / 16);
     a.n_frame_blocks = 2 * a.n_cam * a.batch * cdiv(nvec, 256 * kDirectVec);
     hipLaunchKernelGGL(gather_crop_rgb_kernel, dim3(a.n_frame_blocks + rec_blocks), dim3(256), 0, stream, a);
@@ -761,7 +790,7 @@ static int launch_gather_crop(GatherArgs& a, hipStream_t stream) {
   return SERL_OK;
 }
 
-int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* host_idx,
+int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, int64_t* const* host_idx,
                         const int* counts, const int32_t* host_crop_obs,
                         const int32_t* host_crop_next, const serl_batch* out, void* stream_) {
   SERL_REQUIRE(rbs && host_idx && counts && out, "NULL argument");
@@ -800,13 +829,12 @@ int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* hos
     l0.lock();
   }
   SERL_HIP(hipSetDevice(r0->device));
-  std::vector<int64_t> fresh[SERL_MAX_BUFFERS];
   const int64_t* use_idx[SERL_MAX_BUFFERS] = {nullptr};
   for (int b = 0; b < n_rb; ++b) {
     int rc = check_indices(rbs[b], host_idx[b], counts[b]);
     if (rc) return rc;
-    if ((rc = revalidate(rbs[b], host_idx[b], counts[b], fresh[b]))) return rc;
-    use_idx[b] = fresh[b].empty() ? host_idx[b] : fresh[b].data();
+    if ((rc = revalidate(rbs[b], host_idx[b], counts[b]))) return rc;
+    use_idx[b] = host_idx[b];
     if ((rc = order_after_inserts(rbs[b], stream))) return rc;
   }
   const void* srcs[4] = {use_idx[0], n_rb > 1 ? use_idx[1] : nullptr, host_crop_obs, host_crop_next};
@@ -837,8 +865,8 @@ int serl_rb_gather_crop(serl_rb* const* rbs, int n_rb, const int64_t* const* hos
   if (rc) return rc;
   SERL_HIP(hipEventRecord(r0->stage_done[slot], stream));
   for (int b = 0; b < n_rb; ++b) {
-    SERL_HIP(hipEventRecord(rbs[b]->last_gather, stream));
-    rbs[b]->gather_pending = true;
+    int rc2 = note_gather(rbs[b], stream);
+    if (rc2) return rc2;
   }
   return SERL_OK;
 }

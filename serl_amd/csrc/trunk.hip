@@ -458,9 +458,7 @@ static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int 
   const size_t stats_bytes = al256((size_t)kGnLayers * N * kGnGroups * 2 * sizeof(double));
   const size_t sync_bytes = (size_t)kGnLayers * ((size_t)N * kSyncPerImage + kSyncTickets) * sizeof(int);
   double* stats = (double*)take(stats_bytes + sync_bytes);
-  float* splitk = (float*)take(kSplitKBytes);
   if (ws) {
-    ws->splitk = splitk; ws->splitk_bytes = kSplitKBytes;
     ws->sync = base ? (int*)(base + ((uint8_t*)stats - base) + stats_bytes) : nullptr;
     ws->stats_sync_bytes = stats_bytes + sync_bytes;
     ws->max_images = N; ws->d = d; ws->raw_init = raw_init; ws->pool = pool;

@@ -48,7 +48,6 @@ struct FuseArgs {
   int* sync;                // [image][tiles_n] arrival counters, zeroed with the statistics
   int* ticket;              // [8] per-XCD tile counters, zeroed with the statistics
   int group;                // G: tiles (workgroups) per image -- tickets of one image are consecutive
-  int tmode;                // ticket -> tile map: 0 per-XCD counters (default), 1 one counter + xcd_remap(ticket) (round 2), 2 one counter, image-consecutive
   GnRef gn;                 // this conv's statistics (being produced), scale, bias
   GnRef res_gn;             // mode 3: the projection's GroupNorm (complete: that conv ran before)
   const uint8_t* res_split; // mode 2: the block input (split8)
@@ -65,9 +64,6 @@ struct ConvArgsB {
   const uint16_t* wslab; // row-slab kernel: the planes in its fetch order (pack_slab_order_f16x3) or nullptr
   const uint16_t* wdma;  // LDS-DMA kernel: the planes in its piece order (pack_dma_order_f16x3) or nullptr
   int K;
-  int ksplit;           // register-staged kernel only: K-split factor (1 = off)
-  size_t slab_stride;   // elements between the partial-sum slabs of a K-split launch
-  int dbg;              // timing experiments only (SERL_CONV_DBG): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no LDS reads
 };
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -101,10 +97,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot
 // finds a tile within one round over the 8 counters.
 __device__ __forceinline__ int fused_tile(const FuseArgs& fz, int ntiles) {
   __shared__ int s_tile;
-  if (threadIdx.x == 0 && fz.tmode != 0) {   // measurement variants (SERL_TICKET_MODE)
-    const int t = __hip_atomic_fetch_add(fz.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    s_tile = fz.tmode == 1 ? xcd_remap(t, ntiles) : xcd_remap(t / fz.group, ntiles / fz.group) * fz.group + t % fz.group;
-  } else if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {
     const int G = fz.group, ngroups = ntiles / G, gq = ngroups >> 3, gr = ngroups & 7;
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -281,11 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // K-split (ab.ksplit > 1, small M): `ksplit` neighbouring workgroups share a tile and take consecutive chunk ranges;
-  // each writes its partial sums into its own slab (deterministic), splitk_reduce_stats_kernel adds the slabs
-  const int ksplit = ab.ksplit > 1 ? ab.ksplit : 1;
-  const int id_s = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = id_s % ksplit, id = id_s / ksplit;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   // per-thread im2col rows: element offset of the always-valid centre tap (pixel (oy*s, ox*s)) and a
@@ -309,9 +298,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       }
     }
   }
-  const int nchunks_all = a.KH * a.KW * (a.Cin >> 5);
-  const int cb = (int)((long)nchunks_all * split / ksplit);           // this workgroup's chunks: [cb, nchunks)
-  const int nchunks = (int)((long)nchunks_all * (split + 1) / ksplit);
+  const int nchunks = a.KH * a.KW * (a.Cin >> 5), nchunks_all = nchunks;
+  constexpr int cb = 0;   // first chunk
   // (native vector types: HIP's uint4 struct copies lower to memcpy and keep the arrays out of registers)
   u32x4 ra[AI], rb[BI], ra2[DEEP >= 2 ? AI : 1], rb2[DEEP >= 2 ? BI : 1], ra3[DEEP >= 3 ? AI : 1], rb3[DEEP >= 3 ? BI : 1];
   unsigned okmask = 0, okmask2 = 0, okmask3 = 0;
@@ -330,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
     }                                                                                                          \
     OK = 0;                                                                                                    \
-    if (!(ab.dbg & 2)) {                                                                                       \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       const bool ok = (rmask[i] >> tap) & 1u;                                                                  \
       OK |= (ok ? 1u : 0u) << i;                                                                               \
@@ -345,12 +332,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
                                     : (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (cc_ << 5) + s_ * 8;      \
       RB[i] = *reinterpret_cast<const u32x4*>(wp_);                                                            \
     }                                                                                                          \
-    }                                                                                                          \
   }
 #define SERL_STORE_CHUNK_(BUF, RA, RB, OK)                                                                                  \
   {                                                                                                            \
     uint8_t* st_ = smemb + (BUF) * STAGE;                                                                      \
-    if (!(ab.dbg & 4)) {                                                                                       \
     _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                                           \
       u32x4 v = RA[i];                                                                                         \
       if (!((OK >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                                      \
@@ -361,7 +346,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
       *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + (ab.wdma ? r_ * 64 + s_ * 16 : swz(r_, s_))) = RB[i]; \
-    }                                                                                                          \
     }                                                                                                          \
   }
 
@@ -380,7 +364,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     const uint8_t* st = smemb + (BUF) * STAGE;                                                                 \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
       f16x8 ahi[TM] = {}, alo[TM] = {}, bhi[TN] = {}, blo[TN] = {};                                            \
-      if (!(ab.dbg & 8)) {                                                                                     \
       _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                      \
         const int off = swz(wm * WROWS + tm * 32 + li, 2 * ks + lh);                                           \
         ahi[tm] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
@@ -391,8 +374,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
         bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);                                                   \
         blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);                                         \
       }                                                                                                        \
-      }                                                                                                        \
-      if (!(ab.dbg & 1))                                                                                       \
       _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                        \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                    \
           accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);      \
@@ -457,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     for (int r = 0; r < 16; ++r) {
       const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m < a.M) {
-        float* o = a.out + (size_t)split * ab.slab_stride + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+        float* o = a.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
       }
@@ -497,8 +478,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 // The register-staged kernel above serialises its phases -- measured on b2_conv1: MFMA-only 164 us, + LDS fragment
 // reads 8, + ds_write staging 34, + global-load waits 57 = 263 us -- because a chunk's loads have only one MFMA
 // phase to land and the staging registers (32 per chunk in flight) leave no room for a deeper pipeline next to two
-// 64-register accumulator sets.  Here a chunk is fetched by 16-byte LDS-DMA pieces issued one (NSTAGE = 2) or two
-// (NSTAGE = 3) chunks ahead: no staging registers, no ds_write pass, counted vmcnt waits, one raw s_barrier per chunk.
+// 64-register accumulator sets.  Here a chunk is fetched by 16-byte LDS-DMA pieces issued one chunk ahead (two LDS
+// stages; three stages = one workgroup per CU were measured slower in round 2): no staging registers, no ds_write pass, counted vmcnt waits, one raw s_barrier per chunk.
 //   * a DMA piece is 64 lanes x 16 B written lane-linearly, so swizzles are applied to the SOURCE address: a piece of
 //     the activation tile is 8 rows x 8 units (a row chunk = 32 channels = [hi8 lo8] x 4 in the split8 layout) and
 //     lane l fetches unit (l&7) ^ ((row>>1)&7) of row l>>3; a piece of a weight plane is 16 rows x 4 units and lane l
@@ -509,8 +490,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <int TN, int NSTAGE, int PMODE>
+template <int TN, int PMODE>
 __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
+  constexpr int NSTAGE = 2;
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN, BM = 128, BN = 2 * WCOLS;
   constexpr int A_BYTES = BM * 128, B_PLANE = BN * 64, STAGE = A_BYTES + 2 * B_PLANE;
@@ -620,12 +602,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   // prologue: NSTAGE - 1 chunks in flight
   SERL_DMA_NEXT(0);
   SERL_DMA_ISSUE_ALL();
-  if (NSTAGE == 3) { SERL_DMA_NEXT(1); SERL_DMA_ISSUE_ALL(); }
   constexpr int GROUPS = 2 * TM * TN;   // MFMA groups (3 MFMAs each) per chunk
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed once at most the pieces of the chunks issued after it are outstanding
-    if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");   // every wave's pieces of chunk c are in LDS; stage (c-1) % NSTAGE is free
     SERL_DMA_NEXT((c + NSTAGE - 1) % NSTAGE);  // the chunk to fetch during this iteration (if any)
     const uint8_t* st = smemb + (c % NSTAGE) * STAGE;
@@ -793,146 +773,11 @@ __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-patch variant for the stride-1 3x3 convs with 64 output channels (stage 0: the largest M and the
-// smallest N, where the im2col loader's 9x re-read of every input pixel through L2 -> LDS is the bound).
-// A K chunk is (ky, 16 input channels): the workgroup stages the TR x (Wo+2) input pixels of that kernel
-// row ONCE and serves the three kx taps from LDS by shifting the pixel index, so the activation operand
-// crosses L2 -> LDS 3x instead of 9x.  256 x 64 output tile = TR = 256/Wo whole output rows of one image.
-// Epilogue identical to the generic kernel (plus the fused GroupNorm modes).
-// ---------------------------------------------------------------------------------------------
-constexpr int kRowpatchLds = 2 * (4 * (288 * 16 + 32) + 3 * 2 * 2 * (64 * 16 + 64));   // two stages, see the layout in the kernel
-__global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgsB ab) {
-  const ConvArgs& a = ab.c;
-  constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
-  constexpr int MAXPIX = 288;                    // 8 x 34 (Wo = 32) or 16 x 18 (Wo = 16)
-  // LDS image of a chunk: 16-byte units (8 fp16 = one MFMA k-half of one plane) laid out so that the 32 lanes of an
-  // MFMA fragment read (consecutive pixels / output channels, same plane and k-half) touch CONSECUTIVE units --
-  // ds_read_b128 serves 16-lane groups over a 256-byte bank row, and the former [pixel][32 B] rows put lanes l and l+8 of
-  // a group on the same banks (PMC: 45 % of this kernel's LDS cycles were bank conflicts).  Activations: 4 regions
-  // (plane, k-half) of [pixel][16 B]; weights per tap: 4 regions of [cout][16 B].  Region strides are padded so that the 8
-  // lanes of a ds_write_b128 group (units of 2 pixels x 4 regions, or 4 couts x 2 k-halves) cover all 32 write banks.
-  constexpr int A_REGION = MAXPIX * 16 + 32;     // region q = plane + 2 * k-half at q * A_REGION
-  constexpr int A_BYTES = 4 * A_REGION;
-  constexpr int B_HALF = BN * 16 + 64, B_PLANE = 2 * B_HALF, B_TAP = 2 * B_PLANE;  // per tap: [plane][k-half][cout][16 B]
-  constexpr int STAGE = A_BYTES + 3 * B_TAP;
-  static_assert(2 * STAGE == kRowpatchLds, "LDS size of the launch");
-  constexpr int AI = (MAXPIX * 4 + 255) / 256;   // 16-byte activation records per thread per chunk
-  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
-  const int m0 = id * BM, n0 = 0;
-  const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
-  const int pw = a.Wo + 2, npix = (BM / a.Wo) * pw;
-  const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
-  const int rowstep = a.Wi * a.Cin;
-  int rbase[AI];
-  unsigned rmask[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int idx = tid + 256 * i, pix = idx >> 2, q = idx & 3;
-    rbase[i] = 0; rmask[i] = 0;
-    if (pix < npix) {
-      const int sy = pix / pw, sx = pix - sy * pw;
-      const int ix = sx - 1, iy = oy0 + sy;  // centre-row (ky = 1) input pixel of this stage slot
-      const int ixc = min(max(ix, 0), a.Wi - 1);
-      rbase[i] = ((n_img * a.Hi + iy) * a.Wi + ixc) * a.Cin + 4 * q;
-      if (ix == ixc) rmask[i] = (iy > 0 ? 1u : 0u) | 2u | (iy + 1 < a.Hi ? 4u : 0u);
-    }
-  }
-  const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
-  const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
-  u32x4 ra[AI], rb[3];
-  unsigned okmask = 0;
-  int l_ky = 0, l_c16 = 0;
-
-#define SERL_RP_LOAD(CIDX)                                                                       \
-  {                                                                                              \
-    const int ky_ = l_ky, c0_ = l_c16 << 4;                                                      \
-    const int toff_ = (ky_ - 1) * rowstep + c0_;                                                 \
-    if ((CIDX) + 1 < nchunks) { if (++l_c16 == c16n) { l_c16 = 0; ++l_ky; } }                    \
-    okmask = 0;                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                             \
-      const bool ok = (rmask[i] >> ky_) & 1u;                                                    \
-      okmask |= (ok ? 1u : 0u) << i;                                                             \
-      ra[i] = *reinterpret_cast<const u32x4*>(a.in + rbase[i] + (ok ? toff_ : c0_));             \
-    }                                                                                            \
-    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
-      rb[kx] = *reinterpret_cast<const u32x4*>(wrow + (ky_ * 3 + kx) * a.Cin + c0_);             \
-  }
-#define SERL_RP_STORE(BUF)                                                                       \
-  {                                                                                              \
-    uint8_t* st_ = smemb + (BUF) * STAGE;                                                        \
-    _Pragma("unroll") for (int i = 0; i < AI; ++i) {                                             \
-      u32x4 v = ra[i];                                                                           \
-      if (!((okmask >> i) & 1u)) v = (u32x4){0u, 0u, 0u, 0u};                                    \
-      const int idx_ = tid + 256 * i;                                                            \
-      if (idx_ < MAXPIX * 4)   /* unit q = idx&3 of the pixel's 16 channels: plane q&1, 8-channel block q>>1 */ \
-        *reinterpret_cast<u32x4*>(st_ + (idx_ & 3) * A_REGION + (idx_ >> 2) * 16) = v;             \
-    }                                                                                            \
-    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                             \
-      *reinterpret_cast<u32x4*>(st_ + A_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = rb[kx]; \
-  }
-
-  f32x16 acc[TM][TN], accx[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
-
-  const int li = lane & 31, lh = lane >> 5;
-  int arow[TM];  // LDS byte offset of this lane's pixel (kx = 0) for each 32-row MFMA tile
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int r = wave * WROWS + tm * 32 + li;
-    const int y = r / a.Wo, x = r - y * a.Wo;
-    arow[tm] = 2 * lh * A_REGION + (y * pw + x) * 16;   // hi plane of k-half lh; the lo' plane is one region further
-  }
-  const int boff = A_BYTES + lh * B_HALF + li * 16;
-  SERL_RP_LOAD(0);
-  SERL_RP_STORE(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    SERL_RP_LOAD(c + 1);  // (the last iteration re-reads its own chunk: the counters stop advancing)
-    const uint8_t* st = smemb + buf * STAGE;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        ahi[tm] = *reinterpret_cast<const f16x8*>(st + arow[tm] + kx * 16);
-        alo[tm] = *reinterpret_cast<const f16x8*>(st + A_REGION + arow[tm] + kx * 16);
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        bhi[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + tn * 32 * 16);
-        blo[tn] = *reinterpret_cast<const f16x8*>(st + boff + kx * B_TAP + B_PLANE + tn * 32 * 16);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-        }
-    }
-    SERL_RP_STORE(buf ^ 1);
-    __syncthreads();
-  }
-#undef SERL_RP_LOAD
-#undef SERL_RP_STORE
-
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row-SLAB variant of the row-patch kernel (default for stage 0).  PMC on the row-patch kernel: 0 LDS bank conflicts after
-// the layout fix, MFMA pipe busy 27 % -- the kernel moves 1.43 GB from L2 to LDS per launch (4096 tiles x 12 chunks x
-// (17 KB of activations + 12 KB of weights)) in 300 us = 4.8 TB/s: it is bound by L2 -> LDS traffic, not by LDS or MFMA.
-// Here the K loop is channel-major: for each group of 16 input channels the workgroup stages the (TR + 2) x (Wo + 2)
+// Row-slab kernel for the stride-1 3x3 convs of stage 0 and b1_conv1 (the largest M and the smallest N, where an im2col
+// loader's 9x re-read of every input pixel through L2 -> LDS is the bound): 256 x 64 output tile = 256 / Wo whole output
+// rows of one image.  (Its round-2 predecessor, the row-patch kernel -- one kernel row per chunk, activations crossing
+// L2 -> LDS 3x -- moved 1.43 GB per launch at 4.8 TB/s with the matrix pipe 27 % busy and zero LDS conflicts: traffic-
+// bound; removed in round 3, numbers in profiles/README.md.)  The K loop is channel-major: for each group of 16 input channels the workgroup stages the (TR + 2) x (Wo + 2)
 // input pixels ONCE (a slab: 22 KB) and serves all NINE taps from it (ky shifts the row, kx the pixel); only the 3 taps'
 // weights (13 KB) are streamed per (channel group, ky) sub-chunk.  The next slab is fetched in three parts under the three
 // sub-chunks of the current one, so a thread stages 2 activation units + 3 weight units per sub-chunk (20 registers
@@ -940,11 +785,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowpatch_f16x3_kernel(ConvArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowslabPix = 340;   // (8 + 2) x 34 (Wo = 32); (16 + 2) x 18 = 324 (Wo = 16)
 constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (64 * 16 + 64);
-template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
-  constexpr int A_REGION = kRowslabPix * 16 + 32, A_BYTES = 4 * A_REGION;   // layout as in the row-patch kernel
+  // LDS image: 16-byte units (8 fp16 = one MFMA k-half of one plane) laid out so that the 32 lanes of an MFMA fragment read
+  // (consecutive pixels / output channels, same plane and k-half) touch CONSECUTIVE units -- ds_read_b128 serves 16-lane
+  // groups over a 256-byte bank row, and [pixel][32 B] rows would put lanes l and l+8 of a group on the same banks (PMC:
+  // 45 % of the LDS cycles were bank conflicts with that layout).  Activations: 4 regions (plane, k-half) of [pixel][16 B],
+  // region q = plane + 2 * k-half at q * A_REGION; weights per tap: [plane][k-half][cout][16 B].  Region strides are padded
+  // so that the 8 lanes of a ds_write_b128 group (2 pixels x 4 regions, or 4 couts x 2 k-halves) cover all 32 write banks.
+  constexpr int A_REGION = kRowslabPix * 16 + 32, A_BYTES = 4 * A_REGION;
   constexpr int B_HALF = BN * 16 + 64, B_PLANE = 2 * B_HALF, B_TAP = 2 * B_PLANE, B_BYTES = 3 * B_TAP;
   static_assert(2 * A_BYTES + 2 * B_BYTES == kRowslabLds, "LDS size of the launch");
   constexpr int AJ = 2;   // activation units per thread per sub-chunk: 3 x 2 x 256 = 1536 >= 340 x 4
@@ -976,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
   // fetch-order copy: block (column tile bn, group, tap) of 2048 halfs, this thread's unit at tid * 8
   const uint16_t* wslab = ab.wslab ? ab.wslab + ((size_t)bn * c16n * 9 << 11) + tid * 8 : nullptr;
-  u32x4 ra[AJ], rb[3], ra2[DEEP ? AJ : 1], rb2[DEEP ? 3 : 1];
+  u32x4 ra[AJ], rb[3];
 
 // fetch into registers: part PART of the slab of channel group CG (activations), the 3 taps of (channel group BG, row BKY)
 #define SERL_RS_LOAD_A(RA, PART, CG)                                                               \
@@ -1062,33 +912,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   SERL_RS_STORE_B(rb, 0);
   __syncthreads();
   int cg = 0, ky = 0;   // channel group and kernel row of sub-chunk c
-  if (!DEEP) {
-    for (int c = 0; c < nchunks; ++c) {
-      SERL_RS_LOADS(cg, ky, ra, rb);
-      SERL_RS_COMPUTE(c, cg, ky);
-      // the other weight buffer was last read in sub-chunk c - 1, the other slab buffer during the previous channel group
-      SERL_RS_STORES(c, cg, ky, ra, rb);
-      __syncthreads();
-      if (++ky == 3) { ky = 0; ++cg; }
-    }
-  } else {
-    // the fetches a sub-chunk's stores need are issued ONE SUB-CHUNK EARLIER, into the other register set: a sub-chunk is
-    // only 36 MFMAs per wave (~0.5 us), shorter than a loaded L2 / HBM round trip, so with one sub-chunk of distance the
-    // stores waited on their loads every time; two sets of 5 staging registers fit (242 VGPRs)
-    SERL_RS_LOADS(0, 0, ra, rb);
-    for (int c = 0; c < nchunks; c += 2) {   // nchunks is even (the launcher checks)
-      const int cg1 = ky == 2 ? cg + 1 : cg, ky1 = ky == 2 ? 0 : ky + 1;
-      SERL_RS_LOADS(cg1, ky1, ra2, rb2);
-      SERL_RS_COMPUTE(c, cg, ky);
-      SERL_RS_STORES(c, cg, ky, ra, rb);
-      __syncthreads();
-      const int cg2 = ky1 == 2 ? cg1 + 1 : cg1, ky2 = ky1 == 2 ? 0 : ky1 + 1;
-      SERL_RS_LOADS(cg2, ky2, ra, rb);
-      SERL_RS_COMPUTE(c + 1, cg1, ky1);
-      SERL_RS_STORES(c + 1, cg1, ky1, ra2, rb2);
-      __syncthreads();
-      cg = cg2; ky = ky2;
-    }
+  for (int c = 0; c < nchunks; ++c) {
+    SERL_RS_LOADS(cg, ky, ra, rb);
+    SERL_RS_COMPUTE(c, cg, ky);
+    // the other weight buffer was last read in sub-chunk c - 1, the other slab buffer during the previous channel group
+    // (fetching two sub-chunks ahead with a second staging register set was measured neutral in round 2: removed)
+    SERL_RS_STORES(c, cg, ky, ra, rb);
+    __syncthreads();
+    if (++ky == 3) { ky = 0; ++cg; }
   }
 #undef SERL_RS_LOAD_A
 #undef SERL_RS_LOAD_B
@@ -1101,37 +932,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv_init in split-fp16: u8 image -> normalise -> conv 7x7 stride 2 pad 3, 3 -> 64.
-// K is re-indexed as k' = ky*24 + (kx*3 + c) (21 real taps per kernel row + 3 zero-weight pads, 7 rows
-// -> 168, padded to 176 = 11 MFMA k-steps) so that every 8-wide MFMA k-block is a contiguous run of
-// one patch row in LDS.  Persistent workgroups keep the (hi, lo') weights resident in LDS and walk over
-// 16x16 output tiles.
+// conv_init: u8 image -> normalise -> conv 7x7 stride 2 pad 3, 3 -> 64 (+ fused 3x3/2 max-pool).  Persistent workgroups keep
+// the weight planes resident in LDS and walk over 16x16 output tiles (conv_init_u8_kernel below).
 // ---------------------------------------------------------------------------------------------
 struct ConvInitArgsB {
   const uint8_t* img;   // [N][H][W][3]
-  const uint16_t* whi;  // [64][176] fp16
-  const uint16_t* wlo;  // [64][176] fp16 residual (unscaled)
+  const uint16_t* whi;  // [64][224] fp16 (folded, scaled weights: pack_conv_init_u8_kernel)
+  const uint16_t* wlo;  // [64][224] fp16 residual (unscaled)
   const float* winv;    // [64] 1 / (per-output-channel weight scale)
   float* out;           // [N][Ho][Wo][64]   (POOL: unused)
   double* stats;        // [N][4][2]
   int N, H, W, Ho, Wo, tiles_y, tiles_x, total_tiles;
-  // POOL (fused 3x3/2 max-pool, see conv_init_f16x3_kernel): sign source and the three compact outputs
+  // POOL (fused 3x3/2 max-pool): sign source and the three compact outputs
   const float* gamma;   // [64] GroupNorm scale of norm_init
   float* pooled;        // [N][Ho/2][Wo/2][64] extreme of the in-tile part of every pooling window
   float* first_rows;    // [N][tiles_y][Wo][64] raw conv outputs of rows 0 mod 16
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
-  int dbg;              // timing experiments only (SERL_CI_DBG): 1 no stats atomics, 2 no pool epilogue, 4 no MFMA loop, 8 no patch fill
-  int chunk;            // conv_init_u8: tiles per scheduling chunk (divides tiles_y * tiles_x)
-  int* ticket;          // conv_init_u8: chunk ticket (zeroed per pass) or nullptr = static round-robin
+  int chunk;            // tiles per scheduling chunk (divides tiles_y * tiles_x)
+  int* ticket;          // chunk ticket (zeroed per pass)
 };
 
-constexpr int kCbKP = 176;       // padded K
-constexpr int kCbWP = 184;       // LDS pitch of a weight row (halfs): 368 B, conflict-free ds_read_b128
 constexpr int kCbPatch = 37;     // input rows/cols per 16x16 output tile
-constexpr int kCbPWH = 116;      // LDS pitch of a patch row (halfs): 111 real + slack for the padded k-block
-constexpr int kCbWBytes = 64 * kCbWP * 2;         // one weight plane
-constexpr int kCbPBytes = kCbPatch * kCbPWH * 2;  // one patch plane
-constexpr int kCbLds = 2 * kCbWBytes + 2 * kCbPBytes + 768 * 4;
 
 // POOL: relu(GN(.)) is monotone in the raw conv output with the sign of the channel's GroupNorm scale gamma (a frozen
 // parameter), so max_pool(relu(GN(x))) = relu(GN(extreme(x))) with extreme = max where gamma >= 0 and min where
@@ -1139,218 +960,8 @@ constexpr int kCbLds = 2 * kCbWBytes + 2 * kCbPBytes + 768 * 4;
 // statistics exist: the tile writes, per channel, the extreme over the in-tile part of each 3x3/2 window (1/4 of the
 // raw tensor) plus its first row and first column raw (the missing row/column of the windows of the tile above /
 // to the left), instead of 1 MiB of raw fp32 per image that the pool kernel re-read 1.5x.
-template <bool POOL>
-__global__ __launch_bounds__(256, 2) void conv_init_f16x3_kernel(ConvInitArgsB a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  uint8_t* w_hi = smemb;
-  uint8_t* w_lo = smemb + kCbWBytes;
-  uint16_t* p_hi = reinterpret_cast<uint16_t*>(smemb + 2 * kCbWBytes);
-  uint16_t* p_lo = reinterpret_cast<uint16_t*>(smemb + 2 * kCbWBytes + kCbPBytes);
-  uint32_t* lut = reinterpret_cast<uint32_t*>(smemb + 2 * kCbWBytes + 2 * kCbPBytes);  // [3][256] (hi | lo' << 16)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  // resident weights: 64 rows x 22 16-byte slots per plane
-  for (int v = tid; v < 2 * 64 * 22; v += 256) {
-    const int plane = v / (64 * 22), r = (v / 22) % 64, sl = v % 22;
-    const uint4 val = *reinterpret_cast<const uint4*>((plane ? a.wlo : a.whi) + (size_t)r * kCbKP + sl * 8);
-    *reinterpret_cast<uint4*>((plane ? w_lo : w_hi) + r * (kCbWP * 2) + sl * 16) = val;
-  }
-  // pixel value -> split-fp16 of the ImageNet-normalised input (x/255 - mean)/std, one entry per (channel, byte)
-  for (int v = tid; v < 768; v += 256) {
-    const int ch = v >> 8;
-    const float mean = ch == 0 ? 0.485f : (ch == 1 ? 0.456f : 0.406f);
-    const float stdv = ch == 0 ? 0.229f : (ch == 1 ? 0.224f : 0.225f);
-    const float val = ((float)(v & 255) / 255.0f - mean) / stdv;
-    const _Float16 h = (_Float16)val;
-    const _Float16 l = (_Float16)(val - (float)h);  // unscaled: |x| = O(1) here, lo stays in fp16's normal range
-    lut[v] = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-  }
-  constexpr int PE = (kCbPatch * kCbPWH + 255) / 256;  // patch elements per thread
-  uint32_t pix[PE];  // staged bytes of the NEXT tile: bits 0-7 value, bits 8-9 channel, bit 31 = outside / pad
-#define SERL_CI_FETCH(TILE)                                                                       \
-  {                                                                                               \
-    int b_ = (TILE);                                                                              \
-    const int tx_ = b_ % a.tiles_x;                                                               \
-    b_ /= a.tiles_x;                                                                              \
-    const int ty_ = b_ % a.tiles_y;                                                               \
-    const int n_ = b_ / a.tiles_y;                                                                \
-    const uint8_t* img_ = a.img + (size_t)n_ * a.H * a.W * 3;                                     \
-    const int iy0_ = ty_ * 32 - 3, ix0_ = tx_ * 32 - 3;                                           \
-    _Pragma("unroll") for (int i = 0; i < PE; ++i) {                                              \
-      const int v = tid + 256 * i;                                                                \
-      const int yy = v / kCbPWH, rest = v - yy * kCbPWH;                                          \
-      const int xx = rest / 3, ch = rest - xx * 3;                                                \
-      const int iy = iy0_ + yy, ix = ix0_ + xx;                                                   \
-      const bool ok = v < kCbPatch * kCbPWH && rest < kCbPatch * 3 && (unsigned)iy < (unsigned)a.H && \
-                      (unsigned)ix < (unsigned)a.W;                                               \
-      const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);                     \
-      const uint32_t byte = img_[((size_t)cy * a.W + cx) * 3 + ch];                               \
-      pix[i] = ok ? (byte | ((uint32_t)ch << 8)) : 0x80000000u;                                   \
-    }                                                                                             \
-  }
-  SERL_CI_FETCH(min((int)blockIdx.x, a.total_tiles - 1));
-  const float winv[2] = {a.winv[li], a.winv[32 + li]};
-  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-    int b = tile;
-    const int tx = b % a.tiles_x;
-    b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int n = b / a.tiles_y;
-    const int oy0 = ty * 16, ox0 = tx * 16;
-    __syncthreads();  // previous tile's MFMA reads of the patch are done (weights / LUT are in place)
-#pragma unroll
-    for (int i = 0; i < PE; ++i) {
-      const int v = tid + 256 * i;
-      if (v < kCbPatch * kCbPWH) {
-        const uint32_t e = (pix[i] & 0x80000000u) ? 0u : lut[pix[i] & 0x3FF];
-        p_hi[v] = (uint16_t)(e & 0xFFFF);
-        p_lo[v] = (uint16_t)(e >> 16);
-      }
-    }
-    __syncthreads();
-    SERL_CI_FETCH(min(tile + (int)gridDim.x, a.total_tiles - 1));  // next tile's bytes, in flight under the MFMAs
-    int abase[2];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int p = wave * 64 + tm * 32 + li;
-      abase[tm] = (2 * (p >> 4)) * kCbPWH + (p & 15) * 6;
-    }
-    f32x16 acc[2][2];  // one accumulator: both operands are O(1), so lo is kept unscaled for conv_init
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < kCbKP / 16; ++ks) {
-      // k-block of this lane half; block 21 (beyond the 7 kernel rows) has zero weights: read block 20
-      const int kb0 = 2 * ks, kb1 = min(2 * ks + 1, 20);
-      const int koff0 = (kb0 / 3) * kCbPWH + (kb0 % 3) * 8, koff1 = (kb1 / 3) * kCbPWH + (kb1 % 3) * 8;
-      const int koff = lh ? koff1 : koff0;
-      f16x8 ahi[2], alo[2], bhi[2], blo[2];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const uint32_t* ph = reinterpret_cast<const uint32_t*>(p_hi + abase[tm] + koff);
-        const uint32_t* pl = reinterpret_cast<const uint32_t*>(p_lo + abase[tm] + koff);
-        ahi[tm] = __builtin_bit_cast(f16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
-        alo[tm] = __builtin_bit_cast(f16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
-      }
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int off = (tn * 32 + li) * (kCbWP * 2) + (2 * ks + lh) * 16;
-        bhi[tn] = *reinterpret_cast<const f16x8*>(w_hi + off);
-        blo[tn] = *reinterpret_cast<const f16x8*>(w_lo + off);
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= winv[tn];   // exact (power of two)
-    float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
-    if (!POOL) {
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-          const bool ok = oy < a.Ho && ox < a.Wo;
-          float* o = a.out + (((size_t)n * a.Ho + oy) * a.Wo + ox) * 64;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            const float v = ok ? acc[tm][tn][r] : 0.f;
-            if (ok) o[tn * 32 + li] = v;
-            s[tn] += v;
-            q[tn] += v * v;
-          }
-        }
-    } else {  // (the launcher guarantees Ho, Wo multiples of 16: every tile is full)
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            const float v = acc[tm][tn][r];
-            s[tn] += v;
-            q[tn] += v * v;
-          }
-      // pixel p = wave*64 + tm*32 + 8*(r>>2) + 4*lh + (r&3) -> (row p>>4, col p&15) of the tile
-      if (wave == 0) {  // tile row 0: tm = 0, r < 8, col = 8*(r>>2) + 4*lh + (r&3)
-        float* fr = a.first_rows + (((size_t)n * a.tiles_y + (oy0 >> 4)) * a.Wo + ox0 + 4 * lh) * 64 + li;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn) fr[(8 * (r >> 2) + (r & 3)) * 64 + tn * 32] = acc[0][tn][r];
-      }
-      if (lh == 0) {    // tile column 0: r in {0, 8}, row = wave*4 + tm*2 + (r>>3)
-        float* fc = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + (ox0 >> 4)) * 64 + li;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-              fc[(size_t)(tm * 2 + rr) * a.tiles_x * 64 + tn * 32] = acc[tm][tn][8 * rr];
-      }
-      __syncthreads();  // every wave is done reading the patch planes: reuse them as the pooling stage
-      float* stage = reinterpret_cast<float*>(p_hi);  // [16x16 pixels][16 channels] fp32 = 16 KB <= 2 patch planes
-      static_assert(2 * kCbPBytes >= 16 * 16 * 16 * 4, "pooling stage does not fit the patch planes");
-      const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // 16 channels at a time (fully unrolled: acc[..][g >> 1] stays in registers)
-        if ((li >> 4) == (g & 1)) {
-          const float sgn = a.gamma[(g >> 1) * 32 + li] < 0.f ? -1.f : 1.f;
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int p = wave * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              stage[p * 16 + (li & 15)] = sgn * acc[tm][g >> 1][r];  // sign-folded: always a max below
-            }
-        }
-        __syncthreads();
-        {
-          const int cell = tid >> 2, c4 = tid & 3, py = cell >> 3, px = cell & 7;
-          float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-              const int y = 2 * py + dy, x = 2 * px + dx;
-              if (y < 16 && x < 16) {
-                const float4 v = *reinterpret_cast<const float4*>(stage + (y * 16 + x) * 16 + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-              }
-            }
-          const float4 gm = *reinterpret_cast<const float4*>(a.gamma + g * 16 + c4 * 4);
-          m.x = gm.x < 0.f ? -m.x : m.x; m.y = gm.y < 0.f ? -m.y : m.y;
-          m.z = gm.z < 0.f ? -m.z : m.z; m.w = gm.w < 0.f ? -m.w : m.w;
-          *reinterpret_cast<float4*>(a.pooled + (((size_t)n * Hp + (oy0 >> 1) + py) * Wp + (ox0 >> 1) + px) * 64 +
-                                     g * 16 + c4 * 4) = m;
-        }
-        __syncthreads();
-      }
-    }
-    double* st = a.stats + (size_t)n * kGnGroups * 2;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// conv_init on RAW pixels ("u8" variant, default): the ImageNet normalisation is folded into the weights,
+// conv_init on RAW pixels: the ImageNet normalisation is folded into the weights,
 //     out = sum_taps_inside ((px/255 - mean_c)/std_c) w  =  sum px * w/(255 std_c)  -  sum_taps_inside (mean_c/std_c) w ,
 // so the activation operand is the pixel value itself -- an integer 0..255, EXACT in fp16: it needs no lo' plane and an
 // fp32 product costs TWO fp16 MFMA products (px*w_hi + px*w_lo) instead of three.  The second term depends on which
@@ -1442,8 +1053,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   while (chunk < nchunks) {
     const bool first_of_chunk = tile == chunk * a.chunk;
     if (first_of_chunk && tid == 0)
-      s_next_chunk = (int)gridDim.x + (a.ticket ? __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                : chunk / (int)gridDim.x * (int)gridDim.x + (int)blockIdx.x);
+      s_next_chunk = (int)gridDim.x + __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int b = tile;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
@@ -1454,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = tid + 256 * q;
-      if (t < kTasks && !(a.dbg & 8)) {
+      if (t < kTasks) {
         const int r = t / kGroups, g = t - r * kGroups;
         // bytes 0..11 = pixels 0..3 x (c0,c1,c2); patch column of pixel j = 4g - 1 + j (column -1 is not stored)
         const uint32_t d0 = pre[q][0], d1 = pre[q][1], d2 = pre[q][2];
@@ -1492,7 +1102,6 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-    if (!(a.dbg & 4))
 #pragma unroll
     for (int ks = 0; ks < kC8K / 16; ++ks) {
       const int aoff = (ks >> 1) * kC8Pitch + (ks & 1) * 32;   // kernel row ky = ks/2, k-blocks 2(ks&1) + lh
@@ -1536,7 +1145,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
             q[tn] += v * v;
           }
         }
-    } else if (!(a.dbg & 2)) {  // fused 3x3/2 max-pool, identical to conv_init_f16x3_kernel<true> (every tile is full)
+    } else {  // fused 3x3/2 max-pool (every tile is full)
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1615,7 +1224,6 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     }
     if (++tile == t_end) {   // last tile of the chunk (a chunk lies in one image)
       double* st = a.stats + (size_t)n * kGnGroups * 2;
-      if (!(a.dbg & 1))
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
       s[0] = s[1] = q[0] = q[1] = 0.f;
@@ -1664,30 +1272,9 @@ __global__ __launch_bounds__(256) void pack_conv_init_u8_kernel(const float* w, 
   lo[(size_t)n * kC8K + kp] = __builtin_bit_cast(uint16_t, l);
 }
 
-// conv_init weights [147][64] fp32 (k = ky*21 + kx*3 + c) -> hi / lo' fp16 [64][176] (k' = ky*24 + kx*3 + c)
-__global__ __launch_bounds__(256) void pack_conv_init_kernel(const float* w, uint16_t* hi, uint16_t* lo, float* inv) {
-  __shared__ float red[4];
-  const int n = blockIdx.x, kp = threadIdx.x;
-  const int ky = kp / 24, j = kp - ky * 24;
-  float v = 0.f;
-  if (kp < kCbKP && ky < 7 && j < 21) v = w[(size_t)(ky * 21 + j) * 64 + n];
-  const float sc = channel_scale(fabsf(v), 8, red);
-  if (kp == 0) inv[n] = 1.0f / sc;
-  if (kp >= kCbKP) return;
-  v *= sc;
-  const _Float16 h = (_Float16)clamp_h(v);
-  const _Float16 l = (_Float16)(v - (float)h);  // unscaled (see conv_init_f16x3_kernel)
-  hi[(size_t)n * kCbKP + kp] = __builtin_bit_cast(uint16_t, h);
-  lo[(size_t)n * kCbKP + kp] = __builtin_bit_cast(uint16_t, l);
-}
-
-// SERL_CONV_INIT_U8=0 selects the older 3-product kernel (normalised pixels through a LUT) for A/B runs
-static const bool kConvInitU8 = []() { const char* e = getenv("SERL_CONV_INIT_U8"); return !(e && e[0] == '0'); }();
-
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream) {
-  static_assert(kC8K <= 256 && kCbKP <= 256, "one thread per k'");
-  if (kConvInitU8) hipLaunchKernelGGL(pack_conv_init_u8_kernel, dim3(64), dim3(256), 0, stream, w, hi, lo, inv);
-  else hipLaunchKernelGGL(pack_conv_init_kernel, dim3(64), dim3(256), 0, stream, w, hi, lo, inv);
+  static_assert(kC8K <= 256, "one thread per k'");
+  hipLaunchKernelGGL(pack_conv_init_u8_kernel, dim3(64), dim3(256), 0, stream, w, hi, lo, inv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1699,16 +1286,12 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.tiles_y = cdiv(Ho, 16); a.tiles_x = cdiv(Wo, 16);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
-  static const int dbg = []() { const char* e = getenv("SERL_CI_DBG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg;
+  SERL_REQUIRE(ticket != nullptr, "conv_init needs a chunk ticket");
   const int tpi = a.tiles_y * a.tiles_x;
-  static const int chunk_env = []() { const char* e = getenv("SERL_CI_CHUNK"); return e ? atoi(e) : 0; }();
   a.chunk = tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1);
-  if (chunk_env > 0 && tpi % chunk_env == 0) a.chunk = chunk_env;
-  static const bool static_sched = []() { const char* e = getenv("SERL_CI_STATIC"); return e && atoi(e) != 0; }();
-  a.ticket = static_sched ? nullptr : ticket;
+  a.ticket = ticket;
   // 2 persistent workgroups per CU
-  const int grid = kConvInitU8 ? std::min(a.total_tiles / a.chunk, 512) : std::min(a.total_tiles, 512);
+  const int grid = std::min(a.total_tiles / a.chunk, 512);
   ProfScope prof("conv_init", stream);
   if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
     SERL_REQUIRE(Ho % 16 == 0 && Wo % 16 == 0, "fused conv_init pooling needs full 16x16 tiles");
@@ -1716,20 +1299,17 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
     a.pooled = out;
     a.first_rows = a.pooled + (size_t)N * (Ho / 2) * (Wo / 2) * 64;
     a.first_cols = a.first_rows + (size_t)N * a.tiles_y * Wo * 64;
-    if (kConvInitU8) hipLaunchKernelGGL(conv_init_u8_kernel<true>, dim3(grid), dim3(256), kC8Lds, stream, a);
-    else hipLaunchKernelGGL(conv_init_f16x3_kernel<true>, dim3(grid), dim3(256), kCbLds, stream, a);
+    hipLaunchKernelGGL(conv_init_u8_kernel<true>, dim3(grid), dim3(256), kC8Lds, stream, a);
   } else {
-    if (kConvInitU8) hipLaunchKernelGGL(conv_init_u8_kernel<false>, dim3(grid), dim3(256), kC8Lds, stream, a);
-    else hipLaunchKernelGGL(conv_init_f16x3_kernel<false>, dim3(grid), dim3(256), kCbLds, stream, a);
+    hipLaunchKernelGGL(conv_init_u8_kernel<false>, dim3(grid), dim3(256), kC8Lds, stream, a);
   }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
 
-// GroupNorm statistics of a raw conv output, one workgroup per (image, group).  S > 1: `x` holds S partial-sum slabs of a
-// K-split conv (slab stride `slab_stride` elements); they are added in slab order (deterministic), the total is written
-// to `out` and the statistics are those of the total.
-__global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc, int S, size_t slab_stride, float* out) {
+// GroupNorm statistics of a raw conv output, one workgroup per (image, group): shapes whose statistics cannot ride in the
+// conv's epilogue (pmode 3).
+__global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc) {
   const int n = blockIdx.x / kGnGroups, g = blockIdx.x % kGnGroups;
   const int gs = Cc / kGnGroups;
   const size_t base = (size_t)n * P * Cc + g * gs;
@@ -1737,9 +1317,7 @@ __global__ void gn_stats_kernel_b(const float* x, double* stats, int P, int Cc, 
   for (int e = threadIdx.x; e < P * gs; e += 256) {
     const int p = e / gs, c = e - p * gs;
     const size_t at = base + (size_t)p * Cc + c;
-    float v = x[at];
-    for (int k = 1; k < S; ++k) v += x[at + (size_t)k * slab_stride];
-    if (S > 1) out[at] = v;
+    const float v = x[at];
     s += v;
     q += (double)v * v;
   }
@@ -2012,8 +1590,7 @@ static int resident_workgroups(hipStream_t stream) {
 
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
-                             float* splitk_scratch = nullptr, size_t splitk_bytes = 0) {
+                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -2026,135 +1603,81 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   a.padw = std::max((Wo - 1) * stride + ksz - Wi, 0) / 2;
   a.M = N * Ho * Wo; a.P = Ho * Wo;
   ab.whi = w.hi; ab.wlo = w.lo; ab.winv = w.inv; ab.K = ksz * ksz * Cin;
-  static const bool slab_w = []() { const char* e = getenv("SERL_CONV_SLAB_WEIGHTS"); return !(e && e[0] == '0'); }();
-  ab.wslab = slab_w ? w.slab : nullptr;
-  static const bool dma_w = []() { const char* e = getenv("SERL_CONV_DMA_WEIGHTS"); return !(e && e[0] == '0'); }();
-  ab.wdma = dma_w ? w.dma : nullptr;
-  static const int conv_dbg = []() { const char* e = getenv("SERL_CONV_DBG"); return e ? atoi(e) : 0; }();
-  ab.dbg = conv_dbg;
+  ab.wslab = w.slab; ab.wdma = w.dma;
+  // tile configuration of the register-staged / LDS-DMA kernels: 0 = 128x128, 1 = 256x64 (Cout == 64), 4 = 128x64 with three
+  // chunks in flight (fewer than 512 128x128 tiles but at least 512 128x64 ones; measured per layer at B/2, B/4, B/8),
+  // 2 = 64x64 with three chunks in flight (small M: one rank's share of a data-parallel batch)
   int cfg = Cout >= 128 ? 0 : 1;
   if (cfg == 0 && (long)cdiv(a.M, 128) * (Cout / 128) < 512) cfg = 2;
-  // in between: 128x64 tiles (waves of 64x32) with three chunks in flight when there are enough of them
-  // (measured per layer at B/2, B/4, B/8: faster than 64x64 from 512 such workgroups up, slower below)
-  static const long mid_min = []() { const char* e = getenv("SERL_CONV_MID_MIN"); return e ? atol(e) : 512L; }();
-  if (cfg == 2 && mid_min > 0 && (long)cdiv(a.M, 128) * (Cout / 64) >= mid_min) cfg = 4;
+  if (cfg == 2 && (long)cdiv(a.M, 128) * (Cout / 64) >= 512) cfg = 4;
   const int BM = cfg == 2 ? 64 : (cfg == 1 ? 256 : 128), BN = cfg == 0 ? 128 : 64;
   const int wrows = cfg == 2 ? 32 : 64;
   a.tiles_m = cdiv(a.M, BM); a.tiles_n = Cout / BN;
   const size_t lds = (size_t)2 * (2 * BM * 64 + 2 * BN * 64);
+  // how a wave's rows relate to images (GroupNorm statistics in the epilogue): 0 = a wave lies in one image, 1 / 2 = images
+  // of 32 / 16 pixels, 3 = none of these: statistics by gn_stats_kernel_b after the conv
   int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   if (cfg == 2 && pmode == 1) pmode = 3;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
-  int ksplit = 1;
   {
     ProfScope prof(tag, stream);
-#define SERL_LAUNCH_CONV(WM, WN, TM, TN)                                                                               \
-  do {                                                                                                                 \
-    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 0>), grid, block, lds, stream, ab);      \
-    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 1>), grid, block, lds, stream, ab); \
-    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 2>), grid, block, lds, stream, ab); \
-    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3>), grid, block, lds, stream, ab);                 \
+#define SERL_LAUNCH_CONV(WM, WN, TM, TN, DEEP)                                                                                 \
+  do {                                                                                                                         \
+    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 0, DEEP>), grid, block, lds, stream, ab);        \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 1, DEEP>), grid, block, lds, stream, ab);   \
+    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 2, DEEP>), grid, block, lds, stream, ab);   \
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3, DEEP>), grid, block, lds, stream, ab);                   \
   } while (0)
-    static const bool use_rp = []() { const char* e = getenv("SERL_CONV_ROWPATCH"); return !(e && e[0] == '0'); }();
-    static const bool slab = []() { const char* e = getenv("SERL_CONV_ROWSLAB"); return !(e && e[0] == '0'); }();
-    // SERL_CONV_ROWSLAB_MAXC: widest layer (output channels) the row-slab kernel takes over from the LDS-DMA kernel
-    static const int slab_maxc = []() { const char* e = getenv("SERL_CONV_ROWSLAB_MAXC"); return e ? atoi(e) : 128; }();
-    const bool rp_ok = use_rp && ksz == 3 && stride == 1 && (Cout == 64 || (slab && Cout <= slab_maxc && Cout / 64 <= kSyncPerImage)) && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
-                       (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 &&
-                       (long)N * Hi * Wi * Cin < (1L << 31);
-    // SERL_CONV_DMA: 0 = register-staged kernels only, 2 / 3 = LDS-DMA kernel with that many LDS stages (default 2)
-    static const int dma = []() { const char* e = getenv("SERL_CONV_DMA"); return e ? atoi(e) : 2; }();
-    static const bool dma_c64 = []() { const char* e = getenv("SERL_CONV_DMA_C64"); return e && atoi(e) != 0; }();
-    const bool dma_ok = dma >= 2 && (cfg == 0 || cfg == 4 || (cfg == 1 && dma_c64)) && Cin % 32 == 0 && zero_page != nullptr &&
+    // row-slab kernel: stride-1 3x3 convs with 64 or 128 output channels on 32- or 16-pixel-wide maps (stage 0, b1_conv1)
+    const bool slab_ok = ksz == 3 && stride == 1 && Cout <= 128 && Cout / 64 <= kSyncPerImage && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
+                         (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 && w.slab != nullptr &&
+                         (long)N * Hi * Wi * Cin < (1L << 31);
+    // LDS-DMA kernel: everything else with at least 512 128-row tiles (32-bit byte offsets into the input)
+    const bool dma_ok = (cfg == 0 || cfg == 4) && Cin % 32 == 0 && zero_page != nullptr && w.dma != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
     bool fused = false;
     // the fused epilogue's wait needs more than 8 (G - 1) co-resident workgroups (see FuseArgs); demand twice that of the
     // CUs this stream may use at ONE workgroup per CU, else run the separate elementwise pass
     auto can_wait = [&](int G) { return resident_workgroups(stream) >= 16 * (G - 1) + 1; };
-    if (rp_ok) {
-      a.tiles_m = a.M / 256; a.tiles_n = slab ? Cout / 64 : 1;
+    if (slab_ok) {
+      a.tiles_m = a.M / 256; a.tiles_n = Cout / 64;
       if (fuse && fuse->mode && a.P % 256 == 0 && can_wait(a.P / 256 * a.tiles_n)) {
         ab.fz = *fuse; ab.fz.expected = a.P / 256; ab.fz.group = a.P / 256 * a.tiles_n; fused = true;
       }
-      // SERL_CONV_ROWSLAB_DEEP=1: fetches issued two sub-chunks ahead (second staging register set); measured neutral
-      // (b0 convs 318 / 360 -> 312 / 355 us), so the simpler schedule stays the default
-      static const bool slab_deep = []() { const char* e = getenv("SERL_CONV_ROWSLAB_DEEP"); return e && e[0] == '1'; }();
-      if (slab && slab_deep && (3 * (Cin >> 4)) % 2 == 0)
-        hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
-      else if (slab) hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
-      else hipLaunchKernelGGL(conv3x3_rowpatch_f16x3_kernel, dim3(a.M / 256), block, (size_t)kRowpatchLds, stream, ab);
+      hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
     } else if (dma_ok) {
-      static const int force_tn = []() { const char* e = getenv("SERL_CONV_DMA_TN"); return e ? atoi(e) : 0; }();
-      const int tn = force_tn ? force_tn : (cfg == 0 ? 2 : 1), bn = 64 * tn;
+      const int tn = cfg == 0 ? 2 : 1, bn = 64 * tn;
       a.tiles_m = cdiv(a.M, 128); a.tiles_n = Cout / bn;
       const dim3 g(a.tiles_m * a.tiles_n);
-      const int nst = dma >= 3 ? 3 : 2;
-      const size_t l = (size_t)nst * (128 * 128 + 2 * bn * 64);
+      const size_t l = (size_t)2 * (128 * 128 + 2 * bn * 64);   // two LDS stages (three = one workgroup per CU: measured slower)
       if (pmode == 1 && cfg == 4) pmode = 3;
       if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage && can_wait(a.P / 128 * a.tiles_n)) {
         ab.fz = *fuse; ab.fz.expected = a.P / 128; ab.fz.group = a.P / 128 * a.tiles_n; fused = true;
       } else if (fuse && fuse->mode && pmode == 0 && a.P == 64 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 64) {
-        static const bool local_on = []() { const char* e = getenv("SERL_GN_FUSE_LOCAL"); return !(e && e[0] == '0'); }();
-        if (local_on) { ab.fz = *fuse; ab.fz.expected = 0; fused = true; }   // a wave = one (image, group): no exchange
+        ab.fz = *fuse; ab.fz.expected = 0; fused = true;   // LOCAL: a wave = one (image, group), no exchange
       }
-#define SERL_LAUNCH_DMA(TN_, NS_)                                                                                        \
-  do {                                                                                                                   \
-    if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 0>), g, block, l, stream, ab, zero_page);        \
-    else if (pmode == 1) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 1>), g, block, l, stream, ab, zero_page);   \
-    else if (pmode == 2) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 2>), g, block, l, stream, ab, zero_page);   \
-    else hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, NS_, 3>), g, block, l, stream, ab, zero_page);                   \
+#define SERL_LAUNCH_DMA(TN_)                                                                                        \
+  do {                                                                                                              \
+    if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 0>), g, block, l, stream, ab, zero_page);        \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 1>), g, block, l, stream, ab, zero_page);   \
+    else if (pmode == 2) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 2>), g, block, l, stream, ab, zero_page);   \
+    else hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 3>), g, block, l, stream, ab, zero_page);                   \
   } while (0)
-      if (tn == 2 && nst == 2) SERL_LAUNCH_DMA(2, 2);
-      else if (tn == 2) SERL_LAUNCH_DMA(2, 3);
-      else if (nst == 2) SERL_LAUNCH_DMA(1, 2);
-      else SERL_LAUNCH_DMA(1, 3);
+      if (tn == 2) SERL_LAUNCH_DMA(2);
+      else SERL_LAUNCH_DMA(1);
 #undef SERL_LAUNCH_DMA
-    } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2);
-    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2);
-    else if (cfg == 4) {
-      if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 0, 3>), grid, block, lds, stream, ab);
-      else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 1, 3>), grid, block, lds, stream, ab);
-      else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 2, 3>), grid, block, lds, stream, ab);
-      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 2, 1, 3, 3>), grid, block, lds, stream, ab);
-    } else {  // 64x64 tile with 3 (SERL_CONV_DEEP=2: 2, =0: 1) chunks in flight
-      static const int deep = []() { const char* e = getenv("SERL_CONV_DEEP"); return e ? atoi(e) : 3; }();
-      // small M (one rank's share of a data-parallel batch): fewer than ~512 tiles whose K loops (up to 144 chunks) run at
-      // global-load latency.  SERL_CONV_KSPLIT=8 splits K over 2..8 workgroups per tile (>= 12 chunks each): partial sums go
-      // to slabs, the statistics kernel adds them.  OFF by default: at a per-rank batch of 32 it halves b3_conv1 (109 -> 55 us)
-      // and b3_conv0 (57 -> 37 us), but the statistics then need their own launch per conv (they ride in the conv epilogue
-      // otherwise) and the step got slower (0.733 -> 0.781 ms); neutral at 64 and 128.
-      static const int ks_max = []() { const char* e = getenv("SERL_CONV_KSPLIT"); return e ? atoi(e) : 0; }();
-      const long tiles = (long)a.tiles_m * a.tiles_n;
-      const int nch = ksz * ksz * (Cin >> 5);
-      int S = 1;
-      while (S * 2 <= ks_max && tiles * S * 2 <= 1024 && nch / (S * 2) >= 12 &&
-             (size_t)(S * 2) * a.M * Cout * sizeof(float) <= splitk_bytes) S *= 2;
-      if (S > 1 && splitk_scratch && pmode != 3) {
-        ksplit = S;
-        ab.ksplit = S; ab.slab_stride = (size_t)a.M * Cout;
-        a.out = splitk_scratch;
-        pmode = 3;            // no statistics in the conv: gn_stats_kernel_b below reduces the slabs and takes them
-        grid = dim3((unsigned)(tiles * S));
-      }
-#define SERL_LAUNCH_DEEP(D)                                                                                                      \
-  do {                                                                                                                           \
-    if (pmode == 0) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 0, D>), grid, block, lds, stream, ab);                \
-    else if (pmode == 1) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 1, D>), grid, block, lds, stream, ab);           \
-    else if (pmode == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 2, D>), grid, block, lds, stream, ab);           \
-    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, 2, 1, 1, 3, D>), grid, block, lds, stream, ab);                           \
-  } while (0)
-      if (deep >= 3) SERL_LAUNCH_DEEP(3);
-      else if (deep == 2) SERL_LAUNCH_DEEP(2);
-      else SERL_LAUNCH_CONV(2, 2, 1, 1);
-#undef SERL_LAUNCH_DEEP
-    }
+    } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2, 0);
+    else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2, 0);
+    else if (cfg == 4) SERL_LAUNCH_CONV(2, 2, 2, 1, 3);
+    else SERL_LAUNCH_CONV(2, 2, 1, 1, 3);
+    // (K-split of the small-M convs -- 2..8 workgroups per 64x64 tile, slabs reduced by the statistics kernel -- halved
+    //  b3_conv1 at a per-rank batch of 32 but needed a statistics launch per conv: the step got slower; removed in round 3)
 #undef SERL_LAUNCH_CONV
     if (fuse && !fused) fuse->mode = 0;
   }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {
-    hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, ksplit > 1 ? splitk_scratch : out, stats, a.P,
-                       Cout, ksplit, (size_t)a.M * Cout, out);
+    hipLaunchKernelGGL(gn_stats_kernel_b, dim3(N * kGnGroups), dim3(256), 0, stream, out, stats, a.P, Cout);
     SERL_HIP(hipGetLastError());
   }
   return SERL_OK;
@@ -2191,8 +1714,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   const TrunkDims& d = ws.d;
   auto stats_of = [&](int layer) { return ws.stats + (size_t)layer * ws.max_images * kGnGroups * 2; };
   if (stage_begin < 0) {   // statistics + arrival counters + tickets
-    static const bool zero_kernel = []() { const char* e = getenv("SERL_ZERO_KERNEL"); return !(e && e[0] == '0'); }();
-    if (zero_kernel && ws.stats_sync_bytes % 16 == 0 && ws.stats_sync_bytes < ((size_t)1 << 31)) {
+    if (ws.stats_sync_bytes % 16 == 0 && ws.stats_sync_bytes < ((size_t)1 << 31)) {
       const long n16 = (long)(ws.stats_sync_bytes / 16);
       hipLaunchKernelGGL(zero_sys_kernel, dim3((unsigned)std::min<long>(cdiv(n16, 256), 512)), dim3(256), 0, stream, (void*)ws.stats, n16);
       SERL_HIP(hipGetLastError());
@@ -2206,14 +1728,11 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     f.mode = (e && e[0] == '0') ? 0 : mode;
     f.sync = ws.sync + (size_t)layer * ((size_t)ws.max_images * kSyncPerImage + kSyncTickets);
     f.ticket = f.sync + (size_t)ws.max_images * kSyncPerImage;
-    static const int tmode = []() { const char* e = getenv("SERL_TICKET_MODE"); return e ? atoi(e) : 0; }();
-    f.tmode = tmode;
     return f;
   };
   int rc;
   if (stage_begin < 0) {
-    static const bool fuse_pool_on = []() { const char* e = getenv("SERL_POOL_FUSE"); return !(e && e[0] == '0'); }();
-    const bool fuse_pool = fuse_pool_on && d.h[0] % 16 == 0 && d.w[0] % 16 == 0;
+    const bool fuse_pool = d.h[0] % 16 == 0 && d.w[0] % 16 == 0;   // full 16 x 16 conv_init tiles: pooling fused into conv_init
     if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
                                      d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket))) return rc;
     if (fuse_pool) {
@@ -2256,7 +1775,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     FuseArgs fz0 = fuse_of(l0, 1);
     fz0.gn = gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f);
     fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0, ws.splitk, ws.splitk_bytes))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0))) return rc;
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
     const long tot = (long)N * P * (f / 4);
@@ -2276,7 +1795,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     } else {
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1, ws.splitk, ws.splitk_bytes))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1))) return rc;
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
       hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,

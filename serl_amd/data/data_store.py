@@ -192,7 +192,9 @@ class MemoryEfficientReplayBufferDataStore(DataStoreBase):
 
     # -- gather (memory_efficient_replay_buffer.py:126-164), packed frames on the device
     def gather(self, indx: np.ndarray, stream=None):
-        indx = np.ascontiguousarray(indx, dtype=np.int64)
+        indx = np.ascontiguousarray(indx, dtype=np.int64)   # (stale indices are re-drawn in place by the library)
+        if not indx.flags.writeable:
+            indx = indx.copy()
         B, T = len(indx), self._num_stack
         H, W, Cc = self._img_shape
         dev = self._torch_device
@@ -314,7 +316,10 @@ def gather_crop(parts, crop_obs: Optional[np.ndarray], crop_next: Optional[np.nd
     n = len(parts)
     assert 1 <= n <= _lib.MAX_BUFFERS
     rbs = (C.c_void_p * n)(*[p[0].handle.value for p in parts])
-    idxs = [np.ascontiguousarray(p[1], dtype=np.int64) for p in parts]
+    # the library re-draws, IN PLACE, indices whose slot an insert invalidated since they were drawn: pass the callers'
+    # own arrays whenever possible so that LazyBatch.parts keep describing the gathered batch
+    idxs = [p[1] if (isinstance(p[1], np.ndarray) and p[1].dtype == np.int64 and p[1].flags.c_contiguous and p[1].flags.writeable)
+            else np.ascontiguousarray(p[1], dtype=np.int64).copy() for p in parts]
     idp = (C.c_void_p * n)(*[ix.ctypes.data for ix in idxs])
     counts = (C.c_int * n)(*[len(ix) for ix in idxs])
     co = None if crop_obs is None else np.ascontiguousarray(crop_obs, dtype=np.int32)

@@ -76,7 +76,7 @@ int main(void) {
   serl_info info;
   for (int it = 0; it < 3; ++it) {
     CHECK(serl_rb_sample_indices(rb, B, idx));
-    const int64_t* idxp = idx;
+    int64_t* idxp = idx;   /* in/out: stale indices are re-drawn in place */
     const int count = B;
     serl_rb* rbs[1] = {rb};
     CHECK(serl_rb_gather_crop(rbs, 1, &idxp, &count, NULL, NULL, &db, stream));
