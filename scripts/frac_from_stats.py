@@ -12,9 +12,9 @@ flop_pass = sum(2.0 * m * n_img for t, m in macs.items() if t.startswith("conv_i
 conv_us, passes = 0.0, 0
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["kernel"]
-    if any(p in k for p in ("conv_dma_f16x3_kernel", "conv3x3_rowpatch_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_igemm_f16x3_kernel")):
+    if any(p in k for p in ("conv_dma_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_igemm_f16x3_kernel")):
         conv_us += float(r["total_us"])
-    if "conv_init" in k:
+    if "conv_init_u8_kernel" in k and "pack" not in k:   # one conv_init launch per trunk pass (NOT the one-off weight packing kernel)
         passes += int(r["calls"])
 t = conv_us / passes
 print(f"{passes} trunk passes, block convs {t:.1f} us per pass, {flop_pass/1e9:.1f} algorithmic GFLOP per pass -> "

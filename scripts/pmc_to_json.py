@@ -27,13 +27,13 @@ def family(tot, disp, pats):
 
 ft, fd = load(sys.argv[1])
 wt, wd = load(sys.argv[2])
-CONV16 = ("conv_igemm_f16x3_kernel", "conv3x3_rowpatch_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_dma_f16x3_kernel")
+CONV16 = ("conv_igemm_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_dma_f16x3_kernel")
 out = {"units": "bytes; FETCH_SIZE/WRITE_SIZE are KiB counters, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
                 "request: MI355X_MICROARCH.md HBM section); mean over the dispatches of the family"}
 for name, pats in (("conv_igemm_f16x3", CONV16), ("conv_igemm_f32", ("conv_igemm_kernel",)), ("gather_crop", ("gather_crop_kernel", "gather_crop_rgb_kernel")),
                    ("conv_init_f16x3", ("conv_init_f16x3_kernel", "conv_init_u8_kernel")), ("gn_relu_maxpool", ("gn_relu_maxpool", "pool_finish_split")),
                    ("block_out", ("block_out_split",)), ("gn_relu_split", ("gn_relu_split_kernel",)), ("adam_ema", ("adam_ema",)),
-                   ("gemm_f32", ("gemm_f32_kernel",))):
+                   ("gemm_f32", ("gemm_f32_kernel",)), ("gemm_bf16x3", ("gemm_bf16x3_kernel",)), ("zero_sys", ("zero_sys_kernel",))):
     f, nf = family(ft, fd, pats)
     w, nw = family(wt, wd, pats)
     if nf == 0 and nw == 0:

@@ -539,3 +539,37 @@ def test_fused_groupnorm_epilogue_is_race_free_at_full_batch(gpu, monkeypatch):
         worst = max(worst, float((got - ref).abs().max()) / scale)
     print(f"fused vs elementwise GroupNorm over 40 passes of {n} images: worst rel diff {worst:.2e}")
     assert worst < 2e-6, worst
+
+
+def test_fused_epilogue_is_race_free_over_2000_passes_with_a_corunning_update(gpu, monkeypatch):
+    """the cross-workgroup GroupNorm exchange (per-XCD tickets, memory-side statistics atomics, arrival
+    counters, system-scope zeroing kernel) under the conditions of the pipelined learner -- 2000 consecutive trunk passes of
+    1024 images on one stream while a second agent's update chain (its own small trunk passes, GEMMs, Adam) runs on another
+    stream and competes for CUs, LDS and memory queues.  Every pass must reproduce the features of the separate
+    elementwise GroupNorm passes (SERL_GN_FUSE=0); the worst deviation is accumulated on the device, no sync inside the loop."""
+    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=512, trunk_mode="f16x3")
+    n = 1024
+    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda")
+    monkeypatch.setenv("SERL_GN_FUSE", "0")
+    ref = core.trunk_forward(img).clone()
+    scale = float(ref.abs().max())
+    monkeypatch.setenv("SERL_GN_FUSE", "1")
+    cfg2 = O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3)
+    _, core2 = AH.make_pair(cfg2, 32)
+    db2 = AH.batch_to_device(cfg2, AH.synth_batch(cfg2, 32, seed=1))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    worst = torch.zeros((), device="cuda")
+    for it in range(2000):
+        with torch.cuda.stream(sa):
+            got = core.trunk_forward(img)
+            worst = torch.maximum(worst, (got - ref).abs().max())
+        if it % 2 == 0:
+            with torch.cuda.stream(sb):
+                core2.update_high_utd(db2, 1, None)
+    torch.cuda.synchronize()
+    w = float(worst) / scale
+    print(f"fused vs elementwise GroupNorm over 2000 co-running passes of {n} images: worst rel diff {w:.2e}")
+    assert np.isfinite(w) and w < 2e-6, w
+    assert all(np.isfinite(v) for v in core2.read_info().values())
