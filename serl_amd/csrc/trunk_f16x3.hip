@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       }
     }
   }
-  const int nchunks = a.KH * a.KW * (a.Cin >> 5), nchunks_all = nchunks;
+  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
   constexpr int cb = 0;   // first chunk
   // (native vector types: HIP's uint4 struct copies lower to memcpy and keep the arrays out of registers)
   u32x4 ra[AI], rb[BI], ra2[DEEP >= 2 ? AI : 1], rb2[DEEP >= 2 ? BI : 1], ra3[DEEP >= 3 ? AI : 1], rb3[DEEP >= 3 ? BI : 1];
@@ -327,9 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
       const int cc_ = min(c_, nchunks - 1);                                                                    \
-      /* piece-order copy (pack_dma_order_f16x3): slot s_ of row r_ already holds the unit that belongs at LDS slot s_ */ \
-      const uint16_t* wp_ = ab.wdma ? ab.wdma + ((((size_t)((n0 + r_) >> 6) * nchunks_all + cc_) * 2 + plane_) << 11) + ((r_ & 63) << 5) + s_ * 8 \
-                                    : (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (cc_ << 5) + s_ * 8;      \
+      const uint16_t* wp_ = (plane_ ? ab.wlo : ab.whi) + (size_t)(n0 + r_) * ab.K + (cc_ << 5) + s_ * 8;                  \
       RB[i] = *reinterpret_cast<const u32x4*>(wp_);                                                            \
     }                                                                                                          \
   }
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     _Pragma("unroll") for (int i = 0; i < BI; ++i) {                                                           \
       const int j_ = tid + 256 * i;                                                                            \
       const int plane_ = j_ / (BN * 4), r_ = (j_ / 4) % BN, s_ = j_ & 3;                                       \
-      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + (ab.wdma ? r_ * 64 + s_ * 16 : swz(r_, s_))) = RB[i]; \
+      *reinterpret_cast<u32x4*>(st_ + 2 * A_PLANE + plane_ * B_PLANE + swz(r_, s_)) = RB[i]; \
     }                                                                                                          \
   }
 
@@ -474,176 +472,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant of the implicit GEMM (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through registers).
-// The register-staged kernel above serialises its phases -- measured on b2_conv1: MFMA-only 164 us, + LDS fragment
-// reads 8, + ds_write staging 34, + global-load waits 57 = 263 us -- because a chunk's loads have only one MFMA
-// phase to land and the staging registers (32 per chunk in flight) leave no room for a deeper pipeline next to two
-// 64-register accumulator sets.  Here a chunk is fetched by 16-byte LDS-DMA pieces issued one chunk ahead (two LDS
-// stages; three stages = one workgroup per CU were measured slower in round 2): no staging registers, no ds_write pass, counted vmcnt waits, one raw s_barrier per chunk.
-//   * a DMA piece is 64 lanes x 16 B written lane-linearly, so swizzles are applied to the SOURCE address: a piece of
-//     the activation tile is 8 rows x 8 units (a row chunk = 32 channels = [hi8 lo8] x 4 in the split8 layout) and
-//     lane l fetches unit (l&7) ^ ((row>>1)&7) of row l>>3; a piece of a weight plane is 16 rows x 4 units and lane l
-//     fetches unit (l&3) ^ ((row>>2)&3).  Fragment reads apply the same XOR: conflict-free ds_read_b128.
-//   * out-of-image taps fetch from a zero page (the DMA cannot zero-fill).
-// Tile 128 x (64*TN) with 4 waves of 64 x (32*TN); epilogue identical to the register-staged kernel.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
+// Epilogue of a 128 x (64*TN) tile held by 4 waves of 64 x (32*TN) (LDS-DMA kernels): combine the two accumulators, raw store or
+// fused GroupNorm (+ residual) + ReLU + split8 store, statistics.
 template <int TN, int PMODE>
-__global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
-  constexpr int NSTAGE = 2;
+__device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&acc)[2][TN], f32x16 (&accx)[2][TN], int m0, int n0,
+                                                  int bn, int wm, int wn, int li, int lh) {
+  constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN;
   const ConvArgs& a = ab.c;
-  constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN, BM = 128, BN = 2 * WCOLS;
-  constexpr int A_BYTES = BM * 128, B_PLANE = BN * 64, STAGE = A_BYTES + 2 * B_PLANE;
-  constexpr int A_PIECES = BM / 8 / 4;            // per wave per chunk
-  constexpr int B_PIECES = 2 * (BN / 16) / 4;     // per wave per chunk (both planes)
-  constexpr int PIECES = A_PIECES + B_PIECES;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int id = (ab.fz.mode && ab.fz.expected) ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
-  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
-  const int m0 = bm * BM, n0 = bn * BN;
-  const int ntaps = a.KH * a.KW;
-  // activation pieces of this wave: piece q covers tile rows (q*4 + wave)*8 .. +7; this lane's row / unit in it
-  unsigned rbase[A_PIECES];   // byte offset of the centre tap's pixel (+ this lane's swizzled unit)
-  unsigned rmask[A_PIECES];
-  const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(a.in);
-#pragma unroll
-  for (int q = 0; q < A_PIECES; ++q) {
-    const int row = (q * 4 + wave) * 8 + (lane >> 3);
-    const int u = (lane & 7) ^ ((row >> 1) & 7);
-    const int m = m0 + row;
-    rbase[q] = 0; rmask[q] = 0;
-    if (m < a.M) {
-      const int n = m / a.P, rem = m - n * a.P;
-      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-      rbase[q] = (unsigned)((((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin) * 4 + u * 16);
-      for (int t = 0; t < ntaps; ++t) {
-        const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
-        if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) rmask[q] |= 1u << t;
-      }
-    }
-  }
-  // weight pieces: piece q -> plane / first row; this lane's row and swizzled unit
-  const uint8_t* wsrc[B_PIECES];
-#pragma unroll
-  for (int q = 0; q < B_PIECES; ++q) {
-    const int pb = q * 4 + wave, plane = pb / (BN / 16), prow = (pb % (BN / 16)) * 16 + (lane >> 2);
-    const int su = (lane & 3) ^ ((prow >> 2) & 3);
-    wsrc[q] = reinterpret_cast<const uint8_t*>(plane ? ab.wlo : ab.whi) + ((size_t)(n0 + prow) * ab.K) * 2 + su * 16;
-    if (ab.wdma)   // piece-order copy: block (row block, chunk, plane) of 4 KB, this lane at (row % 64) * 64 + (lane & 3) * 16
-      wsrc[q] = reinterpret_cast<const uint8_t*>(ab.wdma) +
-                ((size_t)((n0 + prow) >> 6) * (a.KH * a.KW * (a.Cin >> 5)) * 2 + plane) * 4096 + ((prow & 63) << 6) + ((lane & 3) << 4);
-  }
-  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
-  const size_t wchunk_stride = ab.wdma ? 8192 : 64;   // bytes between consecutive K chunks of a weight piece's source
-  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_chunk = 0;   // counters of the next chunk to latch (strictly in order)
-  const uint8_t* zp = zero_page + (lane & 7) * 16;
-
-  // One piece of the NEXT chunk (tap / channel offset in nx_*): pieces [0, A_PIECES) are activation pieces, the rest
-  // weight pieces.  Issued one at a time between the MFMA groups of the current chunk: an LDS-DMA instruction costs
-  // ~60 issue cycles among MFMAs but several hundred when eight of them sit in a row ahead of the MFMAs.
-  int nx_tap = 0, nx_toff = 0, nx_chunk = 0, nx_stage = 0;
-#define SERL_DMA_PIECE(PI)                                                                                     \
-  {                                                                                                            \
-    uint8_t* st_ = smemb + nx_stage * STAGE;                                                                   \
-    if ((PI) < A_PIECES) {                                                                                     \
-      const int q = (PI) < A_PIECES ? (PI) : 0;                                                                \
-      const bool ok = (rmask[q] >> nx_tap) & 1u;                                                               \
-      const uint8_t* src = ok ? in_bytes + (size_t)rbase[q] + (long)nx_toff : zp;                              \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st_ + (q * 4 + wave) * 1024), 16, 0, 0); \
-    } else {                                                                                                   \
-      const int q = (PI) >= A_PIECES ? (PI) - A_PIECES : 0;                                                    \
-      const int pb = q * 4 + wave, plane = pb / (BN / 16), prow0 = (pb % (BN / 16)) * 16;                      \
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[q] + (size_t)nx_chunk * wchunk_stride),                         \
-                                       (lds_void_t*)(st_ + A_BYTES + plane * B_PLANE + prow0 * 64), 16, 0, 0); \
-    }                                                                                                          \
-  }
-  // latch the addressing of chunk l_chunk into nx_* and advance the counters
-#define SERL_DMA_NEXT(STG)                                                                                     \
-  {                                                                                                            \
-    /* past the last chunk the counters stop: the last chunk is fetched again into the free stage (no branch */ \
-    /* around the DMA instructions inside the MFMA block; one wasted chunk of traffic per tile)              */ \
-    nx_tap = l_tap; nx_chunk = l_chunk; nx_stage = (STG);                                                      \
-    nx_toff = (((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + l_ci0) * 4;                                 \
-    if (l_chunk + 1 < nchunks) {                                                                               \
-      ++l_chunk;                                                                                               \
-      l_ci0 += 32;                                                                                             \
-      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
-    }                                                                                                          \
-  }
-#define SERL_DMA_ISSUE_ALL()                                                                                   \
-  {                                                                                                            \
-    SERL_DMA_PIECE(0) SERL_DMA_PIECE(1) SERL_DMA_PIECE(2) SERL_DMA_PIECE(3)                                    \
-    if (PIECES > 4) SERL_DMA_PIECE(4) if (PIECES > 5) SERL_DMA_PIECE(5)                                        \
-    if (PIECES > 6) SERL_DMA_PIECE(6) if (PIECES > 7) SERL_DMA_PIECE(7)                                        \
-  }
-
-  f32x16 acc[TM][TN], accx[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
-  const int li = lane & 31, lh = lane >> 5;
-  int aoff[TM], asw[TM], boff[TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int row = wm * WROWS + tm * 32 + li;
-    aoff[tm] = row * 128;
-    asw[tm] = (row >> 1) & 7;
-  }
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) boff[tn] = wn * WCOLS + tn * 32 + li;
-
-  // prologue: NSTAGE - 1 chunks in flight
-  SERL_DMA_NEXT(0);
-  SERL_DMA_ISSUE_ALL();
-  constexpr int GROUPS = 2 * TM * TN;   // MFMA groups (3 MFMAs each) per chunk
-  for (int c = 0; c < nchunks; ++c) {
-    // chunk c has landed once at most the pieces of the chunks issued after it are outstanding
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");   // every wave's pieces of chunk c are in LDS; stage (c-1) % NSTAGE is free
-    SERL_DMA_NEXT((c + NSTAGE - 1) % NSTAGE);  // the chunk to fetch during this iteration (if any)
-    const uint8_t* st = smemb + (c % NSTAGE) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ahi[TM], alo[TM], bhi[TN], blo[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int u = 2 * (2 * ks + lh);   // hi unit of this lane's k-block; the lo' unit is the next one
-        ahi[tm] = *reinterpret_cast<const f16x8*>(st + aoff[tm] + ((u ^ asw[tm]) << 4));
-        alo[tm] = *reinterpret_cast<const f16x8*>(st + aoff[tm] + (((u + 1) ^ asw[tm]) << 4));
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int off = A_BYTES + swz(boff[tn], 2 * ks + lh);
-        bhi[tn] = *reinterpret_cast<const f16x8*>(st + off);
-        blo[tn] = *reinterpret_cast<const f16x8*>(st + B_PLANE + off);
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[tm], bhi[tn], accx[tm][tn], 0, 0, 0);
-          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], blo[tn], accx[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
-          // one or two DMA pieces of the next chunk ride behind every MFMA group
-          const int g = (ks * TM + tm) * TN + tn;
-#pragma unroll
-          for (int pi = 0; pi < PIECES; ++pi)
-            if (pi % GROUPS == g) SERL_DMA_PIECE(pi)
-        }
-    }
-  }
-#undef SERL_DMA_PIECE
-#undef SERL_DMA_NEXT
-#undef SERL_DMA_ISSUE_ALL
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
-
   const int wrow0 = m0 + wm * WROWS;
   float winv[TN];
 #pragma unroll
@@ -718,6 +553,199 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     const float var = fmaxf((float)(m2 - mean * mean), 0.f);
     fused_gn_store<TM, TN>(ab, acc, fres, wrow0 / a.P, wrow0, n0 + wn * WCOLS, li, lh, true, (float)mean, rsqrtf(var + 1e-5f));
   }
+}
+
+// LDS-DMA implicit GEMM (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through registers).
+// The register-staged kernel above serialises its phases -- measured on b2_conv1: MFMA-only 164 us, + LDS fragment
+// reads 8, + ds_write staging 34, + global-load waits 57 = 263 us.  Here the K loop advances in 16-channel SLOTS
+// (A: 128 rows x 64 B = [hi8 lo8 hi8 lo8] of the split8 layout, B: 64*TN rows x 64 B = [hi k0-7, hi k8-15, lo k0-7, lo k8-15])
+// through a ring of four LDS positions:
+//   * a slot's 16-byte LDS-DMA pieces are issued FOUR slots ahead (48 MFMAs = 1536 matrix-pipe cycles before use), one piece
+//     behind every MFMA group (an LDS-DMA instruction costs ~60 issue cycles among MFMAs, several hundred when eight sit in
+//     a row); the wait at the top of an iteration is a COUNTED vmcnt that leaves the two youngest slots in flight, one raw
+//     s_barrier per slot;
+//   * the fragments of slot c + 1 are read from LDS under the MFMAs of slot c (its ring position is refilled with slot c + 4
+//     once every wave has passed the next barrier with lgkmcnt(0));
+//   * a DMA piece is 64 lanes x 16 B written lane-linearly = 16 rows x 4 units, so the bank swizzle is applied on the SOURCE
+//     side: lane l fetches unit (l & 3) ^ ((row >> 2) & 3) of row l >> 2, and the weights are pre-packed in piece order with
+//     the swizzle baked in (pack_dma_order_kernel): conflict-free ds_read_b128;
+//   * out-of-image taps fetch from a zero page (the DMA cannot zero-fill).
+// Round 2's version (two LDS stages of 32 channels, a chunk's last piece issued right before the vmcnt(0) that waited for
+// it) was 2-8 % slower per conv (b2_conv1 229 -> 210 us, b3_conv1 215 -> 193 us, same-call A/B; profiles/README.md).
+// Timing-only ablation of this kernel on b2_conv1 (222 us on that box): MFMAs + barriers only 133 us (ideal at 2.4 GHz:
+// 92 us -- the sustained clock under this load is ~1.7 GHz), + fragment reads 179, + DMA pieces (no reads) 184, DMA + reads
+// without MFMAs 156, no barrier 226: reads and DMA cost ~50 us each ON TOP of the MFMA time wherever they sit in the
+// instruction stream (pinning the order changed 214 -> 210 us), i.e. a shared-throughput / power cost, not exposed latency.
+// Tile 128 x (64*TN) with 4 waves of 64 x (32*TN).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int TN, int PMODE>
+__global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
+  constexpr int NS = 4;
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN, BM = 128, BN = 2 * WCOLS;
+  constexpr int A_BYTES = BM * 64, SLOT = A_BYTES + BN * 64;
+  constexpr int A_PIECES = BM / 16 / 4;           // per wave per slot
+  constexpr int B_PIECES = BN / 16 / 4;
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int id = (ab.fz.mode && ab.fz.expected) ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int ntaps = a.KH * a.KW;
+  unsigned rbase[A_PIECES], rmask[A_PIECES];
+  const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(a.in);
+#pragma unroll
+  for (int q = 0; q < A_PIECES; ++q) {
+    const int row = (q * 4 + wave) * 16 + (lane >> 2);
+    const int u = (lane & 3) ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    rbase[q] = 0; rmask[q] = 0;
+    if (m < a.M) {
+      const int n = m / a.P, rem = m - n * a.P;
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      rbase[q] = (unsigned)((((long)(n * a.Hi + oy * a.stride) * a.Wi + ox * a.stride) * a.Cin) * 4 + u * 16);
+      for (int t = 0; t < ntaps; ++t) {
+        const int iy = oy * a.stride - a.pad + t / a.KW, ix = ox * a.stride - a.padw + t % a.KW;
+        if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) rmask[q] |= 1u << t;
+      }
+    }
+  }
+  const int nslots = ntaps * (a.Cin >> 4);
+  // weight pieces (ring-order copy: 4 KB per (64-row block, slot), swizzle baked in): this lane's 16 bytes of piece q
+  const uint8_t* wsrc[B_PIECES];
+#pragma unroll
+  for (int q = 0; q < B_PIECES; ++q) {
+    const int prow = (q * 4 + wave) * 16 + (lane >> 2);
+    wsrc[q] = reinterpret_cast<const uint8_t*>(ab.wdma) + (size_t)((n0 + prow) >> 6) * nslots * 4096 + ((prow & 63) << 6) + ((lane & 3) << 4);
+  }
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_slot = 0;   // counters of the next slot to latch (strictly in order)
+  const uint8_t* zp = zero_page + (lane & 3) * 16;
+  int nx_tap = 0, nx_toff = 0, nx_k = 0, nx_ring = 0;
+#define SERL_RING_PIECE(PI)                                                                                    \
+  {                                                                                                            \
+    uint8_t* st_ = smemb + nx_ring * SLOT;                                                                     \
+    if ((PI) < A_PIECES) {                                                                                     \
+      const int q = (PI) < A_PIECES ? (PI) : 0;                                                                \
+      const bool ok = (rmask[q] >> nx_tap) & 1u;                                                               \
+      const uint8_t* src = ok ? in_bytes + (size_t)rbase[q] + (long)nx_toff : zp;                              \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st_ + (q * 4 + wave) * 1024), 16, 0, 0); \
+    } else {                                                                                                   \
+      const int q = (PI) >= A_PIECES ? (PI) - A_PIECES : 0;                                                    \
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc[q] + (size_t)nx_k * 4096),                           \
+                                       (lds_void_t*)(st_ + A_BYTES + (q * 4 + wave) * 1024), 16, 0, 0);        \
+    }                                                                                                          \
+  }
+  // past the last slot the counters stop: the last slot is fetched again into a free ring position (uniform loop, counted waits)
+#define SERL_RING_NEXT(RING)                                                                                   \
+  {                                                                                                            \
+    nx_tap = l_tap; nx_k = l_slot; nx_ring = (RING);                                                           \
+    nx_toff = (((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + l_ci0) * 4;                                 \
+    if (l_slot + 1 < nslots) {                                                                                 \
+      ++l_slot;                                                                                                \
+      l_ci0 += 16;                                                                                             \
+      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
+    }                                                                                                          \
+  }
+  f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  int ahi_off[TM], alo_off[TM], bhi_off[TN], blo_off[TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = wm * WROWS + tm * 32 + li, sw = (row >> 2) & 3;
+    ahi_off[tm] = row * 64 + (((2 * lh) ^ sw) << 4);
+    alo_off[tm] = row * 64 + (((2 * lh + 1) ^ sw) << 4);
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int row = wn * WCOLS + tn * 32 + li, sw = (row >> 2) & 3;
+    bhi_off[tn] = A_BYTES + row * 64 + ((lh ^ sw) << 4);
+    blo_off[tn] = A_BYTES + row * 64 + (((2 + lh) ^ sw) << 4);
+  }
+  // prologue: NS slots in flight; slot 0's fragments into the first register set
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    SERL_RING_NEXT(p);
+#pragma unroll
+    for (int pi = 0; pi < PIECES; ++pi) SERL_RING_PIECE(pi)
+  }
+  constexpr int GROUPS = TM * TN;
+  f16x8 fa[2][2 * TM], fb[2][2 * TN];   // [register set][hi/lo per tile]
+#define SERL_RING_READ(SET, ST)                                                                \
+  {                                                                                            \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                        \
+      fa[SET][2 * tm] = *reinterpret_cast<const f16x8*>((ST) + ahi_off[tm]);                   \
+      fa[SET][2 * tm + 1] = *reinterpret_cast<const f16x8*>((ST) + alo_off[tm]);               \
+    }                                                                                          \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                        \
+      fb[SET][2 * tn] = *reinterpret_cast<const f16x8*>((ST) + bhi_off[tn]);                   \
+      fb[SET][2 * tn + 1] = *reinterpret_cast<const f16x8*>((ST) + blo_off[tn]);               \
+    }                                                                                          \
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PIECES) : "memory");
+  asm volatile("s_barrier" ::: "memory");
+  SERL_RING_READ(0, smemb);
+  // iteration c: slot c is in register set CUR; slot c + 1 must have landed (slots c + 2, c + 3 may be in flight) and every
+  // wave must be done reading slot c from LDS before its ring position is refilled with slot c + 4
+#define SERL_RING_READ1(SET, ST, I)                                                            \
+  {                                                                                            \
+    if ((I) < 2 * TM) {                                                                        \
+      const int tm_ = (I) >> 1;                                                                \
+      fa[SET][I] = *reinterpret_cast<const f16x8*>((ST) + (((I) & 1) ? alo_off[tm_ < TM ? tm_ : 0] : ahi_off[tm_ < TM ? tm_ : 0])); \
+    } else {                                                                                   \
+      const int j_ = (I) - 2 * TM, tn_ = j_ >> 1;                                              \
+      fb[SET][j_ < 2 * TN ? j_ : 0] = *reinterpret_cast<const f16x8*>((ST) + ((j_ & 1) ? blo_off[tn_ < TN ? tn_ : 0] : bhi_off[tn_ < TN ? tn_ : 0])); \
+    }                                                                                          \
+  }
+  // iteration c: slot c is in register set CUR; slot c + 1 must have landed (slots c + 2, c + 3 may be in flight) and every
+  // wave must be done reading slot c from LDS before its ring position is refilled with slot c + 4.  Per MFMA group the
+  // instruction order is pinned with scheduling fences: cross MFMA 1, fragment reads of the next slot, hi*hi MFMA, one
+  // LDS-DMA piece, cross MFMA 2 (hipcc otherwise sinks the reads behind the MFMAs that free their registers and issues
+  // the DMA pieces back to back at the end of the iteration).
+#define SERL_RING_ITER(C, CUR)                                                                 \
+  {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PIECES) : "memory");        \
+    asm volatile("s_barrier" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    SERL_RING_NEXT((C) % NS);                                                                  \
+    const uint8_t* stn = smemb + (((C) + 1) % NS) * SLOT;                                      \
+    constexpr int NREAD = 2 * TM + 2 * TN, RPG = (NREAD + GROUPS - 1) / GROUPS;                \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                          \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                      \
+        const int g = tm * TN + tn;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][2 * tm + 1], fb[CUR][2 * tn], accx[tm][tn], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < RPG; ++i) if (g * RPG + i < NREAD) SERL_RING_READ1(1 - (CUR), stn, g * RPG + i) \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][2 * tm], fb[CUR][2 * tn], acc[tm][tn], 0, 0, 0); \
+        _Pragma("unroll") for (int pi = 0; pi < PIECES; ++pi)                                  \
+          if (pi % GROUPS == g) SERL_RING_PIECE(pi)                         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][2 * tm], fb[CUR][2 * tn + 1], accx[tm][tn], 0, 0, 0); \
+      }                                                                                        \
+  }
+  for (int c = 0; c < nslots; c += 2) {   // nslots is even (Cin % 32 == 0)
+    SERL_RING_ITER(c, 0);
+    SERL_RING_ITER(c + 1, 1);
+  }
+#undef SERL_RING_ITER
+#undef SERL_RING_READ
+#undef SERL_RING_READ1
+#undef SERL_RING_PIECE
+#undef SERL_RING_NEXT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
+  dma_tile_epilogue<TN, PMODE>(ab, acc, accx, m0, n0, bn, wm, wn, li, lh);
 }
 
 // Epilogue of a 256 x 64 output tile held by 4 waves of 64 x 64 (all rows in image n_img): combine the two accumulators,
@@ -1372,19 +1400,17 @@ __global__ __launch_bounds__(256) void pack_slab_order_kernel(const uint16_t* hi
   reinterpret_cast<uint4*>(slab)[e] = *reinterpret_cast<const uint4*>(src);
 }
 
-// Copy of the packed planes in the LDS-DMA kernel's piece order: per (64-row block, 32-wide K chunk, plane) one contiguous
-// 4 KB block [row][slot], slot s of row r holding the 16-byte unit s ^ ((r >> 2) & 3) -- the swizzle the kernel applies on
-// the source side -- so that lane l of a 16-row piece reads 16 bytes at l * 16.
+// Copy of the packed planes in the LDS-DMA kernel's piece order: per (64-row block, 16-wide K slot) one contiguous 4 KB block
+// [row][position], position p of row r holding unit p ^ ((r >> 2) & 3); unit u = plane (u >> 1), k-half (u & 1).
 __global__ __launch_bounds__(256) void pack_dma_order_kernel(const uint16_t* hi, const uint16_t* lo, uint16_t* dma, int K, int Cout) {
-  const int nch = K >> 5;
+  const int nsl = K >> 4;
   const long e = (long)blockIdx.x * 256 + threadIdx.x;   // one thread per 16-byte unit
   if (e >= (long)2 * Cout * K / 8) return;
-  const int t = (int)(e & 255), r64 = t >> 2, slot = t & 3;
-  long blk = e >> 8;
-  const int plane = (int)(blk & 1); blk >>= 1;
-  const int chunk = (int)(blk % nch);
-  const int j = (int)(blk / nch);
-  const uint16_t* src = (plane ? lo : hi) + (size_t)(j * 64 + r64) * K + chunk * 32 + ((slot ^ ((r64 >> 2) & 3)) << 3);
+  const int t = (int)(e & 255), r64 = t >> 2, pos = t & 3;
+  const long blk = e >> 8;
+  const int slot = (int)(blk % nsl), j = (int)(blk / nsl);
+  const int u = pos ^ ((r64 >> 2) & 3);
+  const uint16_t* src = ((u >> 1) ? lo : hi) + (size_t)(j * 64 + r64) * K + slot * 16 + ((u & 1) << 3);
   reinterpret_cast<uint4*>(dma)[e] = *reinterpret_cast<const uint4*>(src);
 }
 
@@ -1649,22 +1675,22 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       const int tn = cfg == 0 ? 2 : 1, bn = 64 * tn;
       a.tiles_m = cdiv(a.M, 128); a.tiles_n = Cout / bn;
       const dim3 g(a.tiles_m * a.tiles_n);
-      const size_t l = (size_t)2 * (128 * 128 + 2 * bn * 64);   // two LDS stages (three = one workgroup per CU: measured slower)
+      const size_t l = (size_t)4 * (128 * 64 + bn * 64);   // ring of four 16-channel slots
       if (pmode == 1 && cfg == 4) pmode = 3;
       if (fuse && fuse->mode && pmode == 0 && a.P % 128 == 0 && a.tiles_n <= kSyncPerImage && can_wait(a.P / 128 * a.tiles_n)) {
         ab.fz = *fuse; ab.fz.expected = a.P / 128; ab.fz.group = a.P / 128 * a.tiles_n; fused = true;
       } else if (fuse && fuse->mode && pmode == 0 && a.P == 64 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 64) {
         ab.fz = *fuse; ab.fz.expected = 0; fused = true;   // LOCAL: a wave = one (image, group), no exchange
       }
-#define SERL_LAUNCH_DMA(TN_)                                                                                        \
+#define SERL_LAUNCH_DMA(KERN, TN_, ...)                                                                              \
   do {                                                                                                              \
-    if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 0>), g, block, l, stream, ab, zero_page);        \
-    else if (pmode == 1) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 1>), g, block, l, stream, ab, zero_page);   \
-    else if (pmode == 2) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 2>), g, block, l, stream, ab, zero_page);   \
-    else hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 3>), g, block, l, stream, ab, zero_page);                   \
+    if (pmode == 0) hipLaunchKernelGGL((KERN<TN_, 0 __VA_ARGS__>), g, block, l, stream, ab, zero_page);        \
+    else if (pmode == 1) hipLaunchKernelGGL((KERN<TN_, 1 __VA_ARGS__>), g, block, l, stream, ab, zero_page);   \
+    else if (pmode == 2) hipLaunchKernelGGL((KERN<TN_, 2 __VA_ARGS__>), g, block, l, stream, ab, zero_page);   \
+    else hipLaunchKernelGGL((KERN<TN_, 3 __VA_ARGS__>), g, block, l, stream, ab, zero_page);                   \
   } while (0)
-      if (tn == 2) SERL_LAUNCH_DMA(2);
-      else SERL_LAUNCH_DMA(1);
+      if (tn == 2) SERL_LAUNCH_DMA(conv_dma_f16x3_kernel, 2);
+      else SERL_LAUNCH_DMA(conv_dma_f16x3_kernel, 1);
 #undef SERL_LAUNCH_DMA
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2, 0);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2, 0);
