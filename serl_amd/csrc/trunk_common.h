@@ -103,8 +103,10 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
 
 // conv_init in split-fp16 (weights re-indexed and padded to [64][176])
 int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, hipStream_t stream);
-// pool_gamma != nullptr: fused 3x3/2 max-pool (trunk_f16x3.hip); `out` then receives the three compact outputs
+// pool_gamma != nullptr: fused 3x3/2 max-pool (trunk_f16x3.hip); `out` then receives the three compact outputs;
+// complete_pool: the pooled tensor is final (whole-image chunks), no pool_finish pass needed
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr, int* ticket = nullptr);
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma = nullptr, int* ticket = nullptr,
+                           bool complete_pool = false);
 
 }  // namespace serl

@@ -218,7 +218,7 @@ __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16
     } else {
       gn_coef1<true>(fz.gn, n_img, c, sc, sh);
     }
-    if (fz.mode == 3) gn_coef1<false>(fz.res_gn, n_img, c, rs, rh);
+    if (fz.mode >= 3) gn_coef1<false>(fz.res_gn, n_img, c, rs, rh);
     const int cbyte = (c & ~7) * 4 + (odd ? 16 : 0) + (c & 6) * 2;
     const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh}, rs2 = {rs, rs}, rh2 = {rh, rh};
 #pragma unroll
@@ -241,6 +241,10 @@ __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16
         } else if (fz.mode == 3) {
           const f32x2 x = {__builtin_bit_cast(float, res.v[tm][tn][r0]), __builtin_bit_cast(float, res.v[tm][tn][r1])};
           v = (x * rs2 + rh2) + v;
+        } else if (fz.mode == 4) {   // residual = relu(GroupNorm(raw)): the block input that was never materialised (RAWIN)
+          const f32x2 x = {__builtin_bit_cast(float, res.v[tm][tn][r0]), __builtin_bit_cast(float, res.v[tm][tn][r1])};
+          const f32x2 y = x * rs2 + rh2;
+          v = (f32x2){fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)} + v;
         }
         v = (f32x2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
         const h16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -813,6 +817,11 @@ __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&a
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowslabPix = 340;   // (8 + 2) x 34 (Wo = 32); (16 + 2) x 18 = 324 (Wo = 16)
 constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (64 * 16 + 64);
+// RAWIN: the input is the RAW fp32 tensor of the producing layer (conv_init's completed pooling output) and GroupNorm + ReLU +
+// the hi / lo' split are applied while a slab is staged (a.in_gn: per-channel scale / shift of this tile's image, held in
+// LDS) -- the elementwise pass that would materialise the split8 tensor (read 268 MB + write 268 MB per trunk pass) is gone.
+// A thread then stages one (pixel, k-half) = 8 channels per slab part: two 16-byte fp32 loads in, one hi and one lo' unit out.
+template <bool RAWIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
@@ -839,6 +848,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   const int c16n = a.Cin >> 4, nchunks = 3 * c16n;
   int rbase[3][AJ];        // element offset of unit (part, j) of a slab at channel group 0 (clamped into the image)
   unsigned okbits = 0;     // bit part*AJ + j: the unit's pixel lies inside the image (else it is stored as zeros)
+  __shared__ float s_gn[2][128];   // RAWIN: GroupNorm scale / shift per input channel of this tile's image
+  if (RAWIN) {
+    if (tid < a.Cin) gn_coef1<false>(a.in_gn, n_img, tid, s_gn[0][tid], s_gn[1][tid]);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {   // (pixel, k-half) = part * 256 + tid; both staging registers belong to it
+      const int v = part * 256 + tid, pix = v >> 1, kh = v & 1;
+      const int sy = pix / pw, sx = pix - sy * pw;
+      const int iy = oy0 - 1 + sy, ix = sx - 1;
+      const int iyc = min(max(iy, 0), a.Hi - 1), ixc = min(max(ix, 0), a.Wi - 1);
+      rbase[part][0] = ((n_img * a.Hi + iyc) * a.Wi + ixc) * a.Cin + 8 * kh;
+      rbase[part][1] = rbase[part][0] + 4;
+      if (pix < npix && iy == iyc && ix == ixc) okbits |= 3u << (part * AJ);
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
   for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -850,6 +874,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
       rbase[part][j] = ((n_img * a.Hi + iyc) * a.Wi + ixc) * a.Cin + 4 * q;
       if (pix < npix && iy == iyc && ix == ixc) okbits |= 1u << (part * AJ + j);
     }
+  }
   const int b_plane = tid >> 7, b_cout = (tid >> 1) & 63, b_half = tid & 1;
   const uint16_t* wrow = (b_plane ? ab.wlo : ab.whi) + (size_t)(n0 + b_cout) * ab.K + b_half * 8;
   // fetch-order copy: block (column tile bn, group, tap) of 2048 halfs, this thread's unit at tid * 8
@@ -864,7 +889,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
     RB[kx] = wslab ? *reinterpret_cast<const u32x4*>(wslab + ((size_t)(((BG) * 3 + (BKY)) * 3 + kx) << 11)) \
                    : *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
-#define SERL_RS_STORE_A(RA, PART, ABUF)                                                            \
+#define SERL_RS_STORE_A(RA, PART, ABUF, CGN)                                                       \
+  if (RAWIN) {                                                                                     \
+    const int v_ = (PART) * 256 + tid, kh_ = v_ & 1, cb_ = ((CGN) << 4) + 8 * kh_;                 \
+    u32x4 hi_ = {0u, 0u, 0u, 0u}, lo_ = {0u, 0u, 0u, 0u};                                          \
+    if ((okbits >> ((PART) * AJ)) & 1u) {                                                          \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+        const float4 x_ = __builtin_bit_cast(float4, RA[j]);                                       \
+        const float4 sc_ = *reinterpret_cast<const float4*>(&s_gn[0][cb_ + 4 * j]);                \
+        const float4 sh_ = *reinterpret_cast<const float4*>(&s_gn[1][cb_ + 4 * j]);                \
+        const float4 y_ = make_float4(fmaxf(x_.x * sc_.x + sh_.x, 0.f), fmaxf(x_.y * sc_.y + sh_.y, 0.f), \
+                                      fmaxf(x_.z * sc_.z + sh_.z, 0.f), fmaxf(x_.w * sc_.w + sh_.w, 0.f)); \
+        uint2 h2_, l2_;                                                                            \
+        split4(y_, h2_, l2_);                                                                      \
+        hi_[2 * j] = h2_.x; hi_[2 * j + 1] = h2_.y; lo_[2 * j] = l2_.x; lo_[2 * j + 1] = l2_.y;    \
+      }                                                                                            \
+    }                                                                                              \
+    if (v_ < kRowslabPix * 2) {                                                                    \
+      uint8_t* d_ = smA + (ABUF) * A_BYTES + (2 * kh_) * A_REGION + (v_ >> 1) * 16;                \
+      *reinterpret_cast<u32x4*>(d_) = hi_;                                                         \
+      *reinterpret_cast<u32x4*>(d_ + A_REGION) = lo_;                                              \
+    }                                                                                              \
+  } else                                                                                           \
   _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                 \
     const int u_ = ((PART) * AJ + j) * 256 + tid;                                                  \
     u32x4 v = RA[j];                                                                               \
@@ -887,8 +933,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 #define SERL_RS_STORES(C, CG, KY, RA, RB)                                                          \
   {                                                                                                \
     SERL_RS_STORE_B(RB, ((C) + 1) & 1);                                                            \
-    if ((KY) == 0) { SERL_RS_STORE_A(RA, 0, ((CG) + 1) & 1); } else if ((KY) == 1) { SERL_RS_STORE_A(RA, 1, ((CG) + 1) & 1); } \
-    else { SERL_RS_STORE_A(RA, 2, ((CG) + 1) & 1); }                                               \
+    const int sn2_ = min((CG) + 1, c16n - 1);                                                      \
+    if ((KY) == 0) { SERL_RS_STORE_A(RA, 0, ((CG) + 1) & 1, sn2_); } else if ((KY) == 1) { SERL_RS_STORE_A(RA, 1, ((CG) + 1) & 1, sn2_); } \
+    else { SERL_RS_STORE_A(RA, 2, ((CG) + 1) & 1, sn2_); }                                         \
   }
 #define SERL_RS_COMPUTE(C, CG, KY)                                                                 \
   {                                                                                                \
@@ -935,7 +982,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 #pragma unroll
   for (int part = 0; part < 3; ++part) {
     SERL_RS_LOAD_A(ra, part, 0);
-    SERL_RS_STORE_A(ra, part, 0);
+    SERL_RS_STORE_A(ra, part, 0, 0);
   }
   SERL_RS_STORE_B(rb, 0);
   __syncthreads();
@@ -1011,7 +1058,12 @@ constexpr int kC8PBytes = 14336;             // patch (37 x 384 = 14208 B) / row
 constexpr int kC8Lds = 2 * kC8WBytes + kC8PBytes;
 static_assert(kCbPatch * kC8Pitch <= kC8PBytes, "patch does not fit");
 
-template <bool POOL>
+// POOL: 0 = raw conv output; 1 = in-tile part of the pooling windows + first rows / columns (completed by
+// pool_finish_split_kernel; chunks of 4 tiles: the path for few images); 2 = COMPLETE pooling: a chunk is a whole image walked
+// in reverse raster order, so the first row of the tile below and the first column of the tile to the right -- the missing
+// third row / column of the windows on this tile's bottom / right edge -- were written by THIS workgroup one to five tiles
+// earlier and are read back from L2 (same CU: no cross-XCD coherence involved); no second pass over the pooled tensor.
+template <int POOL>
 __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   uint8_t* w_hi = smemb;
@@ -1030,9 +1082,11 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   const bool aligned = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.img) & 3) == 0;
   uint32_t pre[2][3];
   unsigned pmask[2];   // bit j: pixel j of the group is inside the image
+  const int tpi = a.tiles_y * a.tiles_x;
+#define SERL_C8_ORDER(T) (POOL == 2 ? (T) - (T) % tpi + (tpi - 1 - (T) % tpi) : (T))   /* reverse raster inside an image */
 #define SERL_C8_FETCH(TILE)                                                                             \
   {                                                                                                     \
-    int b_ = (TILE);                                                                                    \
+    int b_ = SERL_C8_ORDER(TILE);                                                                       \
     const int tx_ = b_ % a.tiles_x;                                                                     \
     b_ /= a.tiles_x;                                                                                    \
     const int ty_ = b_ % a.tiles_y;                                                                     \
@@ -1082,7 +1136,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     const bool first_of_chunk = tile == chunk * a.chunk;
     if (first_of_chunk && tid == 0)
       s_next_chunk = (int)gridDim.x + __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    int b = tile;
+    int b = SERL_C8_ORDER(tile);
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
     const int ty = b % a.tiles_y;
@@ -1156,7 +1210,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= winv[tn];   // exact (power of two)
-    if (!POOL) {
+    if (POOL == 0) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1174,6 +1228,32 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
           }
         }
     } else {  // fused 3x3/2 max-pool (every tile is full)
+      // POOL == 2: the neighbours' first column / first row (raw values written by this workgroup at earlier tiles)
+      float nb_col[2][4], nb_row[2][4][3];
+      const bool has_right = POOL == 2 && tx + 1 < a.tiles_x, has_below = POOL == 2 && ty + 1 < a.tiles_y;
+      if (POOL == 2) {
+        if (has_right && lh) {
+          const float* fcn = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + tx + 1) * 64 + li;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nb_col[tn][i] = fcn[(size_t)i * a.tiles_x * 64 + tn * 32];
+        }
+        if (has_below && wave == 3) {
+          const float* frn = a.first_rows + (((size_t)n * a.tiles_y + ty + 1) * a.Wo + ox0) * 64 + li;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+              const int px = 2 * (2 * (sl >> 1) + lh) + (sl & 1);
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const int x = min(2 * px + dx, a.Wo - 1 - ox0);   // (the clamped duplicate leaves the max unchanged)
+                nb_row[tn][sl][dx] = frn[(size_t)x * 64 + tn * 32];
+              }
+            }
+        }
+      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1225,6 +1305,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
           const float r0 = __shfl_xor(v0[0], 32), r1 = __shfl_xor(v0[1], 32);
           hrow[tn][i][1] = fmaxf(part[0], lh ? r1 : r0);
           hrow[tn][i][3] = lh ? part[1] : fmaxf(part[1], r1);   // lh = 1, q = 1: column 16 belongs to the next tile
+          if (POOL == 2 && has_right && lh) hrow[tn][i][3] = fmaxf(hrow[tn][i][3], sg * nb_col[tn][i]);
         }
       }
       __syncthreads();  // every wave is done reading the patch: its first 8 KB become the row-exchange buffer
@@ -1245,6 +1326,8 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
           const float even = fmaxf(fmaxf(hrow[tn][0][sl], hrow[tn][1][sl]), hrow[tn][2][sl]);
           float odd = fmaxf(hrow[tn][2][sl], hrow[tn][3][sl]);
           if (wave < 3) odd = fmaxf(odd, ex[(((wave + 1) * 2 + tn) * 4 + sl) * 64 + lane]);
+          else if (POOL == 2 && has_below)   // row 16 = the first row of the tile below
+            odd = fmaxf(odd, fmaxf(fmaxf(sg * nb_row[tn][sl][0], sg * nb_row[tn][sl][1]), sg * nb_row[tn][sl][2]));
           orow[(size_t)px * 64] = sg * even;
           orow[((size_t)Wp + px) * 64] = sg * odd;
         }
@@ -1261,6 +1344,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     }
   }
 #undef SERL_C8_FETCH
+#undef SERL_C8_ORDER
 }
 
 // Block-wide max of |v| (256 threads) -> power-of-two scale that puts it into [2^(top-1), 2^top).
@@ -1308,7 +1392,7 @@ int pack_conv_init_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv,
 }
 
 int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, double* stats, int N, int H, int W,
-                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma, int* ticket) {
+                           int Ho, int Wo, hipStream_t stream, const float* pool_gamma, int* ticket, bool complete_pool) {
   ConvInitArgsB a{};
   a.img = img; a.whi = w.hi; a.wlo = w.lo; a.winv = w.inv; a.out = out; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
@@ -1316,7 +1400,7 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   SERL_REQUIRE(ticket != nullptr, "conv_init needs a chunk ticket");
   const int tpi = a.tiles_y * a.tiles_x;
-  a.chunk = tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1);
+  a.chunk = (pool_gamma && complete_pool) ? tpi : (tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1));
   a.ticket = ticket;
   // 2 persistent workgroups per CU
   const int grid = std::min(a.total_tiles / a.chunk, 512);
@@ -1327,9 +1411,10 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
     a.pooled = out;
     a.first_rows = a.pooled + (size_t)N * (Ho / 2) * (Wo / 2) * 64;
     a.first_cols = a.first_rows + (size_t)N * a.tiles_y * Wo * 64;
-    hipLaunchKernelGGL(conv_init_u8_kernel<true>, dim3(grid), dim3(256), kC8Lds, stream, a);
+    if (complete_pool) hipLaunchKernelGGL(conv_init_u8_kernel<2>, dim3(grid), dim3(256), kC8Lds, stream, a);
+    else hipLaunchKernelGGL(conv_init_u8_kernel<1>, dim3(grid), dim3(256), kC8Lds, stream, a);
   } else {
-    hipLaunchKernelGGL(conv_init_u8_kernel<false>, dim3(grid), dim3(256), kC8Lds, stream, a);
+    hipLaunchKernelGGL(conv_init_u8_kernel<0>, dim3(grid), dim3(256), kC8Lds, stream, a);
   }
   SERL_HIP(hipGetLastError());
   return SERL_OK;
@@ -1614,9 +1699,21 @@ static int resident_workgroups(hipStream_t stream) {
   return n;
 }
 
+struct RawInput { const float* raw; GnRef gn; };   // a conv input still in raw fp32 form + the GroupNorm to apply on load
+
+// shapes the row-slab kernel takes: stride-1 3x3 convs with 64 or 128 output channels on 32- or 16-pixel-wide maps
+static bool rowslab_shape_ok(int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride) {
+  return ksz == 3 && stride == 1 && Cout <= 128 && Cout / 64 <= kSyncPerImage && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
+         (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && (long)N * Hi * Wi * Cin < (1L << 31);
+}
+// the fused epilogue's wait needs more than 8 (G - 1) co-resident workgroups (see FuseArgs); demand twice that of the
+// CUs this stream may use at ONE workgroup per CU, else run the separate elementwise pass
+static bool fused_can_wait(hipStream_t stream, int G) { return resident_workgroups(stream) >= 16 * (G - 1) + 1; }
+
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
-                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr) {
+                             hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
+                             const RawInput* raw_in = nullptr) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -1655,22 +1752,24 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<WM, WN, TM, TN, 3, DEEP>), grid, block, lds, stream, ab);                   \
   } while (0)
     // row-slab kernel: stride-1 3x3 convs with 64 or 128 output channels on 32- or 16-pixel-wide maps (stage 0, b1_conv1)
-    const bool slab_ok = ksz == 3 && stride == 1 && Cout <= 128 && Cout / 64 <= kSyncPerImage && Cin % 16 == 0 && Hi == Ho && Wi == Wo &&
-                         (Wo == 32 || Wo == 16) && Ho % (256 / Wo) == 0 && a.pad == 1 && a.padw == 1 && w.slab != nullptr &&
-                         (long)N * Hi * Wi * Cin < (1L << 31);
+    const bool slab_ok = rowslab_shape_ok(N, Hi, Wi, Cin, Ho, Wo, Cout, ksz, stride) && a.pad == 1 && a.padw == 1 && w.slab != nullptr;
+    SERL_REQUIRE(!raw_in || (slab_ok && Cin <= 128), "raw input is only supported by the row-slab kernel");
     // LDS-DMA kernel: everything else with at least 512 128-row tiles (32-bit byte offsets into the input)
     const bool dma_ok = (cfg == 0 || cfg == 4) && Cin % 32 == 0 && zero_page != nullptr && w.dma != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
     bool fused = false;
-    // the fused epilogue's wait needs more than 8 (G - 1) co-resident workgroups (see FuseArgs); demand twice that of the
-    // CUs this stream may use at ONE workgroup per CU, else run the separate elementwise pass
-    auto can_wait = [&](int G) { return resident_workgroups(stream) >= 16 * (G - 1) + 1; };
+    auto can_wait = [&](int G) { return fused_can_wait(stream, G); };
     if (slab_ok) {
       a.tiles_m = a.M / 256; a.tiles_n = Cout / 64;
       if (fuse && fuse->mode && a.P % 256 == 0 && can_wait(a.P / 256 * a.tiles_n)) {
         ab.fz = *fuse; ab.fz.expected = a.P / 256; ab.fz.group = a.P / 256 * a.tiles_n; fused = true;
       }
-      hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      if (raw_in) {
+        a.in = raw_in->raw; a.in_gn = raw_in->gn;
+        hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      } else {
+        hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      }
     } else if (dma_ok) {
       const int tn = cfg == 0 ? 2 : 1, bn = 64 * tn;
       a.tiles_m = cdiv(a.M, 128); a.tiles_n = Cout / bn;
@@ -1757,26 +1856,44 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     return f;
   };
   int rc;
+  // FAST STAGE-0 INPUT: with many images conv_init completes the pooling itself (whole-image chunks) and block 0 consumes the
+  // raw pooled tensor directly -- b0_conv0 applies GroupNorm + ReLU + split while staging its slabs (row-slab RAWIN), b0_conv1's
+  // fused epilogue rebuilds the residual from the same raw tensor (mode 4): no elementwise pass over the pooled tensor.
+  // Needs: full 16x16 conv_init tiles, at least 2 images per persistent workgroup, block 0 on the row-slab kernel with its
+  // fused epilogue available.  Decided from shapes only, so that a pass issued in pieces decides the same way every time.
+  const bool fuse_pool = d.h[0] % 16 == 0 && d.w[0] % 16 == 0;   // full 16 x 16 conv_init tiles: pooling fused into conv_init
+  const bool fuse_on = [] { const char* e = getenv("SERL_GN_FUSE"); return !(e && e[0] == '0'); }();
+  const int P0 = d.h[2] * d.w[2];
+  const bool complete_pool = fuse_pool && N >= 512 && N % 512 == 0;
+  const bool raw_b0 = complete_pool && fuse_on && kStageStride[0] == 1 && w.blk[0].proj == nullptr &&
+                      rowslab_shape_ok(N, d.h[1], d.w[1], 64, d.h[2], d.w[2], kStageFilters[0], 3, 1) && pk.blk[0][0].slab != nullptr &&
+                      pk.blk[0][1].slab != nullptr && P0 % 256 == 0 && fused_can_wait(stream, P0 / 256 * (kStageFilters[0] / 64));
+  const GnRef gn_init = gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64);
   if (stage_begin < 0) {
-    const bool fuse_pool = d.h[0] % 16 == 0 && d.w[0] % 16 == 0;   // full 16 x 16 conv_init tiles: pooling fused into conv_init
     if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
-                                     d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket))) return rc;
-    if (fuse_pool) {
+                                     d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket, complete_pool))) return rc;
+    if (raw_b0) {
+      // nothing: block 0 reads ws.raw_init (the completed pooled tensor) itself
+    } else if (complete_pool) {
+      const long tot = (long)N * d.h[1] * d.w[1] * 16;
+      ProfScope prof("gn_relu_maxpool", stream);
+      hipLaunchKernelGGL(gn_relu_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init, gn_init,
+                         reinterpret_cast<uint4*>(ws.pool), N, d.h[1] * d.w[1], 64);
+      SERL_HIP(hipGetLastError());
+    } else if (fuse_pool) {
       const long tot = (long)N * d.h[1] * (d.w[1] / 4) * 16;   // 4 pooled pixels per thread (Wo % 16 == 0)
       const int ty = d.h[0] / 16, tx = d.w[0] / 16;
       const float* pooled = ws.raw_init;
       const float* frows = pooled + (size_t)N * d.h[1] * d.w[1] * 64;
       const float* fcols = frows + (size_t)N * ty * d.w[0] * 64;
       ProfScope prof("gn_relu_maxpool", stream);
-      hipLaunchKernelGGL(pool_finish_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, pooled, frows, fcols,
-                         gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+      hipLaunchKernelGGL(pool_finish_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, pooled, frows, fcols, gn_init,
                          reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], ty, tx);
       SERL_HIP(hipGetLastError());
     } else {
       const long tot = (long)N * d.h[1] * d.w[1] * 16;
       ProfScope prof("gn_relu_maxpool", stream);
-      hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init,
-                         gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64),
+      hipLaunchKernelGGL(gn_relu_maxpool_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.raw_init, gn_init,
                          reinterpret_cast<uint4*>(ws.pool), N, d.h[0], d.w[0], d.h[1], d.w[1], 64);
       SERL_HIP(hipGetLastError());
     }
@@ -1801,7 +1918,11 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     FuseArgs fz0 = fuse_of(l0, 1);
     fz0.gn = gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f);
     fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0))) return rc;
+    const bool raw_in = i == 0 && raw_b0;
+    const RawInput rin{ws.raw_init, gn_init};
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
+                                raw_in ? &rin : nullptr))) return rc;
+    SERL_REQUIRE(!raw_in || fz0.mode, "block 0 was planned on the fused row-slab path");
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
     const long tot = (long)N * P * (f / 4);
@@ -1812,16 +1933,20 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
       SERL_HIP(hipGetLastError());
     }
     const bool last = i == kTrunkStages - 1;
-    FuseArgs fz1 = fuse_of(l1, last ? 0 : (has_proj ? 3 : 2));
+    FuseArgs fz1 = fuse_of(l1, last ? 0 : (has_proj ? 3 : (raw_in ? 4 : 2)));
     fz1.gn = gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f);
     fz1.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].out);
     if (has_proj) {
       fz1.res_raw = ws.blk[i].rawp;
       fz1.res_gn = gn_ref_b(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f);
+    } else if (raw_in) {
+      fz1.res_raw = ws.raw_init;
+      fz1.res_gn = gn_init;
     } else {
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
     if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1))) return rc;
+    SERL_REQUIRE(!raw_in || fz1.mode, "block 0 was planned on the fused row-slab path");
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
       hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,

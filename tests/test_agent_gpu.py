@@ -573,3 +573,26 @@ def test_fused_epilogue_is_race_free_over_2000_passes_with_a_corunning_update(gp
     print(f"fused vs elementwise GroupNorm over 2000 co-running passes of {n} images: worst rel diff {w:.2e}")
     assert np.isfinite(w) and w < 2e-6, w
     assert all(np.isfinite(v) for v in core2.read_info().values())
+
+
+@pytest.mark.parametrize("H,n", [(64, 512), (128, 1024)])
+def test_raw_stage0_input_path(gpu, monkeypatch, H, n):
+    """With >= 512 images conv_init completes the 3x3/2 max-pool itself (whole-image chunks, neighbour rows / columns read back
+    by the same workgroup) and block 0 consumes the RAW pooled tensor: GroupNorm + ReLU + split while the row-slab kernel stages
+    its slabs, the residual rebuilt in b0_conv1's fused epilogue.  Checked against (a) the materialised path (SERL_GN_FUSE=0:
+    completed pooling + elementwise GroupNorm pass + separate block-output pass) and (b) the fp64 oracle on the first and last
+    images (resnet_v1.py:249-262)."""
+    cfg = O.Config(image_keys=("a",), H=H, W=H, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=n // 2, trunk_mode="f16x3")
+    img = torch.randint(0, 256, (n, H, H, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    monkeypatch.setenv("SERL_GN_FUSE", "0")
+    slow = core.trunk_forward(img).clone()
+    monkeypatch.setenv("SERL_GN_FUSE", "1")
+    fast = core.trunk_forward(img).clone()
+    scale = float(slow.abs().max())
+    d = float((fast - slow).abs().max()) / scale
+    sel = list(range(6)) + list(range(n - 6, n))
+    ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
+    err = AH.rel_err(fast[sel].cpu().numpy(), ref)
+    print(f"raw stage-0 path {H}x{H} n={n}: vs materialised path {d:.2e}, vs fp64 oracle {err:.2e}")
+    assert d < 2e-6 and err < 5e-6
