@@ -211,6 +211,34 @@ struct XLoader {
   int ok[NV];   // this thread's row exists
   long sK;
   int row0, kq;   // !KFAST: tile row of this thread, first k of its group
+  // gather mode (GemmDesc::gtab): the operand is a virtual im2col matrix
+  const int* tab = nullptr;   // KFAST: unused after init; !KFAST: row offsets, indexed by k
+  int gseg = 0, gkbias = 0, gcnt = 0;
+  long gpitch = 0;
+  bool bias_row = false;      // !KFAST: this thread's tile row is the bias column (all ones)
+  // KFAST (forward): tile rows are im2col rows, k runs along a patch; !KFAST (weight gradient): tile rows are patch columns
+  __device__ __forceinline__ void init_gather(const GemmDesc& g, int batch, int r0, int R, int k_begin, int tid) {
+    gseg = g.gseg; gkbias = g.gkbias; gpitch = g.gpitch; sK = 1;
+    if (KFAST) {
+      tab = g.gtab + (long)batch * g.M;
+      const int ky = k_begin / gseg;
+      gcnt = (k_begin - ky * gseg) / BK;   // chunks already consumed in the current kernel row
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i, r = idx / (BK / 4);
+        ok[i] = r0 + r < R;
+        p[i] = g.A + (ok[i] ? tab[r0 + r] : 0) + (long)ky * gpitch + (k_begin - ky * gseg) + 4 * (idx % (BK / 4));
+      }
+    } else {
+      tab = g.gtab + (long)batch * g.K;
+      row0 = tid & 63; kq = NE * (tid >> 6);
+      const int kcol = r0 + row0;
+      ok[0] = kcol < R;
+      bias_row = kcol == gkbias;
+      const int ky = min(kcol, gkbias - 1) / gseg;
+      p[0] = g.A + (long)ky * gpitch + (min(kcol, gkbias - 1) - ky * gseg);
+    }
+  }
   __device__ __forceinline__ void init(const float* X, long sR, long sK_, int r0, int R, int k_begin, int tid) {
     sK = sK_;
     if (KFAST) {
@@ -228,7 +256,28 @@ struct XLoader {
   }
   // the chunk starting at k0 (elements at k >= k_end are zero); advances to the next chunk
   __device__ __forceinline__ void load(float (&r)[NE], int k0, int k_end) {
-    if (KFAST) {
+    if (tab && KFAST) {   // gather, forward: a chunk lies inside one kernel row (gseg % BK == 0) or is the bias chunk
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int k = k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok[i] && k < gkbias) v = *reinterpret_cast<const f32x4u*>(p[i]);
+        else if (ok[i] && k == gkbias && k < k_end) v[0] = 1.0f;
+        r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
+        p[i] += BK;
+      }
+      if (++gcnt == gseg / BK) {   // next kernel row
+        gcnt = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) p[i] += gpitch - gseg;
+      }
+    } else if (tab) {     // gather, weight gradient: k runs over the im2col rows
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int k = k0 + kq + j;
+        r[j] = (ok[0] && k < k_end) ? (bias_row ? 1.0f : p[0][tab[k]]) : 0.f;
+      }
+    } else if (KFAST) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int krem = k_end - (k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4)));
@@ -301,7 +350,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   if (k_begin < k_end) {
     XLoader<A_KFAST, BK> la;
     XLoader<B_KFAST, BK> lb;
-    la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
+    if (g.gtab) la.init_gather(g, batch, m0, g.M, k_begin, tid);
+    else la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
     lb.init(g.B + (long)batch * g.sBb, g.sBn, g.sBk, n0, g.N, k_begin, tid);
     float ra[BK / 4], rb[BK / 4];
     la.load(ra, k_begin, k_end);
@@ -336,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     const int n = n0 + wn * 32 + li;
-    if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = acc[r];
+    if (m < g.M && n < g.N) C[(long)m * g.ldc + n] = g.relu ? fmaxf(acc[r], 0.f) : acc[r];
   }
 }
 
@@ -392,6 +442,13 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   }
   const bool vec = (a_k || a_m) && (b_k || b_n);
   SERL_REQUIRE(vec || n == 1, "mixed operand layouts in a GEMM group");
+  bool gather = false;   // (gather / relu descriptors exist only in the bf16x3 kernel)
+  for (int i = 0; i < n; ++i) {
+    gather = gather || gs[i].gtab != nullptr || gs[i].relu;
+    SERL_REQUIRE(!gs[i].gtab || (gs[i].gseg > 0 && gs[i].gseg % 16 == 0 && (gs[i].sAk == 1 || gs[i].sAm == 1)), "bad gather GEMM");
+    SERL_REQUIRE(!gs[i].relu || gs[i].splitk == 1, "relu epilogue with a K-split");
+  }
+  SERL_REQUIRE(!gather || vec, "gather GEMM needs a vector layout");
   for (int i = 0; i < n; ++i) {
     const GemmDesc& g = gs[i];
     SERL_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.nbatch > 0 && g.splitk > 0, "bad GEMM shape");
@@ -404,7 +461,7 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   dim3 grid(gx, gy, z);
   // SERL_GEMM=f32: the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) instead of bf16x3 -- A/B timing and parity runs
   static const bool exact = []() { const char* e = getenv("SERL_GEMM"); return e && e[0] == 'f'; }();
-  if (vec && !exact) {   // BK = 16 (12 KB of LDS); BK = 32 (24 KB) was measured 30 us per step slower next to the trunk pass
+  if (vec && (!exact || gather)) {   // BK = 16 (12 KB of LDS); BK = 32 (24 KB) was measured 30 us per step slower next to the trunk pass
 
     if (a_k && b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
     else if (a_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);

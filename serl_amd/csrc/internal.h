@@ -73,6 +73,15 @@ struct GemmDesc {
   long sBk, sBn, sBb;
   long ldc, sCz;       // row stride of C and slab stride
   int nbatch, splitk;  // grid.z = nbatch*splitk, z = batch*splitk + split
+  // GATHER (SmallEncoder implicit GEMM): A is the VIRTUAL im2col matrix col[row][k] of an NHWC activation tensor at A,
+  //   col[row][k] = A[gtab[row] + (k / gseg) * gpitch + k % gseg]  for k < gkbias,   col[row][gkbias] = 1 (the bias column),
+  // gseg = 3 * cin (one kernel row: contiguous in NHWC), gpitch = wi * cin, gtab[row] = offset of the patch's first element.
+  // Forward: sAk == 1 (m = row, k = column; batch b starts at row b * M); weight gradient: sAm == 1 (m = column, k = row;
+  // batch b starts at row b * K).  gseg % 16 == 0.  nullptr = ordinary strided operand.
+  const int* gtab = nullptr;
+  int gseg = 0, gkbias = 0;
+  long gpitch = 0;
+  int relu = 0;        // C = max(acc, 0) (splitk == 1 only)
 };
 int gemm_f32(const GemmDesc& g, hipStream_t stream);
 

@@ -21,7 +21,9 @@ long small_conv_offset(int layer);   // offset of layer's kernel inside that blo
 struct SmallWorkspace {
   SmallDims d{};
   int max_images = 0;             // images per pass (all cameras together)
-  float* col[kSmallLayers]{};     // im2col [rows_l][ldk_l] of the last forward (ones column appended: bias rides in the GEMM)
+  float* col[kSmallLayers]{};     // layer 0 only: explicit im2col [rows_0][ldk_0] of the u8 frames (ones column appended)
+  int* tab[kSmallLayers]{};       // layers 1..3: offset of every im2col row's patch in the layer's NHWC input (implicit GEMM)
+  bool tab_ready = false;
   float* act[kSmallLayers]{};     // ReLU outputs [rows_l][cout_l]
   float* dact = nullptr;          // gradient wrt a layer's output (ping)
   float* dact2 = nullptr;         // (pong)

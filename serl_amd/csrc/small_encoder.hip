@@ -2,12 +2,14 @@
 // Reference: serl_launcher/vision/small_encoders.py:9-55 (features (32,64,128,256), 3x3 kernels, stride 2, padding
 // VALID, pool_method "avg" -- agents/continuous/drq.py:137-153).
 //
-// A conv layer is an explicit im2col + the update chain's fp32-MFMA GEMM (heads.hip gemm_f32: exact fp32 products on
-// v_mfma_f32_32x32x2_f32).  The im2col matrix carries a trailing column of ones and a layer's parameters sit in the
-// arena as [9*cin + 1][cout] (HWIO kernel immediately followed by the bias), so the bias is part of the forward GEMM and
-// its gradient part of the weight-gradient GEMM, which writes straight into the gradient arena.  The secondary
-// encoder of the north star: built for parity first (288 GB of HBM make the explicit im2col affordable); the frozen
-// ResNet-10 path is the one the benchmark times.
+// A conv layer is a GEMM of the update chain's kernel (heads.hip gemm_bf16x3: fp32 operands split exactly into three bf16
+// pieces, fp32 accumulate) over the layer's im2col matrix, which carries a trailing column of ones; a layer's parameters sit
+// in the arena as [9*cin + 1][cout] (HWIO kernel immediately followed by the bias), so the bias is part of the forward GEMM
+// and its gradient part of the weight-gradient GEMM, which writes straight into the gradient arena.  Layers 1..3 are IMPLICIT
+// GEMMs: the im2col matrix is never written -- the GEMM's operand loader gathers a patch row from the NHWC activations (one
+// kernel row = 3*cin contiguous floats; GemmDesc::gtab holds every row's patch offset), forward and weight gradient alike, and
+// ReLU is the forward GEMM's epilogue.  (Round 2 wrote explicit im2col matrices: 1.2 GB per pass, 46 % of the step.)  Layer 0
+// (u8 frames, K = 27) keeps its explicit im2col; the input gradient is dcol = dy x W^T followed by a col2im gather.
 #include <algorithm>
 
 #include "heads.h"
@@ -45,11 +47,13 @@ static size_t carve(SmallWorkspace& ws, uint8_t* base, int max_images, int H, in
   long max_act = 0, max_col = 0;
   for (int l = 0; l < kSmallLayers; ++l) {
     const long r = rows_of(ws.d, l, max_images);
-    ws.col[l] = take((size_t)r * ldk(l));
+    if (l == 0) ws.col[l] = take((size_t)r * ldk(l));
+    else ws.tab[l] = reinterpret_cast<int*>(take((size_t)r));
     ws.act[l] = take((size_t)r * kSmallFeat[l + 1]);
     max_act = std::max(max_act, r * kSmallFeat[l + 1]);
-    max_col = std::max(max_col, r * ldk(l));
+    if (l > 0) max_col = std::max(max_col, r * ldk(l));
   }
+  ws.tab_ready = false;
   ws.dact = take(max_act);
   ws.dact2 = take(max_act);
   ws.dcol = take(max_col);
@@ -100,12 +104,13 @@ __global__ __launch_bounds__(256) void small_im2col_kernel(const void* xin, floa
   }
 }
 
-__global__ __launch_bounds__(256) void small_relu_kernel(float* x, long n4) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  float4 v = reinterpret_cast<float4*>(x)[e];
-  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-  reinterpret_cast<float4*>(x)[e] = v;
+// tab[m] = offset (floats) of the first element of im2col row m = (image, oy, ox) in the layer's NHWC input
+__global__ __launch_bounds__(256) void small_patch_table_kernel(int* tab, long rows, int hi, int wi, int ho, int wo, int cin) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const long n = m / ((long)ho * wo);
+  const int rem = (int)(m - n * (long)ho * wo), oy = rem / wo, ox = rem - oy * wo;
+  tab[m] = (int)(((n * hi + 2 * oy) * wi + 2 * ox) * cin);
 }
 
 // pooled[cam][img][c] = mean over the P pixels of act[(cam*n + img)*P + p][c]   (jnp.mean(x, axis=(-3, -2)))
@@ -170,26 +175,35 @@ int small_forward(SmallWorkspace& ws, const float* P, long conv_off, long cam_st
   const SmallDims& d = ws.d;
   SERL_REQUIRE(d.h[kSmallLayers] >= 1 && d.w[kSmallLayers] >= 1, "image too small for the SmallEncoder");
   ProfScope prof("small_encoder_fwd", stream);
+  if (!ws.tab_ready) {   // (static shapes: once per workspace)
+    for (int l = 1; l < kSmallLayers; ++l) {
+      const long r = rows_of(d, l, ws.max_images);
+      SERL_REQUIRE((long)ws.max_images * d.h[l] * d.w[l] * kSmallFeat[l] < (1L << 31), "SmallEncoder activation too large for 32-bit offsets");
+      hipLaunchKernelGGL(small_patch_table_kernel, dim3(cdiv(r, 256)), dim3(256), 0, stream, ws.tab[l], r, d.h[l], d.w[l],
+                         d.h[l + 1], d.w[l + 1], kSmallFeat[l]);
+      SERL_HIP(hipGetLastError());
+    }
+    ws.tab_ready = true;
+  }
   for (int l = 0; l < kSmallLayers; ++l) {
     const int cin = kSmallFeat[l], cout = kSmallFeat[l + 1], K = 9 * cin + 1, pitch = ldk(l);
     const long rows = rows_of(d, l, n_img), rows_cam = rows_of(d, l, n);
-    const long tot = rows * 10;
-    if (l == 0)
+    GemmDesc g{};   // act[cam] = relu(col[cam] ([rows_cam][K+1]) x [kernel ; bias]_cam ([K+1][cout]))
+    if (l == 0) {
+      const long tot = rows * 10;
       hipLaunchKernelGGL(small_im2col_kernel<true>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const void*)frames, ws.col[0],
                          rows, d.h[0], d.w[0], d.h[1], d.w[1], cin, pitch, n, frame_cam_stride);
-    else
-      hipLaunchKernelGGL(small_im2col_kernel<false>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const void*)ws.act[l - 1],
-                         ws.col[l], rows, d.h[l], d.w[l], d.h[l + 1], d.w[l + 1], cin, pitch, n, (long)n);
-    SERL_HIP(hipGetLastError());
-    GemmDesc g{};   // act[cam] = col[cam] ([rows_cam][K+1]) x [kernel ; bias]_cam ([K+1][cout])
-    g.A = ws.col[l]; g.sAm = pitch; g.sAk = 1; g.sAb = rows_cam * pitch;
+      SERL_HIP(hipGetLastError());
+      g.A = ws.col[0]; g.sAm = pitch; g.sAk = 1; g.sAb = rows_cam * pitch;
+    } else {
+      g.A = ws.act[l - 1]; g.sAm = 0; g.sAk = 1; g.sAb = 0;
+      g.gtab = ws.tab[l]; g.gseg = 3 * cin; g.gkbias = 9 * cin; g.gpitch = (long)d.w[l] * cin;
+    }
     g.B = P + conv_off + small_conv_offset(l); g.sBk = cout; g.sBn = 1; g.sBb = cam_stride;
     g.C = ws.act[l]; g.ldc = cout; g.sCz = rows_cam * cout;
-    g.M = (int)rows_cam; g.N = cout; g.K = K; g.nbatch = n_cam; g.splitk = 1;
+    g.M = (int)rows_cam; g.N = cout; g.K = K; g.nbatch = n_cam; g.splitk = 1; g.relu = 1;
     int rc = gemm_f32(g, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(small_relu_kernel, dim3(cdiv(rows * cout / 4, 256)), dim3(256), 0, stream, ws.act[l], rows * cout / 4);
-    SERL_HIP(hipGetLastError());
   }
   const int P4 = d.h[kSmallLayers] * d.w[kSmallLayers];
   hipLaunchKernelGGL(small_avgpool_kernel, dim3((int)n_img), dim3(256), 0, stream, ws.act[kSmallLayers - 1], pooled, n, P4,
@@ -216,7 +230,12 @@ int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_s
       int S = (int)std::min<long>(64, std::max<long>(1, rows_cam / 2048));
       while (S > 1 && (long)S * n_cam * K * cout > ws.slabs_cap) S >>= 1;
       GemmDesc g{};
-      g.A = ws.col[l]; g.sAm = 1; g.sAk = pitch; g.sAb = rows_cam * pitch;
+      if (l == 0) {
+        g.A = ws.col[0]; g.sAm = 1; g.sAk = pitch; g.sAb = rows_cam * pitch;
+      } else {   // col_l^T gathered from the layer's input activations (still in the workspace)
+        g.A = ws.act[l - 1]; g.sAm = 1; g.sAk = 0; g.sAb = 0;
+        g.gtab = ws.tab[l]; g.gseg = 3 * cin; g.gkbias = 9 * cin; g.gpitch = (long)d.w[l] * cin;
+      }
       g.B = dy; g.sBk = cout; g.sBn = 1; g.sBb = rows_cam * cout;
       g.M = K; g.N = cout; g.K = (int)rows_cam; g.nbatch = n_cam; g.splitk = S;
       float* out = G + conv_off + small_conv_offset(l);
