@@ -18,6 +18,7 @@ timeout 300 python bench.py --no-cpu-baseline --steps 40 --repeats 3 --encoder s
 timeout 200 python bench.py $NB --force-collective > $O/bench_collective_1rank.json 2> /dev/null
 timeout 200 python bench.py --workload actor_latency > $O/actor_latency.json 2> /dev/null
 timeout 300 python bench.py --workload sac_state --steps 200 > $O/sac_state.json 2> /dev/null
+timeout 200 python scripts/probes/replay_race.py 1500 48 > $O/replay_race.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 PB="--no-cpu-baseline --no-verify --fill 3000 --steps 30 --warmup 5 --repeats 1"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python $R/bench.py $PB > $O/stats.log 2>&1
