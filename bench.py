@@ -112,6 +112,9 @@ def main():
                          "default: SERL_UPDATE_AFTER_STAGE or off")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
+    ap.add_argument("--overlap-reduce", choices=["on", "off"], default="off",
+                    help="N > 1: two gradient buckets reduced on a communication stream under the encoder-head backward (on) or "
+                         "one all-reduce per update on the update stream itself (off)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="go through torch.distributed.run (one rank per GPU, RCCL group) even with --gpus 1")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -230,7 +233,7 @@ def main():
             dist.all_reduce(t)
 
     learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
-                                  all_reduce=all_reduce, seed=7, schedule=sched)
+                                  all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on")
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
 
@@ -381,9 +384,12 @@ def main():
             "all_reduces_per_step": coll["calls"] / max(args.steps * len(dts), 1),
             "bytes_per_step": coll["bytes"] / max(args.steps * len(dts), 1),
             "avg_us_by_bytes": {str(k): round(float(np.mean(v)), 2) for k, v in sorted(by_size.items())},
-            "note": "per critic update two overlapped all-reduce(SUM) buckets on a communication stream -- [ensemble | Q head | proprio | "
-                    "loss scalars] issued while the encoder-head backward still runs, then [encoder heads] -- and one of [scalars | "
-                    "actor grads] per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
+            "overlap_reduce": args.overlap_reduce,
+            "note": ("per critic update two overlapped all-reduce(SUM) buckets on a communication stream -- [ensemble | Q head | proprio | "
+                     "loss scalars] issued while the encoder-head backward still runs, then [encoder heads] -- " if args.overlap_reduce == "on"
+                     else "per critic update ONE all-reduce(SUM) of [critic grads | loss scalars] on the update stream (no stream crossing; "
+                          "--overlap-reduce on = two buckets on a communication stream, measured slower at B/8) ")
+                    + "and one of [scalars | actor grads] per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
     if verify is not None:
         out["verify"] = verify
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -16,6 +16,9 @@ for w in 2 4 8; do timeout 200 python bench.py $NB --emulate-world $w > $O/bench
 for w in drq_demos peg fwbw; do timeout 300 python bench.py --workload $w --steps 40 --warmup 5 --repeats 3 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 timeout 300 python bench.py --no-cpu-baseline --steps 40 --repeats 3 --encoder small > $O/bench_small_encoder.json 2> $O/bench_small.err
 timeout 200 python bench.py $NB --force-collective > $O/bench_collective_1rank.json 2> /dev/null
+timeout 200 python bench.py $NB --emulate-world 8 --overlap-reduce on > $O/bench_emulate_world8_overlap_on.json 2> /dev/null
+timeout 200 python bench.py $NB --emulate-world 8 --force-collective > $O/bench_emulate_world8_collective.json 2> /dev/null
+timeout 200 python bench.py $NB --emulate-world 8 --force-collective --overlap-reduce on > $O/bench_emulate_world8_collective_overlap_on.json 2> /dev/null
 timeout 200 python bench.py --workload actor_latency > $O/actor_latency.json 2> /dev/null
 timeout 300 python bench.py --workload sac_state --steps 200 > $O/sac_state.json 2> /dev/null
 timeout 200 python scripts/probes/replay_race.py 1500 48 > $O/replay_race.txt 2>&1

@@ -10,6 +10,9 @@ pairs = {"bench": "bench", "bench_f32": "bench_trunk_f32", "bench_car4": "bench_
          "bench_emulate_world4": "bench_emulate_world4", "bench_emulate_world8": "bench_emulate_world8",
          "bench_drq_demos": "bench_drq_demos", "bench_peg": "bench_peg", "bench_fwbw": "bench_fwbw",
          "bench_small_encoder": "bench_small_encoder", "bench_collective_1rank": "bench_collective_1rank",
+         "bench_emulate_world8_overlap_on": "bench_emulate_world8_overlap_on",
+         "bench_emulate_world8_collective": "bench_emulate_world8_collective",
+         "bench_emulate_world8_collective_overlap_on": "bench_emulate_world8_collective_overlap_on",
          "actor_latency": "actor_latency", "sac_state": "sac_state"}
 J = {}
 for src, dst in pairs.items():
@@ -46,6 +49,7 @@ rows = f"""| file | what | command |
 | `{RD}_bench_drq_demos.json`, `{RD}_bench_peg.json`, `{RD}_bench_fwbw.json` | BASELINE.json configs[2..4] as bench workloads (two HBM replay buffers sampled 50/50 and concatenated on the device; CAR 8 / 8 / 4; batch 256 / 256 / 512; a step = one `update_high_utd` call = CAR grad steps): **{w2['value']} / {w3['value']} / {w4['value']} grad-steps/s** ({w2['ms_per_step']} / {w3['ms_per_step']} / {w4['ms_per_step']} ms per call); verification {ver(w2):.1e} / {ver(w3):.1e} / {ver(w4):.1e} | `python bench.py --workload drq_demos` (`peg`, `fwbw`) |
 | `{RD}_bench_small_encoder.json` | `encoder_type="small"` (trainable SmallEncoder, forward + backward through the encoder every grad step, no frozen trunk): {sm['value']} grad-steps/s ({sm['ms_per_step']} ms); conv stack (implicit GEMMs on the bf16x3 kernel) at {sm['roofline'].get('algorithmic_tflops', sm['roofline']['achieved'])} algorithmic TFLOP/s; round 2 with explicit im2col matrices: 68.0 grad-steps/s | `python bench.py --encoder small --no-cpu-baseline --steps 40` |
 | `{RD}_bench_emulate_world{{2,4,8}}.json` | ONE rank's share (B/N samples, no collective) of an N-GPU data-parallel step on this GPU = upper bound of the strong-scaling step rate before RCCL time: {e2['value']} / {e4['value']} / {e8['value']} grad-steps/s ({e2['ms_per_step']} / {e4['ms_per_step']} / {e8['ms_per_step']} ms) -> {e2['value']/b['value']:.2f}x / {e4['value']/b['value']:.2f}x / {e8['value']/b['value']:.2f}x of 1 GPU | `python bench.py --emulate-world N --steps 100 --no-cpu-baseline` |
+| `{RD}_bench_emulate_world8_overlap_on.json`, `{RD}_bench_emulate_world8_collective.json`, `{RD}_bench_emulate_world8_collective_overlap_on.json` | what the gradient exchange costs a rank BEFORE any link time, at B/8: default (one all-reduce per update on the update stream) {e8['ms_per_step']} ms; opt-in overlapped buckets on a communication stream {J['bench_emulate_world8_overlap_on']['ms_per_step']} ms (two cross-stream dependencies per critic update at 60-100 us each); with the RCCL calls really issued on a 1-rank group: {J['bench_emulate_world8_collective']['ms_per_step']} ms (default) vs {J['bench_emulate_world8_collective_overlap_on']['ms_per_step']} ms (overlapped); runs {runs(J['bench_emulate_world8_collective'])} / {runs(J['bench_emulate_world8_collective_overlap_on'])} | `python bench.py --emulate-world 8 [--overlap-reduce on] [--force-collective] --steps 100 --no-cpu-baseline` |
 | `{RD}_bench_collective_1rank.json` | the N > 1 code path on one rank (RCCL all-reduces really issued, world size 1): {co['value']} grad-steps/s; {coll.get('all_reduces_per_step')} all-reduces per step, {coll.get('bytes_per_step')} bytes; per all-reduce {coll.get('avg_us_by_bytes')} us | `python bench.py --force-collective --no-cpu-baseline --steps 100` |
 | `{RD}_kernel_stats.csv`, `{RD}_kernel_stats_serial.csv`, `{RD}_kernel_stats_small_encoder.csv` | `rocprofv3 --kernel-trace --stats` per-kernel summaries of the pipelined, the serial and the SmallEncoder bench commands (`scripts/rocprof_summary.py`) | `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-verify [--no-pipeline] [--encoder small] --fill 3000 --steps 30 --warmup 5 --repeats 1` |
 | `{RD}_frac_from_stats.txt` | `roofline.frac` recomputed from those CSVs alone (`scripts/frac_from_stats.py`): pipelined `{fr[0].split('frac')[-1].strip()}` vs {r['frac']} from the HIP events inside `bench.py`; serial `{fr[1].split('frac')[-1].strip()}` vs {se['roofline']['frac']} | `python scripts/frac_from_stats.py profiles/{RD}_kernel_stats_serial.csv` |

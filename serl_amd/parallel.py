@@ -125,7 +125,7 @@ class DataParallelLearner:
 
     def __init__(self, core, gather, buffers: List[object], batch_sizes: List[int], rank: int = 0,
                  world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10, schedule=None,
-                 overlap_reduce: bool = True):
+                 overlap_reduce: bool = False):
         self.core, self.gather, self.buffers, self.batch_sizes = core, gather, buffers, batch_sizes
         self.rank, self.world = rank, world
         self.B = sum(batch_sizes)
@@ -143,9 +143,14 @@ class DataParallelLearner:
         if world > 1 and hasattr(core, "set_shard"):
             core.set_shard(rank * self.Bl, self.B)   # device noise indexed by the global sample id
         self._next_slot = 0
-        # Bucketed, overlapped gradient all-reduce (DDP-style): the critic phase publishes [ensemble | head | proprio |
-        # scalars] before it starts the encoder-head backward; that bucket is reduced on a communication stream while
+        # overlap_reduce=True: bucketed, overlapped gradient all-reduce (DDP-style): the critic phase publishes [ensemble | head |
+        # proprio | scalars] before it starts the encoder-head backward; that bucket is reduced on a communication stream while
         # the encoder heads' weight gradients are still being computed, the second bucket follows, and only `apply` waits.
+        # OPT-IN since round 3's measurement (profiles/README.md): a dependency that crosses HIP streams costs 60-100 us on this
+        # stack, the update stream crosses twice per critic update (comm waits for the bucket event, `apply` waits for comm),
+        # and at one rank's share of an 8-GPU batch that is more (0.772 -> 0.841 ms per step, unstable with RCCL actually
+        # issued: 0.86 / 1.18 ms) than the ~0.1 ms of encoder-head backward a bucket can hide behind.  Default: ONE all-reduce
+        # of the critic gradients on the update stream itself, no stream crossing.
         self._overlap = bool(overlap_reduce) and hasattr(core, "critic_grads_bucketed") and hasattr(core, "grad_bucket")
         self._comm = None
 

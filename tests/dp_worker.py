@@ -59,7 +59,8 @@ def main():
         dist.all_reduce(h)
         t.copy_(h)
 
-    learner = DataParallelLearner(core, gather, [rb], [B], rank, world, all_reduce=all_reduce, seed=7, schedule=SerialSchedule())
+    learner = DataParallelLearner(core, gather, [rb], [B], rank, world, all_reduce=all_reduce, seed=7, schedule=SerialSchedule(),
+                                  overlap_reduce=os.environ.get("SERL_TEST_OVERLAP", "1") == "1")   # (the opt-in bucketed path stays covered)
     drawn = []
     orig = rb.replica.sample_indices
     rb.replica.sample_indices = lambda n: (drawn.append(orig(n)) or drawn[-1])

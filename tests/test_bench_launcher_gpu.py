@@ -17,19 +17,20 @@ def _bench(*args, timeout=600):
                           timeout=timeout, cwd=ROOT)
 
 
-def test_one_rank_through_the_launcher(gpu):
-    r = _bench("--gpus", "1", "--force-launcher", *SMALL)
+@pytest.mark.parametrize("overlap,n_ar", [("off", 2), ("on", 3)])
+def test_one_rank_through_the_launcher(gpu, overlap, n_ar):
+    r = _bench("--gpus", "1", "--force-launcher", "--overlap-reduce", overlap, *SMALL)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 3
     c = out["collective"]
     assert c["world_size"] == 1 and c["launcher"] == "torch.distributed.run" and c["backend"].startswith("nccl")
-    # per step (CAR = 1): the critic gradients in two overlapped buckets ([ensemble | head | proprio | scalars], then the
-    # encoder heads) and one [scalars | actor grads] all-reduce
-    assert c["all_reduces_per_step"] == 3
+    # per step (CAR = 1): the critic gradients (default: one all-reduce on the update stream; opt-in: two overlapped buckets
+    # [ensemble | head | proprio | scalars], then the encoder heads) and one [scalars | actor grads] all-reduce
+    assert c["all_reduces_per_step"] == n_ar
     assert c["bytes_per_step"] > 17.5e6
-    assert len(c["avg_us_by_bytes"]) == 3
+    assert len(c["avg_us_by_bytes"]) == n_ar
 
 
 def test_refuses_more_ranks_than_gpus(gpu):
