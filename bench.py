@@ -196,7 +196,7 @@ def main():
     small = args.encoder == "small"
     if not small:
         core.set_trunk_mode(args.trunk)
-    dbs = [DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank) for _ in range(2)]
+    dbs = [DeviceBatch(Bl, len(KEYS), H, W, 3, S, A, local_rank) for _ in range(3)]   # one per pipeline slot
 
     def gather(parts, co, cn, slot):                     # fused K2+K3+K4 into the slot's device batch
         gather_crop(parts, co, cn, dbs[slot])

@@ -238,9 +238,12 @@ int serl_agent_read_info(serl_agent* a, serl_info* host_out, void* stream);
  * *_grads and apply.  global_count = samples of this (mini)batch over all ranks (loss normaliser). */
 int serl_agent_encode(serl_agent* a, const serl_batch* batch, void* stream); /* frozen trunk, both passes */
 /* Software pipelining: the frozen trunk does not depend on the trainable parameters, so the trunk
- * pass of batch i+1 (slot (i+1)&1, on a second stream) may overlap the update of batch i.  The
- * caller orders the streams with events; serl_agent_select_slot picks the batch the following
- * *_grads calls consume.  serl_agent_encode == encode_slot(0) + select_slot(0). */
+ * pass of batch i+1 (another slot, on a second stream) may overlap the update of batch i.  There are
+ * THREE slots (0..2): with two, the pass of batch i+2 has to wait ON THE DEVICE for the update of batch i
+ * (a cross-stream dependency, 60-100 us on this stack); with three it reuses the slot of batch i-1, whose
+ * update a host that runs one step ahead can confirm with an event query.  The caller orders the
+ * streams with events; serl_agent_select_slot picks the batch the following *_grads calls consume.
+ * serl_agent_encode == encode_slot(0) + select_slot(0). */
 int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, void* stream);
 /* The same pass issued in consecutive pieces: stages [stage_begin, stage_end] with -1 = conv_init + max-pool and 0..3 = the
  * residual stages (split-fp16 trunk, full-size batch).  The caller may record an event between two pieces, e.g. to start

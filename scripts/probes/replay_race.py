@@ -3,7 +3,7 @@ busy stream (the gather kernel runs long after the host validated its indices), 
 usage: python scripts/probes/replay_race.py [iters] [cap]"""
 import sys, threading, time
 import numpy as np, torch
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 from helpers import make_spaces
 from serl_amd.data.data_store import MemoryEfficientReplayBufferDataStore
 

@@ -148,7 +148,7 @@ class DrQAgent:
         # already sampled the NEXT batch, so its gather + crop + frozen trunk run on a second stream under this update
         self.prefetch = True
         self._sched = None
-        self._slot_batches = [None, None]
+        self._slot_batches = [None, None, None]   # one device batch per pipeline slot (TorchPipelineSchedule.slots)
         self._prefetched = None   # (key of the lazy batch, slot)
 
     # ------------------------------------------------------------------ construction
@@ -304,16 +304,14 @@ class DrQAgent:
         return self._slot_batches[slot]
 
     def _produce(self, batch: LazyBatch, slot, db):
-        """gather + crop on the caller's stream (tens of microseconds: an actor-side insert never waits long for an
-        in-flight gather), frozen trunk on the side stream."""
-        sch, torch_ = self._sched, torch
+        """gather + crop and the frozen trunk on the side stream.  (Round 2 gathered on the caller's stream and made the side
+        stream wait for it: a dependency that crosses streams costs 60-100 us on this stack, at every pass.  An actor-side
+        insert that overwrites a slot waits ON THE COPY STREAM for the gathers in flight, never on the host.)"""
+        sch = self._sched
         co, cn = self._draw_crops(db.batch)
-        gather_crop(batch.parts, co, cn, db)
-        ev = torch_.cuda.Event()
-        ev.record(torch_.cuda.current_stream(self.core.device))
-        sch.side_stream.wait_event(ev)
-        sch.wait_consumed(slot)
+        sch.wait_consumed(slot)     # host side: the update that used this slot ended two passes ago
         with sch.side():
+            gather_crop(batch.parts, co, cn, db)
             self.core.encode_slot(db, slot)
         sch.produced(slot)
 
@@ -331,15 +329,15 @@ class DrQAgent:
             db = self._slot_batches[slot]
         else:
             # not prefetched (first call, or the caller skipped a batch).  All trunk work goes through the side stream,
-            # in order: the two feature slots share one trunk workspace.
-            slot = 0 if self._prefetched is None else 1 - self._prefetched[1]
+            # in order: the feature slots share one trunk workspace.
+            slot = 0 if self._prefetched is None else (self._prefetched[1] + 1) % sch.slots
             db = self._slot_batch(slot, B)
             self._produce(batch, slot, db)
             sch.wait_produced(slot)
         self._prefetched = None
         nxt = batch.peek_next() if batch.peek_next is not None else None
         if nxt is not None and nxt.batch_size == B:
-            s2 = 1 - slot
+            s2 = (slot + 1) % sch.slots
             self._produce(nxt, s2, self._slot_batch(s2, B))
             # (the parts are kept alive with the key: a freed index array's address could otherwise be reused by a
             # later sample and false-match)

@@ -94,9 +94,10 @@ struct serl_agent {
   TrunkPacked tpk{};
   int trunk_mode = 1;  // 0: exact fp32 MFMA convs, 1: split-fp16 (f16x3) convs for the blocks
   float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
-  float* feats_slot[3] = {nullptr, nullptr, nullptr};  // 0/1: pipelined update batches, 2: sample_actions
-  serl_batch cur_slot[2]{};
-  bool slot_valid[2] = {false, false};
+  static constexpr int kSlots = 3;                                  // pipelined update batches in flight (see serl_mi355.h)
+  float* feats_slot[kSlots + 1] = {nullptr, nullptr, nullptr, nullptr};   // 0..kSlots-1: update batches, kSlots: sample_actions
+  serl_batch cur_slot[kSlots]{};
+  bool slot_valid[kSlots] = {false, false, false};
   EncBuf encP{}, encT{}, encO{};
   CritBuf critT{}, crit{};
   PolBuf pol{}, polT{};
@@ -293,7 +294,8 @@ size_t carve(serl_agent* a, void* base) {
   a->info_acc = b.take<float>(8);
   a->aux = b.take<float>(X_N);
   const size_t persistent = b.off;  // zero-initialised region ends here
-  for (int k = 0; k < 3; ++k) a->feats_slot[k] = b.take<float>((k < 2 ? 2L : 1L) * c.n_cam * B * a->HW * 512);   // (HW = 0 without a trunk)
+  for (int k = 0; k <= serl_agent::kSlots; ++k)
+    a->feats_slot[k] = b.take<float>((k < serl_agent::kSlots ? 2L : 1L) * c.n_cam * B * a->HW * 512);   // (HW = 0 without a trunk)
   a->feats = a->feats_slot[0];
   auto enc = [&](EncBuf& e) {
     e.f = b.take<float>((long)c.n_cam * B * a->D);
@@ -893,7 +895,7 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
 
 int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slot, int stage_begin, int stage_end, void* stream) {
   SERL_REQUIRE(a, "NULL agent");
-  SERL_REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
+  SERL_REQUIRE(slot >= 0 && slot < serl_agent::kSlots, "slot must be 0..%d", serl_agent::kSlots - 1);
   SERL_REQUIRE(stage_begin >= -1 && stage_begin <= stage_end && stage_end < kTrunkStages, "bad stage range [%d, %d]", stage_begin, stage_end);
   int rc = check_batch(a, batch);
   if (rc) return rc;
@@ -920,7 +922,7 @@ int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slo
 
 int serl_agent_select_slot(serl_agent* a, int slot) {
   SERL_REQUIRE(a, "NULL agent");
-  SERL_REQUIRE((slot == 0 || slot == 1) && a->slot_valid[slot], "slot %d holds no encoded batch", slot);
+  SERL_REQUIRE(slot >= 0 && slot < serl_agent::kSlots && a->slot_valid[slot], "slot %d holds no encoded batch", slot);
   a->feats = a->feats_slot[slot];
   a->cur = a->cur_slot[slot];
   a->has_batch = true;
@@ -1197,11 +1199,11 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   // trunk on [n_cam][n] images -> feats slot 0; state goes through a temporary serl_batch view
   const size_t fbytes = (size_t)c.H * c.W * 3;
   for (int k = 0; k < c.n_cam && !a->small; ++k)
-    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[2] + ((long)k * c.batch) * a->HW * 512, st, a->trunk_mode ? &a->tpk : nullptr));
+    RC(trunk_forward(a->tw, a->tws, dev_frames + (size_t)k * n * fbytes, n, a->feats_slot[serl_agent::kSlots] + ((long)k * c.batch) * a->HW * 512, st, a->trunk_mode ? &a->tpk : nullptr));
   serl_batch saved = a->cur;
   const bool had = a->has_batch;
   float* saved_feats = a->feats;
-  a->feats = a->feats_slot[2];
+  a->feats = a->feats_slot[serl_agent::kSlots];
   a->cur = serl_batch{};
   a->cur.batch = n;
   a->cur.state = const_cast<float*>(dev_state);

@@ -71,8 +71,13 @@ class SerialSchedule:
 
 
 class TorchPipelineSchedule:
-    """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream."""
-    slots = 2
+    """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream.
+
+    THREE batch slots: the pass of batch i+2 reuses the slot of batch i-1, and the host confirms that update(i-1) is done
+    with a host-side event wait (normally already complete: the host then runs at most two updates ahead of the device)
+    instead of making the side stream wait for update(i) on the device -- a dependency that crosses streams costs 60-100 us
+    on this stack and sat on the trunk stream's critical path at every pass boundary."""
+    slots = 3
 
     def __init__(self, device, prioritise_update=True, prioritise_trunk=False, update_after_stage=None):
         """update_after_stage = s (0..2): the update of batch i starts only when the trunk pass of batch i+1 has finished
@@ -82,13 +87,13 @@ class TorchPipelineSchedule:
         self.torch = torch
         self.device = device
         self.update_after_stage = update_after_stage
-        self.ev_mid = [torch.cuda.Event() for _ in range(2)]
+        self.ev_mid = [torch.cuda.Event() for _ in range(self.slots)]
         # the update's long chain of small dependent kernels gets the high-priority queue so that it is
         # not starved by the (throughput-bound) trunk kernels of the next batch
         self.side_stream = torch.cuda.Stream(device=device, priority=-1 if prioritise_trunk else 0)
         self.main_stream = torch.cuda.Stream(device=device, priority=-1) if prioritise_update else None
-        self.ev_prod = [torch.cuda.Event() for _ in range(2)]
-        self.ev_cons = [None, None]
+        self.ev_prod = [torch.cuda.Event() for _ in range(self.slots)]
+        self.ev_cons = [None] * self.slots
 
     def side(self):
         return self.torch.cuda.stream(self.side_stream)
@@ -116,7 +121,7 @@ class TorchPipelineSchedule:
 
     def wait_consumed(self, slot):
         if self.ev_cons[slot] is not None:
-            self.side_stream.wait_event(self.ev_cons[slot])
+            self.ev_cons[slot].synchronize()   # host side; the update that used this slot ended two passes ago
 
 
 class DataParallelLearner:

@@ -336,7 +336,7 @@ def test_pipelined_schedule_matches_serial(gpu):
         rb.seed(0)
         for tr in itertools.islice(transition_stream(cfg.image_keys, 64, 64, 3, 1, 5, 3, 20, 1), 120):
             rb.insert(tr)
-        dbs = [DeviceBatch(8, 2, 64, 64, 3, 5, 3, 0) for _ in range(2)]
+        dbs = [DeviceBatch(8, 2, 64, 64, 3, 5, 3, 0) for _ in range(3)]   # one per pipeline slot
 
         def gather(parts, co, cn, slot):
             gather_crop(parts, co, cn, dbs[slot])
