@@ -183,6 +183,8 @@ int small_forward(SmallWorkspace& ws, const float* P, long conv_off, long cam_st
                          d.h[l + 1], d.w[l + 1], kSmallFeat[l]);
       SERL_HIP(hipGetLastError());
     }
+    // one-time: later passes may come in on OTHER streams (sample_actions, a pipelined schedule) and must find the tables complete
+    SERL_HIP(hipStreamSynchronize(stream));
     ws.tab_ready = true;
   }
   for (int l = 0; l < kSmallLayers; ++l) {
