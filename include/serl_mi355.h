@@ -296,6 +296,11 @@ int serl_agent_trunk_forward(serl_agent* a, const uint8_t* dev_frames, int n, fl
 int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64_t count);
 /* inject gradients / scalars ("g_critic", "g_actor", "scalars") before serl_agent_apply: optimizer tests */
 int serl_agent_debug_set(serl_agent* a, const char* what, const float* host, int64_t count);
+/* Which kernels the LAST split-fp16 trunk pass selected, as text ("images=128 pool=1 raw_b0=0 b0_conv0=S/1/0/f1 ...":
+ * layer=kernel/tile-config/statistics-mode/f<fused epilogue>; kernel S = row-slab, D = LDS-DMA, R = register-staged implicit
+ * GEMM).  The per-rank shapes of a data-parallel job (resnet_v1.py:260-269 at N = B/8 images) pick other kernels than the
+ * full batch; the parity tests assert which path they exercised. */
+int serl_agent_trunk_plan(serl_agent* a, char* out, int cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Reward classifier, inference only (next-row N4; serl_launcher/networks/reward_classifier.py:16-113).

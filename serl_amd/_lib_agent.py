@@ -72,6 +72,7 @@ def declare(lib):
         "serl_agent_sample_actions": [vp, vp, vp, i32, vp, vp, vp],
         "serl_agent_trunk_forward": [vp, vp, i32, vp, vp],
         "serl_agent_debug_get": [vp, C.c_char_p, vp, i64],
+        "serl_agent_trunk_plan": [vp, C.c_char_p, i32],
         "serl_agent_debug_set": [vp, C.c_char_p, vp, i64],
     }
     for name, args in sigs.items():

@@ -227,6 +227,20 @@ class AgentCore:
         return out
 
 
+    def trunk_plan(self) -> dict:
+        """Kernels the last split-fp16 trunk pass selected: {"images", "pool", "raw_b0", "<layer>": (kernel, cfg, pmode, fused)}."""
+        buf = C.create_string_buffer(512)
+        _lib.check(self.L.serl_agent_trunk_plan(self._h, buf, 512))
+        out = {}
+        for tok in buf.value.decode().split():
+            k, v = tok.split("=")
+            if "/" in v:
+                kern, cfg, pm, fz = v.split("/")
+                out[k] = (kern, int(cfg), int(pm), int(fz[1:]))
+            else:
+                out[k] = int(v)
+        return out
+
     def debug_set(self, what: str, value):
         v = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(-1))
         _lib.check(self.L.serl_agent_debug_set(self._h, what.encode(), v.ctypes.data, v.size))

@@ -1222,6 +1222,22 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
   return SERL_OK;
 }
 
+int serl_agent_trunk_plan(serl_agent* a, char* out, int cap) {
+  SERL_REQUIRE(a && out && cap > 0, "bad argument");
+  const TrunkPlan& p = a->tws.plan;
+  std::string s = "images=" + std::to_string(p.images) + " pool=" + std::to_string(p.pool) + " raw_b0=" + std::to_string(p.raw_b0);
+  static const char* kNames[3] = {"conv0", "conv1", "proj"};
+  for (int i = 0; i < kTrunkStages; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const TrunkPlan::L& l = p.conv[i][k];
+      if (!l.kern) continue;
+      s += " b" + std::to_string(i) + "_" + kNames[k] + "=" + std::string(1, l.kern) + "/" + std::to_string(l.cfg) + "/" +
+           std::to_string(l.pmode) + "/f" + std::to_string(l.fused);
+    }
+  snprintf(out, cap, "%s", s.c_str());
+  return SERL_OK;
+}
+
 int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64_t count) {
   SERL_REQUIRE(a && what && host_out, "NULL argument");
   SERL_HIP(hipSetDevice(a->cfg.device));

@@ -27,7 +27,17 @@ struct TrunkDims {
 TrunkDims trunk_dims(int H, int W);
 
 constexpr int kSyncPerImage = 8, kSyncTickets = 16;
+// Which kernels the last split-fp16 pass selected (introspection for the parity tests: the shapes a data-parallel rank runs
+// choose other kernels than the full batch does).  kern: 'S' row-slab, 'D' LDS-DMA, 'R' register-staged implicit GEMM,
+// 0 = layer absent; cfg: tile configuration of launch_conv_f16x3; fused: GroupNorm epilogue inside the conv (1 exchange, 2 local).
+struct TrunkPlan {
+  int images = 0;
+  int pool = 0;      // 0: separate GroupNorm + max-pool pass, 1: pooled in conv_init + pool_finish, 2: completed in conv_init
+  int raw_b0 = 0;    // block 0 reads conv_init's raw pooled tensor (RAWIN)
+  struct L { char kern = 0; int cfg = 0, pmode = 0, fused = 0; } conv[kTrunkStages][3];
+};
 struct TrunkWorkspace {
+  TrunkPlan plan{};
   int max_images = 0;
   TrunkDims d{};
   float* raw_init = nullptr;  // [N][h0][w0][64]

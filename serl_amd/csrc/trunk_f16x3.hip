@@ -1713,7 +1713,7 @@ static bool fused_can_wait(hipStream_t stream, int G) { return resident_workgrou
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
                              hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
-                             const RawInput* raw_in = nullptr) {
+                             const RawInput* raw_in = nullptr, TrunkPlan::L* plan = nullptr) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -1799,6 +1799,11 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     //  b3_conv1 at a per-rank batch of 32 but needed a statistics launch per conv: the step got slower; removed in round 3)
 #undef SERL_LAUNCH_CONV
     if (fuse && !fused) fuse->mode = 0;
+    if (plan) {
+      plan->kern = slab_ok ? 'S' : (dma_ok ? 'D' : 'R');
+      plan->cfg = cfg; plan->pmode = pmode;
+      plan->fused = fused ? (ab.fz.expected == 0 ? 2 : 1) : 0;
+    }
   }
   SERL_HIP(hipGetLastError());
   if (pmode == 3) {
@@ -1869,6 +1874,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
                       rowslab_shape_ok(N, d.h[1], d.w[1], 64, d.h[2], d.w[2], kStageFilters[0], 3, 1) && pk.blk[0][0].slab != nullptr &&
                       pk.blk[0][1].slab != nullptr && P0 % 256 == 0 && fused_can_wait(stream, P0 / 256 * (kStageFilters[0] / 64));
   const GnRef gn_init = gn_ref_b(stats_of(0), w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64);
+  ws.plan.images = N; ws.plan.pool = complete_pool ? 2 : (fuse_pool ? 1 : 0); ws.plan.raw_b0 = raw_b0 ? 1 : 0;
   if (stage_begin < 0) {
     if ((rc = launch_conv_init_f16x3(frames, PackedConvWeights{pk.init.hi, pk.init.lo, pk.init.inv}, ws.raw_init, stats_of(0), N, d.H,
                                      d.W, d.h[0], d.w[0], stream, fuse_pool ? w.gn_init_s : nullptr, fuse_of(0, 0).ticket, complete_pool))) return rc;
@@ -1921,10 +1927,11 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const bool raw_in = i == 0 && raw_b0;
     const RawInput rin{ws.raw_init, gn_init};
     if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
-                                raw_in ? &rin : nullptr))) return rc;
+                                raw_in ? &rin : nullptr, &ws.plan.conv[i][0]))) return rc;
     SERL_REQUIRE(!raw_in || fz0.mode, "block 0 was planned on the fused row-slab path");
     if (has_proj)
-      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero))) return rc;
+      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero, nullptr,
+                                  nullptr, &ws.plan.conv[i][2]))) return rc;
     const long tot = (long)N * P * (f / 4);
     if (!fz0.mode) {
       ProfScope prof("gn_relu_split", stream);
@@ -1945,7 +1952,8 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     } else {
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1))) return rc;
+    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1,
+                                nullptr, &ws.plan.conv[i][1]))) return rc;
     SERL_REQUIRE(!raw_in || fz1.mode, "block 0 was planned on the fused row-slab path");
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
