@@ -301,6 +301,9 @@ int serl_agent_debug_set(serl_agent* a, const char* what, const float* host, int
  * GEMM).  The per-rank shapes of a data-parallel job (resnet_v1.py:260-269 at N = B/8 images) pick other kernels than the
  * full batch; the parity tests assert which path they exercised. */
 int serl_agent_trunk_plan(serl_agent* a, char* out, int cap);
+/* Number of update-chain kernels (everything but the frozen trunk, the SmallEncoder convs and the replay kernels) launched
+ * since the library was loaded: the tests pin the launch count of an update_critics + update_high_utd pair (sac.py:243-299). */
+int64_t serl_debug_chain_launches(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Reward classifier, inference only (next-row N4; serl_launcher/networks/reward_classifier.py:16-113).

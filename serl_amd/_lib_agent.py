@@ -79,5 +79,7 @@ def declare(lib):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i32
+    lib.serl_debug_chain_launches.argtypes = []
+    lib.serl_debug_chain_launches.restype = i64
     lib.serl_agent_get_step.argtypes = [vp]
     lib.serl_agent_get_step.restype = i64

@@ -93,6 +93,11 @@ struct serl_agent {
   TrunkWorkspace tws{};
   TrunkPacked tpk{};
   int trunk_mode = 1;  // 0: exact fp32 MFMA convs, 1: split-fp16 (f16x3) convs for the blocks
+  // last-arriver fusion of the update chain (heads.hip): LayerNorm / slab reductions / the tanh-Gaussian head run inside the GEMM
+  // launches that feed them, the critic loss rides on the LayerNorm backward that consumes dQ, noise is hashed where it is used.
+  // SERL_CHAIN_FUSE=0 restores one launch per operation (A/B timing; the fused path is bit-identical on identical noise).
+  bool fuse = true;
+  int* ctr = nullptr;   // arrival counters: kCtrLanes ranges of kCtrPerLane (zero between launches)
   float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
   static constexpr int kSlots = 3;                                  // pipelined update batches in flight (see serl_mi355.h)
   float* feats_slot[kSlots + 1] = {nullptr, nullptr, nullptr, nullptr};   // 0..kSlots-1: update batches, kSlots: sample_actions
@@ -127,7 +132,7 @@ struct serl_agent {
   // the optimizer -- are queued and issued as ONE column-sum launch and ONE grouped weight-gradient GEMM at the end
   // of the phase (flush_param_grads): 8 fewer dependent kernel boundaries per grad-step pair
   bool pg_defer = false;
-  Colsum3Args pg_cs[kMaxMulti];
+  Colsum3Args pg_cs[kMaxColsum];
   int pg_ncs = 0;
   GemmDesc pg_wg[kMaxGemmGroups];
   int pg_nwg = 0;
@@ -136,6 +141,8 @@ struct serl_agent {
 namespace {
 
 constexpr int kSleSplit = 8;
+constexpr int kCtrPerLane = 4096, kCtrLanes = kMaxGemmGroups;
+long pad64(long x) { return (x + 63) / 64 * 64; }
 // the parameter-gradient kernels of a phase are always deferred to the end of the phase (issuing them layer by layer was
 // measured 3 % slower at a per-rank batch of 32, equal at 256)
 
@@ -324,7 +331,9 @@ size_t carve(serl_agent* a, void* base) {
     mlp(pbuf->m, B);
     pbuf->pre = b.take<float>(2 * B * A); pbuf->std = b.take<float>(B * A); pbuf->logp = b.take<float>(B);
   }
-  long cap = std::max<long>({(long)c.n_cam * 32 * B * c.bottleneck, N * B * (long)a->XA, 8 * B * Hd, 4 * N * B * Hd});
+  // (fused epilogues keep whole 64x64 slab tiles: rows and columns padded to 64)
+  const long Bp = pad64(B);
+  long cap = std::max<long>({(long)c.n_cam * 32 * Bp * c.bottleneck, N * Bp * pad64(a->XA), 8 * Bp * Hd, 4 * N * Bp * Hd, 16L * 64 * Hd});
   a->slabs_cap = cap;
   for (int k = 0; k < 3; ++k) a->slabs_lane[k] = b.take<float>(cap);
   a->slabs = a->slabs_lane[0];
@@ -343,6 +352,7 @@ size_t carve(serl_agent* a, void* base) {
     a->mask_buf[k] = b.take<uint8_t>((long)c.n_cam * B * a->D);
   }
   a->act_tmp = b.take<float>(B * A);
+  a->ctr = b.take<int>((long)kCtrPerLane * kCtrLanes);
   if (a->small) {
     void* smem = b.take<uint8_t>(small_workspace_bytes(c.n_cam * c.batch, c.H, c.W));
     if (base) small_workspace_bind(a->sws, smem, c.n_cam * c.batch, c.H, c.W);
@@ -385,6 +395,8 @@ struct EncJob {
   EncBuf* e;
   const float* act_src;  // optional rider: copy [cnt][A] actions (ld A) to act_dst (ld XA)
   float* act_dst;
+  int gen_mask = 0;            // fused chain, mask == nullptr: hash the Dropout keep-mask inside the SLE kernel from mask_seed
+  uint64_t mask_seed = 0;
 };
 int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
@@ -409,6 +421,7 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   for (int i = 0; i < n; ++i) {
     const EncJob& j = jobs[i];
     EncBuf& e = *j.e;
+    sv[i] = SleFwdArgs{};
     sv[i].x = a->feats + (((long)j.which * c.n_cam) * c.batch + off) * a->HW * 512;
     sv[i].K = j.P + o.cam[0].sle;
     sv[i].mask = j.mask ? j.mask + (long)off * a->D : nullptr;
@@ -436,6 +449,19 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       pr.copy_cols = c.act_dim;
     }
   }
+  if (a->fuse) {   // LayerNorm + tanh by the last-arriving workgroup of every 64-row tile of the bottleneck GEMM (heads.hip)
+    SERL_REQUIRE((long)c.n_cam * cdiv(cnt, 64) <= kCtrPerLane && (long)c.n_cam * S * pad64(cnt) * c.bottleneck <= a->slabs_cap,
+                 "encoder GEMM exceeds the fused epilogue's scratch");
+    for (int i = 0; i < n; ++i) {
+      GemmDesc& g = gd[i];
+      g.ldc = c.bottleneck; g.sCz = pad64(cnt) * c.bottleneck;
+      g.epi = kEpiLn; g.ctr = a->ctr + (long)i * kCtrPerLane;
+      g.ln = lv[i];
+      g.ln.slab_stride = g.sCz;
+      sv[i].gen = jobs[i].gen_mask; sv[i].seed = jobs[i].mask_seed;
+      sv[i].row_offset = a->shard_off + off; sv[i].rows_global = a->shard_global ? a->shard_global : Bfull;
+    }
+  }
   if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
     const size_t fbytes = (size_t)c.H * c.W * 3;
     for (int i = 0; i < n; ++i) {
@@ -443,10 +469,15 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       const uint8_t* fr = a->cur.frames + (((size_t)j.which * c.n_cam) * Bfull + off) * fbytes;
       RC(small_forward(a->sws, j.P, o.cam[0].conv, o.cam_stride, fr, Bfull, c.n_cam, cnt, j.e->f, (long)c.batch * a->D, st));
     }
-  } else
-  RC(sle_fwd_multi(sv, n, 1.0f / (1.0f - c.dropout), cnt, a->HW, 512, c.n_cam, (long)c.batch * a->HW * 512, o.cam_stride,
-                   Bfull * a->D, (long)c.batch * a->D, st));
+  } else if (a->fuse) {   // channel-blocked SLE (+ hashed Dropout mask) with the proprio branch as extra workgroups of the launch
+    RC(sle_proprio_fwd_multi(sv, pv, n, 1.0f - c.dropout, cnt, a->HW, 512, c.n_cam, (long)c.batch * a->HW * 512, o.cam_stride,
+                             Bfull * a->D, (long)c.batch * a->D, c.state_dim, st));
+  } else {
+    RC(sle_fwd_multi(sv, n, 1.0f / (1.0f - c.dropout), cnt, a->HW, 512, c.n_cam, (long)c.batch * a->HW * 512, o.cam_stride,
+                     Bfull * a->D, (long)c.batch * a->D, st));
+  }
   RC(gemm_f32_multi(gd, n, st));
+  if (a->fuse) return a->small ? proprio_fwd_multi(pv, n, c.state_dim, cnt, st) : SERL_OK;
   RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
   return proprio_fwd_multi(pv, n, c.state_dim, cnt, st);
 }
@@ -486,6 +517,18 @@ int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, 
     l.dot_w = j.dot_w; l.dot_b = j.dot_b; l.dot_out = j.dot_out;
     l.dot_gstride = j.dot_gstride; l.dot_b_gstride = j.dot_b_gstride;
   }
+  if (a->fuse) {
+    SERL_REQUIRE((long)groups * cdiv(rows_per_group, 64) <= kCtrPerLane && (long)groups * splitk * pad64(rows_per_group) * Hd <= a->slabs_cap,
+                 "Dense layer exceeds the fused epilogue's scratch");
+    for (int i = 0; i < n; ++i) {
+      GemmDesc& g = gd[i];
+      g.sCz = pad64(rows_per_group) * Hd;
+      g.epi = kEpiLn; g.ctr = a->ctr + (long)i * kCtrPerLane;
+      g.ln = lv[i];
+      g.ln.slab_stride = g.sCz;
+    }
+    return gemm_f32_multi(gd, n, st);
+  }
   RC(gemm_f32_multi(gd, n, st));
   return ln_tanh_fwd_multi(lv, n, Hd, st);
 }
@@ -498,6 +541,8 @@ struct PolJob {
   float* act_out; long ld_act;
   float* sum_logp;
   float* alpha_out;  // optional rider: alpha = softplus(lagrange) of P (lagrange.py:49-50)
+  // fused chain, eps == nullptr: the draws are hashed inside the head kernel from (eps_seed, global row) and kept in eps_out
+  float* eps_out = nullptr; uint64_t eps_seed = 0; long eps_row0 = 0;
 };
 int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
@@ -521,11 +566,33 @@ int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStrea
     g.B = P + o.a_Wm; g.sBk = A; g.sBn = 1; g.sBb = o.a_Ws - o.a_Wm;
     g.C = a->slabs_lane[i]; g.ldc = A; g.sCz = (long)cnt * A;
     g.M = cnt; g.N = A; g.K = Hd; g.nbatch = 2; g.splitk = 4;
-    pv[i] = PolicyDistArgs{a->slabs_lane[i], 4, P + o.a_bm, P + o.a_bs, pb.pre, j.eps, j.act_out, j.ld_act, pb.logp, pb.std,
-                           j.sum_logp, P + o.lam, j.alpha_out};
+    pv[i] = PolicyDistArgs{};
+    pv[i].slabs = a->slabs_lane[i]; pv[i].S = 4; pv[i].bias_mean = P + o.a_bm; pv[i].bias_ls = P + o.a_bs; pv[i].pre = pb.pre;
+    pv[i].eps = j.eps; pv[i].act = j.act_out; pv[i].ld_act = j.ld_act; pv[i].logp = pb.logp; pv[i].std_out = pb.std;
+    pv[i].sum_logp = j.sum_logp; pv[i].lam = P + o.lam; pv[i].alpha_out = j.alpha_out;
   }
   RC(dense_ln_tanh_multi(a, d1, n, 1, cnt, a->E, 8, st));
   RC(dense_ln_tanh_multi(a, d2, n, 1, cnt, Hd, 4, st));
+  if (a->fuse) {   // the tanh-Gaussian head inside the head GEMM: last arriver of every 64-row tile (heads.hip, kEpiPolicy)
+    SERL_REQUIRE(cdiv(cnt, 64) <= kCtrPerLane && 8 * pad64(cnt) * 64 <= a->slabs_cap, "policy head exceeds the fused epilogue's scratch");
+    for (int i = 0; i < n; ++i) {
+      const PolJob& j = jobs[i];
+      GemmDesc& g = gd[i];
+      g.ldc = 64; g.sCz = pad64(cnt) * 64;
+      g.epi = kEpiPolicy; g.ctr = a->ctr + (long)i * kCtrPerLane;
+      g.pd = pv[i];
+      g.pd.sum_logp = nullptr;
+      g.pd.eps_out = j.eps_out; g.pd.seed = j.eps_seed; g.pd.row_offset = j.eps_row0;
+      g.pd.B = cnt; g.pd.A = A; g.pd.std_min = c.std_min; g.pd.std_max = c.std_max;
+      g.pd.slab_ld = g.ldc; g.pd.slab_stride = g.sCz;
+      SERL_REQUIRE(j.eps || j.eps_out, "policy noise: neither draws nor a buffer for hashed ones");
+      if (j.sum_logp) {   // sum_b log pi: a vector-sum job of the phase's deferred column-sum launch
+        SERL_REQUIRE(a->pg_defer && a->pg_ncs < kMaxColsum, "no room for the log-prob sum job");
+        a->pg_cs[a->pg_ncs++] = Colsum3Args{j.pb->logp, nullptr, nullptr, 1, cnt, 1, nullptr, j.sum_logp, nullptr, 0, 2};
+      }
+    }
+    return gemm_f32_multi(gd, n, st);
+  }
   RC(gemm_f32_multi(gd, n, st));
   return policy_dist_fwd_multi(pv, n, cnt, A, c.std_min, c.std_max, st);
 }
@@ -560,7 +627,7 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
                       long y_goff, const float* xhat, const float* rstd, const float* gamma, long p_gstride,
                       int groups, int rows_per_group, int D, float* dpre, float* dg, float* G, long g_off,
                       long be_off, long b_off, long pg_gstride, hipStream_t st, const float* dq = nullptr,
-                      const float* dq_w = nullptr, float dq_const = 0.f, long dq_w_gstride = 0) {
+                      const float* dq_w = nullptr, float dq_const = 0.f, long dq_w_gstride = 0, const LossArgs* loss = nullptr) {
   LnBwdArgs l{};
   l.dy = dy; l.ld_dy = ld_dy; l.dy_goff = dy_goff;
   l.y = y; l.ld_y = ld_y; l.y_goff = y_goff;
@@ -568,9 +635,14 @@ int dense_ln_tanh_bwd(serl_agent* a, const float* dy, long ld_dy, long dy_goff, 
   l.rows = groups * rows_per_group; l.rows_per_group = rows_per_group;
   l.dx = dpre; l.dg = dg;
   l.dq = dq; l.dq_w = dq_w; l.dq_const = dq_const; l.dq_w_gstride = dq_w_gstride;
-  RC(ln_tanh_bwd(l, D, st));
-  if (G && a->pg_defer && a->pg_ncs < kMaxMulti) {
-    a->pg_cs[a->pg_ncs++] = Colsum3Args{dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride};
+  if (loss) {   // the critic loss rides on this launch and every row derives its dQ from the loss arguments (no critic_loss launch)
+    l.D = D; l.dq_inline = 1;
+    RC(ln_tanh_bwd_multi(&l, 1, *loss, st));
+  } else {
+    RC(ln_tanh_bwd(l, D, st));
+  }
+  if (G && a->pg_defer && a->pg_ncs < kMaxColsum) {
+    a->pg_cs[a->pg_ncs++] = Colsum3Args{dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, 0};
   } else if (G) {
     RC(colsum3(dg, xhat, dpre, groups, rows_per_group, D, G + g_off, G + be_off, G + b_off, pg_gstride, st));
   }
@@ -610,14 +682,58 @@ int igrad(const float* dY, long ldy, long dy_gstride, const float* W, long ldw, 
   return gemm_f32(g, st);
 }
 
+// dX = sum_g dY[g] * W[g]^T: the per-group products go to padded scratch slabs and the last workgroup to arrive at an output
+// tile adds them in group order (heads.hip, kEpiReduce) -- igrad + reduce_slabs in one launch
+int igrad_sum(serl_agent* a, const float* dY, long ldy, long dy_gstride, const float* W, long ldw, long w_gstride, float* out,
+              long ldo, int groups, int rows, int Kin, int Nout, hipStream_t st) {
+  GemmDesc g{};
+  g.A = dY; g.sAm = ldy; g.sAk = 1; g.sAb = dy_gstride;
+  g.B = W; g.sBk = 1; g.sBn = ldw; g.sBb = w_gstride;
+  g.C = a->slabs; g.ldc = pad64(Kin); g.sCz = pad64(rows) * g.ldc;
+  g.M = rows; g.N = Kin; g.K = Nout; g.nbatch = groups; g.splitk = 1;
+  g.epi = kEpiReduce; g.zred = groups; g.ctr = a->ctr; g.out = out; g.ld_out = ldo; g.out_gstride = 0;
+  SERL_REQUIRE((long)cdiv(rows, 64) * cdiv(Kin, 64) <= kCtrPerLane && groups * g.sCz <= a->slabs_cap, "input gradient exceeds the fused epilogue's scratch");
+  return gemm_f32(g, st);
+}
+
 // Critic backward from dq [ens][cnt] down to dx [cnt][E+A]; parameter grads into Gc when `pg`.
 // dq: [ens][cnt] gradient wrt Q, or nullptr with the constant `dq_const` for every element (actor loss)
 int critic_bwd(serl_agent* a, const float* P, CritBuf& cb, int cnt, bool pg, hipStream_t st, const float* dq,
-               float dq_const) {
+               float dq_const, const LossArgs* loss = nullptr) {
   const serl_agent_cfg& c = a->cfg;
   const Offs& o = a->o;
   const int Hd = c.hidden, N = c.ensemble;
   float* G = pg ? a->Gc : nullptr;
+  if (a->fuse) {
+    if (pg) {   // head kernel gradient: a deferred GEMM; a long K is split and the slabs are summed by the last arriver
+      GemmDesc g{};
+      const int groups = a->state_only ? N : 1, K = a->state_only ? cnt : N * cnt, split = K <= 1024 ? 1 : (a->state_only ? 4 : 8);
+      g.A = a->dq; g.sAm = 1; g.sAk = 1; g.sAb = a->state_only ? cnt : 0;   // one row: dq as [1][K]
+      g.B = cb.m.h2; g.sBk = Hd; g.sBn = 1; g.sBb = a->state_only ? (long)cnt * Hd : 0;
+      g.M = 1; g.N = Hd; g.K = K; g.nbatch = groups; g.splitk = split;
+      if (split == 1) { g.C = a->Gc + o.c_hw; g.ldc = Hd; g.sCz = Hd; }
+      else {
+        g.C = a->slabs; g.ldc = Hd; g.sCz = 64L * Hd;
+        g.epi = kEpiReduce; g.zred = split; g.ctr = a->ctr; g.out = a->Gc + o.c_hw; g.ld_out = Hd; g.out_gstride = Hd;
+        SERL_REQUIRE((long)groups * split * g.sCz <= a->slabs_cap && groups * cdiv(Hd, 64) <= kCtrPerLane, "head gradient exceeds the scratch");
+      }
+      SERL_REQUIRE(a->pg_defer && a->pg_nwg < kMaxGemmGroups, "no room for the deferred head-gradient GEMM");
+      a->pg_wg[a->pg_nwg++] = g;
+    }
+    RC(dense_ln_tanh_bwd(a, nullptr, Hd, (long)cnt * Hd, cb.m.h2, Hd, (long)cnt * Hd, cb.m.xh2, cb.m.rs2, P + o.c_g2, Hd,
+                         N, cnt, Hd, a->da2, a->dg2, G, o.c_g2, o.c_be2, o.c_b2, Hd, st, dq, P + o.c_hw, dq_const,
+                         a->state_only ? Hd : 0, loss));
+    if (pg)
+      RC(wgrad(a, cb.m.h1, Hd, (long)cnt * Hd, a->da2, Hd, (long)cnt * Hd, a->Gc + o.c_w2, Hd, (long)Hd * Hd, N, Hd, Hd,
+               cnt, st));
+    RC(igrad(a->da2, Hd, (long)cnt * Hd, P + o.c_w2, Hd, (long)Hd * Hd, a->dh1, Hd, (long)cnt * Hd, N, cnt, Hd, Hd, st));
+    RC(dense_ln_tanh_bwd(a, a->dh1, Hd, (long)cnt * Hd, cb.m.h1, Hd, (long)cnt * Hd, cb.m.xh1, cb.m.rs1, P + o.c_g1, Hd,
+                         N, cnt, Hd, a->da1, a->dg1, G, o.c_g1, o.c_be1, o.c_b1, Hd, st));
+    if (pg)
+      RC(wgrad(a, cb.x, a->XA, 0, a->da1, Hd, (long)cnt * Hd, a->Gc + o.c_w1, Hd, (long)a->XA * Hd, N, a->XA, Hd, cnt, st));
+    // dx = sum_e da1[e] * W1[e]^T, the ensemble sum inside the GEMM launch
+    return igrad_sum(a, a->da1, Hd, (long)cnt * Hd, P + o.c_w1, Hd, (long)a->XA * Hd, a->dx, a->XA, N, cnt, a->XA, Hd, st);
+  }
   if (pg && !a->state_only) {  // shared head kernel: dw[j] = sum_{e,b} dq*h2
     GemmDesc g{};
     g.A = a->dq; g.sAm = 0; g.sAk = 1; g.sAb = 0;
@@ -681,6 +797,11 @@ int encode_bwd_critic(serl_agent* a, const float* P, EncBuf& e, int off, int cnt
   return SERL_OK;
 }
 
+// Fused chain: the critic path's backward below dx in one piece -- the LayerNorm backward of the camera heads (width 256) and of
+// the proprio branch (width 64) share ONE launch, the SpatialLearnedEmbeddings gradient sums its batch splits itself
+// (sle_bwd_fused), every parameter gradient is deferred.  `event_bucket0`: see serl_agent_critic_grads_bucketed.
+int enc_proprio_bwd_critic_fused(serl_agent* a, const float* P, EncBuf& e, int off, int cnt, hipStream_t st, void* event_bucket0);
+
 // proprio-branch backward: dy = gradient wrt the proprio code (ld/offset given), into G (Gc or Ga)
 int proprio_bwd(serl_agent* a, const float* P, const float* dy, long ld_dy, const float* y, long ld_y, EncBuf& e,
                 int which, int off, int cnt, float* G, long base_off, hipStream_t st) {
@@ -691,6 +812,45 @@ int proprio_bwd(serl_agent* a, const float* P, const float* dy, long ld_dy, cons
                        o.p_g - base_off, o.p_be - base_off, o.p_b - base_off, 0, st));
   const float* s = a->cur.state + ((long)which * a->cur.batch + off) * c.state_dim;
   return wgrad(a, s, c.state_dim, 0, a->dp, Pd, 0, G + (o.p_W - base_off), Pd, 0, 1, c.state_dim, Pd, cnt, st);
+}
+
+int enc_proprio_bwd_critic_fused(serl_agent* a, const float* P, EncBuf& e, int off, int cnt, hipStream_t st, void* event_bucket0) {
+  const serl_agent_cfg& c = a->cfg;
+  const Offs& o = a->o;
+  const int Bn = c.bottleneck, Pd = c.proprio_dim;
+  const long pc = (long)c.n_cam * Bn;
+  LnBwdArgs lb[2] = {LnBwdArgs{}, LnBwdArgs{}};
+  LnBwdArgs& h = lb[0];   // camera heads
+  h.dy = a->dx; h.ld_dy = a->XA; h.dy_goff = Bn;
+  h.y = e.enc; h.ld_y = e.ld; h.y_goff = Bn;
+  h.xhat = e.xhat; h.rstd = e.rstd; h.gamma = P + o.cam[0].lng; h.pstride = o.cam_stride;
+  h.rows = c.n_cam * cnt; h.rows_per_group = cnt; h.dx = a->dz; h.dg = a->dgz; h.D = Bn;
+  LnBwdArgs& q = lb[1];   // proprio branch
+  q.dy = a->dx + pc; q.ld_dy = a->XA; q.dy_goff = 0;
+  q.y = e.enc + pc; q.ld_y = e.ld; q.y_goff = 0;
+  q.xhat = e.pxhat; q.rstd = e.prstd; q.gamma = P + o.p_g; q.pstride = 0;
+  q.rows = cnt; q.rows_per_group = cnt; q.dx = a->dp; q.dg = a->dgp; q.D = Pd;
+  RC(ln_tanh_bwd_multi(lb, 2, LossArgs{}, st));
+  SERL_REQUIRE(a->pg_defer && a->pg_ncs + 2 <= kMaxColsum, "no room for the deferred LayerNorm gradients");
+  a->pg_cs[a->pg_ncs++] = Colsum3Args{a->dgp, e.pxhat, a->dp, 1, cnt, Pd, a->Gc + o.p_g, a->Gc + o.p_be, a->Gc + o.p_b, 0, 0};
+  a->pg_cs[a->pg_ncs++] = Colsum3Args{a->dgz, e.xhat, a->dz, c.n_cam, cnt, Bn, a->Gc + o.cam[0].lng, a->Gc + o.cam[0].lnb,
+                                      a->Gc + o.cam[0].db, o.cam_stride, 0};
+  const float* s = a->cur.state + (long)off * c.state_dim;
+  RC(wgrad(a, s, c.state_dim, 0, a->dp, Pd, 0, a->Gc + o.p_W, Pd, 0, 1, c.state_dim, Pd, cnt, st));
+  if (event_bucket0) {   // bucket 0 (ensemble | head | proprio | scalars) is final once these deferred jobs have run
+    RC(flush_param_grads(a, st));
+    SERL_HIP(hipEventRecord((hipEvent_t)event_bucket0, st));
+  }
+  RC(wgrad(a, e.f, a->D, (long)c.batch * a->D, a->dz, Bn, (long)cnt * Bn, a->Gc + o.cam[0].dW, Bn, o.cam_stride,
+           c.n_cam, a->D, Bn, cnt, st));
+  RC(igrad(a->dz, Bn, (long)cnt * Bn, P + o.cam[0].dW, Bn, o.cam_stride, a->df, a->D, (long)cnt * a->D, c.n_cam, cnt,
+           a->D, Bn, st));
+  if (a->small) return small_backward(a->sws, P, o.cam[0].conv, o.cam_stride, c.n_cam, cnt, a->df, (long)cnt * a->D, a->Gc, st);
+  const long sle_n = (long)a->HW * 512 * c.sle_features;
+  const float* x = a->feats + (long)off * a->HW * 512;
+  SERL_REQUIRE((long)c.n_cam * a->HW * 2 <= kCtrPerLane, "SLE gradient exceeds the arrival counters");
+  return sle_bwd_fused(x, a->df, a->sle_part, cnt, a->HW, 512, kSleSplit, c.n_cam, (long)c.batch * a->HW * 512, (long)cnt * a->D,
+                       (long)kSleSplit * sle_n, a->Gc + o.cam[0].sle, o.cam_stride, a->ctr, st);
 }
 
 // Noise of one update phase: caller-provided tensors are used as they are (parity mode), missing ones are
@@ -716,6 +876,21 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
                                cnt_total, a->shard_global, a->shard_off, a->D};
     *mask = a->mask_buf[slot];
   }
+}
+
+// Fused chain: nothing is generated ahead of time.  Missing normal draws are hashed inside the policy-head epilogue (same
+// stream as gen_noise: seed and global-row indexing unchanged) and kept in eps_buf[slot]; a missing Dropout mask is hashed
+// inside the SLE kernel.  The seeds advance exactly as fetch_noise advances them.
+struct FusedNoise { const float* eps; float* eps_out; uint64_t eps_seed; const uint8_t* mask; int gen_mask; uint64_t mask_seed; };
+FusedNoise fetch_noise_fused(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot) {
+  const serl_agent_cfg& c = a->cfg;
+  FusedNoise f{};
+  f.eps = given_eps;
+  f.eps_out = a->eps_buf[slot];
+  if (!given_eps) f.eps_seed = c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr));
+  if (given_mask || a->state_only || a->small) f.mask = a->small ? nullptr : given_mask;
+  else { f.gen_mask = 1; f.mask_seed = c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)); }
+  return f;
 }
 
 // learning rate of optimizer `tx` at `count` (optimizers.py:14-30): warm-up -> constant, or warm-up -> cosine decay
@@ -761,6 +936,7 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   SERL_HIP(hipSetDevice(cfg->device));
   serl_agent* a = new serl_agent();
   a->cfg = *cfg;
+  { const char* e = getenv("SERL_CHAIN_FUSE"); a->fuse = !(e && e[0] == '0'); }
   build_layout(a);
   const size_t bytes = carve(a, nullptr);
   hipError_t e = hipMalloc(&a->arena, bytes);
@@ -992,11 +1168,39 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   for (int k = 0; k < m_sub; ++k) SERL_REQUIRE(sel.idx[k] >= 0 && sel.idx[k] < c.ensemble, "REDQ index out of range");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
+  const int A = c.act_dim;
+  if (a->fuse) {
+    const FusedNoise fz = fetch_noise_fused(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0);
+    EncJob ej[3] = {{a->theta, 1, fz.mask, &a->encP, nullptr, nullptr},
+                    {a->theta_t, 1, nullptr, &a->encT, nullptr, nullptr},
+                    {a->theta, 0, nullptr, &a->encO, a->cur.action + (long)off * A, a->crit.x + a->E}};
+    ej[0].gen_mask = fz.gen_mask; ej[0].mask_seed = fz.mask_seed;
+    RC(encode_multi(a, ej, 3, off, cnt, st));
+    PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, fz.eps ? fz.eps + (long)off * A : nullptr, a->critT.x + a->E, a->XA, nullptr,
+              c.backup_entropy ? a->aux + X_ALPHA : nullptr};
+    pj.eps_out = fz.eps_out + (long)off * A; pj.eps_seed = fz.eps_seed; pj.eps_row0 = a->shard_off + off;
+    RC(policy_fwd_multi(a, &pj, 1, cnt, st));
+    const CritJob cj[2] = {{a->theta_t, &a->critT}, {a->theta, &a->crit}};
+    RC(critic_fwd_multi(a, cj, 2, cnt, st));
+    // REDQ target + loss: a rider workgroup of the LayerNorm-backward launch that consumes dQ (no critic_loss launch)
+    const LossArgs L{1, a->critT.q, a->crit.q, a->cur.reward + off, a->cur.mask + off, sel, c.ensemble, cnt, c.discount,
+                     1.0f / ((float)c.ensemble * (float)global_count), a->ytgt, a->dq, a->SC, a->Gc + o.c_hb, a->state_only ? 1 : 0,
+                     c.backup_entropy ? a->pol.logp : nullptr, c.backup_entropy ? a->aux + X_ALPHA : nullptr};
+    SERL_REQUIRE(!a->state_only || c.ensemble <= 16, "per-member head bias supports ensembles of at most 16");
+    RC(critic_bwd(a, a->theta, a->crit, cnt, true, st, a->dq, 0.f, &L));
+    if (!a->state_only) RC(enc_proprio_bwd_critic_fused(a, a->theta, a->encO, off, cnt, st, event_bucket0));
+    else if (event_bucket0) {
+      RC(flush_param_grads(a, st));
+      SERL_HIP(hipEventRecord((hipEvent_t)event_bucket0, st));
+    }
+    RC(flush_param_grads(a, st));
+    a->last_global = global_count;
+    return SERL_OK;
+  }
   const float* eps; const uint8_t* mask;
   NoiseBatch nb;
   fetch_noise(a, nb, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask);
   RC(nb.flush(st));
-  const int A = c.act_dim;
   // the three encoder passes of the critic loss in one set of launches: online policy input at next_obs
   // (dropout), target-critic input at next_obs (target_params, train=False), online-critic input at obs
   // (train=False; the batch's actions ride along into [enc | action])
@@ -1039,11 +1243,56 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
+  hipStream_t s0 = st;
+  if (a->fuse) {
+    const FusedNoise fp = fetch_noise_fused(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1);
+    const FusedNoise ft = fetch_noise_fused(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2);
+    EncJob ej[3] = {{a->theta, 1, ft.mask, &a->encT, nullptr, nullptr},
+                    {a->theta, 0, nullptr, &a->encO, nullptr, nullptr},
+                    {a->theta, 0, fp.mask, &a->encP, nullptr, nullptr}};
+    ej[0].gen_mask = ft.gen_mask; ej[0].mask_seed = ft.mask_seed;
+    ej[2].gen_mask = fp.gen_mask; ej[2].mask_seed = fp.mask_seed;
+    RC(encode_multi(a, ej, 3, 0, cnt, s0));
+    PolJob pj[2] = {{a->theta, &a->polT, a->encT.enc, a->encT.ld, ft.eps, a->act_tmp, A, a->SC + S_LOGP_NEXT, a->aux + X_ALPHA},
+                    {a->theta, &a->pol, a->encP.enc, a->encP.ld, fp.eps, a->crit.x + a->E, a->XA, a->SC + S_LOGP, nullptr}};
+    pj[0].eps_out = ft.eps_out; pj[0].eps_seed = ft.eps_seed; pj[0].eps_row0 = a->shard_off;
+    pj[1].eps_out = fp.eps_out; pj[1].eps_seed = fp.eps_seed; pj[1].eps_row0 = a->shard_off;
+    RC(policy_fwd_multi(a, pj, 2, cnt, s0));
+    eps_pi = fp.eps ? fp.eps : fp.eps_out;   // (the backward reads the draws the head epilogue used)
+    const CritJob cj{a->theta, &a->crit};
+    RC(critic_fwd_multi(a, &cj, 1, cnt, s0));
+    RC(critic_bwd(a, a->theta, a->crit, cnt, false, s0, nullptr, -1.0f / ((float)c.ensemble * (float)global_count)));
+    RC(policy_dist_bwd(a->dx + a->E, a->XA, a->crit.x + a->E, a->XA, a->pol.pre, a->pol.std, eps_pi, a->aux + X_ALPHA,
+                       1.0f / (float)global_count, cnt, A, c.std_min, c.std_max, a->dpre, a->crit.q, c.ensemble,
+                       a->SC + S_QPI, s0));
+    const long hs = o.a_Ws - o.a_Wm;
+    float* Ga = a->Ga;
+    const long b0 = o.Pa0;
+    RC(wgrad(a, a->pol.m.h2, Hd, 0, a->dpre, A, (long)cnt * A, Ga + (o.a_Wm - b0), A, hs, 2, Hd, A, cnt, s0));
+    SERL_REQUIRE(a->pg_ncs < kMaxColsum, "no room for the head-bias gradient job");
+    a->pg_cs[a->pg_ncs++] = Colsum3Args{a->dpre, nullptr, nullptr, 2, cnt, A, nullptr, Ga + (o.a_bm - b0), nullptr, hs, 1};
+    // dh2 = dmean W_mean^T + dlog_std W_logstd^T: both products and their sum in one launch
+    RC(igrad_sum(a, a->dpre, A, (long)cnt * A, a->theta + o.a_Wm, A, hs, a->dh2, Hd, 2, cnt, Hd, A, s0));
+    RC(dense_ln_tanh_bwd(a, a->dh2, Hd, 0, a->pol.m.h2, Hd, 0, a->pol.m.xh2, a->pol.m.rs2, a->theta + o.a_g2, 0, 1, cnt, Hd,
+                         a->da2, a->dg2, Ga, o.a_g2 - b0, o.a_be2 - b0, o.a_b2 - b0, 0, s0));
+    RC(wgrad(a, a->pol.m.h1, Hd, 0, a->da2, Hd, 0, Ga + (o.a_w2 - b0), Hd, 0, 1, Hd, Hd, cnt, s0));
+    RC(igrad(a->da2, Hd, 0, a->theta + o.a_w2, Hd, 0, a->dh1, Hd, 0, 1, cnt, Hd, Hd, s0));
+    RC(dense_ln_tanh_bwd(a, a->dh1, Hd, 0, a->pol.m.h1, Hd, 0, a->pol.m.xh1, a->pol.m.rs1, a->theta + o.a_g1, 0, 1, cnt, Hd,
+                         a->da1, a->dg1, Ga, o.a_g1 - b0, o.a_be1 - b0, o.a_b1 - b0, 0, s0));
+    RC(wgrad(a, a->encP.enc, a->encP.ld, 0, a->da1, Hd, 0, Ga + (o.a_w1 - b0), Hd, 0, 1, a->E, Hd, cnt, s0));
+    if (!a->state_only) {
+      const long pc = (long)c.n_cam * c.bottleneck;
+      RC(igrad(a->da1, Hd, 0, a->theta + o.a_w1 + pc * Hd, Hd, 0, a->dprop_y, c.proprio_dim, 0, 1, cnt, c.proprio_dim, Hd, s0));
+      RC(proprio_bwd(a, a->theta, a->dprop_y, c.proprio_dim, a->encP.enc + pc, a->encP.ld, a->encP, 0, 0, cnt, Ga, b0, s0));
+    }
+    RC(flush_param_grads(a, s0));
+    a->last_global = global_count;
+    return SERL_OK;
+  }
   NoiseBatch nb;
   fetch_noise(a, nb, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi);
   fetch_noise(a, nb, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t);
   RC(nb.flush(st));
-  hipStream_t s0 = st;
   // encoder passes of the actor step in one set of launches: temperature loss input (next_obs, dropout;
   // sac.py:223-234), critic-side encoding of obs (train=False), policy input at obs (dropout; sac.py:193-221)
   const EncJob ej[3] = {{a->theta, 1, mask_t, &a->encT, nullptr, nullptr},
@@ -1214,13 +1463,16 @@ int serl_agent_sample_actions(serl_agent* a, const uint8_t* dev_frames, const fl
     RC(fill(a->eps_buf[0], 0.f, (long)n * c.act_dim, st));
     dev_eps = a->eps_buf[0];
   }
-  const PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, dev_eps, dev_out_actions, c.act_dim, nullptr, nullptr};
+  PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, dev_eps, dev_out_actions, c.act_dim, nullptr, nullptr};
+  pj.eps_out = a->eps_buf[0];
   RC(policy_fwd_multi(a, &pj, 1, n, st));
   a->cur = saved;
   a->has_batch = had;
   a->feats = saved_feats;
   return SERL_OK;
 }
+
+int64_t serl_debug_chain_launches(void) { return (int64_t)g_chain_launches; }
 
 int serl_agent_trunk_plan(serl_agent* a, char* out, int cap) {
   SERL_REQUIRE(a && out && cap > 0, "bad argument");

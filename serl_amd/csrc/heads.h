@@ -4,6 +4,8 @@
 
 namespace serl {
 
+extern long g_chain_launches;   // kernels launched by heads.hip since the library was loaded (diagnostic)
+
 // The update chain is a long sequence of small dependent kernels, each costing ~5 us of launch/drain latency
 // whatever its size: independent instances of the same kind of work (the three EncodingWrapper passes of a
 // loss, the online and target critics, the two policy evaluations of the actor step) share one launch.
@@ -17,22 +19,15 @@ int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int ro
                  long bias_gstride, float* out, long ld_out, long out_gstride, bool accumulate,
                  hipStream_t stream, float scale = 1.0f);
 
-// rows are grouped (group g = row / rows_per_group) and every group has its own bias/gamma/beta at
-// `pstride` floats apart; the pre-activation is bias + sum of S GEMM slabs laid out [g*S + s][local row][D]
-struct LnFwdArgs {
-  const float* slabs; int S; long slab_stride;
-  const float *bias, *gamma, *beta; long pstride;
-  int rows, rows_per_group;
-  float* y; long ld_y; long y_goff;  // y[local_row*ld_y + group*y_goff + col] (column slices / group blocks)
-  float* xhat;           // [rows][D] or nullptr
-  float* rstd;           // [rows] or nullptr
-  // optional fused row-dot (critic head, actor_critic_nets.py:65-73): dot_out[row] = sum_col y*dot_w + dot_b[0]
-  const float* dot_w; const float* dot_b; float* dot_out;
-  long dot_gstride, dot_b_gstride;  // 0: one head shared by all groups (DrQ critic); else per-group heads (ensemblized Critic)
-  int relu;              // 0: tanh (the MLPs / encoder heads); 1: ReLU (BinaryClassifier, reward_classifier.py:24-26)
-};
 int ln_tanh_fwd_multi(const LnFwdArgs* a, int n, int D, hipStream_t stream);
 
+// REDQ target + critic loss as a rider workgroup of the LayerNorm-backward launch that consumes dQ (sac.py:142-191)
+struct RedqSel { int n; int idx[16]; };
+struct LossArgs {
+  int on;
+  const float *qt, *q, *reward, *mask; RedqSel sel; int E, B; float discount, inv_norm;
+  float *y_out, *dq, *scalars, *dbias; int per_member; const float *logp_next, *alpha;
+};
 struct LnBwdArgs {
   const float* dy; long ld_dy; long dy_goff;  // same addressing as LnFwdArgs::y (ignored in rank-1 mode)
   // rank-1 mode (gradient through the critic head): dy[row][col] = (dq ? dq[row] : dq_const) * dq_w[col]
@@ -44,37 +39,49 @@ struct LnBwdArgs {
   int rows, rows_per_group;
   float* dx;  // [rows][D] gradient wrt the pre-activation
   float* dg;  // [rows][D] dy*(1-y^2)  (-> dbeta = colsum(dg), dgamma = colsum(dg*xhat))
+  int D;          // ln_tanh_bwd_multi only: 64 or 256
+  int dq_inline;  // ln_tanh_bwd_multi, rank-1 mode: dq[row] = 2 (q - y) inv_norm computed from the LossArgs of the launch
 };
 int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream);
+// up to kMaxMulti LayerNorm backward passes of possibly different widths in one launch (+ the critic-loss rider when loss.on)
+int ln_tanh_bwd_multi(const LnBwdArgs* a, int n, const LossArgs& loss, hipStream_t stream);
 
 int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
            long out_gstride, bool accumulate, hipStream_t stream);
 struct Colsum3Args {
   const float *dg, *xhat, *dpre; int groups, rows_per_group, D;
   float *o_gamma, *o_beta, *o_bias; long gstride;
+  int mode;   // 0: the three sums of a Dense->LN->tanh layer; 1: o_beta[g][j] = sum_r dg[r][j] only (bias gradient of a plain
+              // Dense); 2: o_beta[0] = sum_r dg[r] (a vector's sum: rows_per_group elements, D = groups = 1)
 };
+constexpr int kMaxColsum = 8;
 int colsum3_multi(const Colsum3Args* layers, int n, hipStream_t stream);
 int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream);
-struct SleFwdArgs { const float* x; const float* K; const uint8_t* mask; float* f; };
+struct SleFwdArgs {
+  const float* x; const float* K; const uint8_t* mask; float* f;
+  // sle_proprio_fwd only: mask == nullptr && gen -> Dropout keep-mask hashed from (seed, camera, GLOBAL row, channel)
+  int gen; uint64_t seed; long row_offset, rows_global;
+};
+// SpatialLearnedEmbeddings channel-blocked (a workgroup = 256 channels x 8 samples: the kernel K is read once per workgroup,
+// not once per sample) + inline Dropout mask + the proprio branch as extra workgroups of the same launch (pv == nullptr: none)
+struct ProprioArgs;
+int sle_proprio_fwd_multi(const SleFwdArgs* v, const ProprioArgs* pv, int n, float keep, int N, int HW, int Cc, int groups, long x_gs,
+                          long k_gs, long mask_gs, long f_gs, int state_dim, hipStream_t stream);
 int sle_fwd_multi(const SleFwdArgs* v, int n, float keep_scale, int N, int HW, int Cc, int groups, long x_gs, long k_gs,
                   long mask_gs, long f_gs, hipStream_t stream);
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
             long x_gs, long df_gs, long part_gs, hipStream_t stream);
+// the same with the sum over the batch splits done by the last-arriving workgroup of every (camera, pixel, channel block):
+// out[g][hw][c][j] (camera stride out_gs) -- no reduce_slabs launch.  ctr: groups * HW * cdiv(Cc, 256) zeroed counters.
+int sle_bwd_fused(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
+                  long x_gs, long df_gs, long part_gs, float* out, long out_gs, int* ctr, hipStream_t stream);
 // dbias: gradient of the head bias -- one scalar (shared head) or, with per_member_bias, one per ensemble member.
 // sel: the target ensemble members whose minimum backs up (sac.py:150-161: critic_subsample_size random members, n = 0: all).
 // logp_next / alpha != nullptr: backup_entropy (sac.py:174-176): y -= alpha[0] * logp_next[b]
-struct RedqSel { int n; int idx[16]; };
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, RedqSel sel, int E,
                 int B, float discount, float inv_norm, float* y_out, float* dq, float* scalars, float* dbias,
                 hipStream_t stream, bool per_member_bias = false, const float* logp_next = nullptr, const float* alpha = nullptr);
-// tanh-Gaussian policy head: slabs = raw head GEMM outputs (mean, log_std); biases added here, result kept in `pre`
-struct PolicyDistArgs {
-  const float* slabs; int S;  // head GEMM output [mean | log_std][S K-splits][B][A]
-  const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
-  float* act; long ld_act; float* logp; float* std_out; float* sum_logp;
-  const float* lam; float* alpha_out;  // optional rider: alpha_out[0] = softplus(lam[0])
-};
 int policy_dist_fwd_multi(const PolicyDistArgs* v, int n, int B, int A, float std_min, float std_max, hipStream_t stream);
 // proprio branch: y = tanh(LN(state W + b)) with W [S][64] (encoding.py:55-70), one wave per row
 struct ProprioArgs {

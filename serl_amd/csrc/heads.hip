@@ -10,6 +10,10 @@
 
 namespace serl {
 
+// every kernel launch of the update chain is counted (serl_debug_chain_launches: the tests pin the chain's launch count)
+long g_chain_launches = 0;
+#define SERL_LAUNCH_CHAIN(...) do { ++g_chain_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // =============================================================================================
@@ -102,6 +106,220 @@ struct OperandLoader {
   }
 };
 
+// =============================================================================================
+// Last-arriver epilogues (GemmDesc::epi).  The update chain is ~60 small dependent kernels; a launch boundary costs it more
+// than most of these kernels do.  Where a GEMM was followed by a kernel whose only job was to sum the GEMM's slabs (K-split
+// or ensemble members) and apply something row-local (bias + LayerNorm + tanh, the tanh-Gaussian head), the consumer now runs
+// inside the GEMM launch, in the workgroup that arrives LAST at the output tile:
+//   * every workgroup writes its 64x64 slab tile with 16-byte WRITE-THROUGH stores (buffer_store_dwordx4 sc1: the bytes leave
+//     the XCD's L2, so no release fence / L2 write-back is needed), every wave drains its stores (s_waitcnt vmcnt(0), written
+//     as inline asm so the compiler cannot drop it), __syncthreads, then ONE lane takes a ticket from the tile's arrival
+//     counter with a returning memory-side atomic;
+//   * the workgroup that draws the last ticket re-zeroes the counter and reads every slab of the tile with sc1 loads (served
+//     past its own L1: no acquire fence / invalidate needed) IN INDEX ORDER -- the same order the separate reduce_slabs /
+//     ln_tanh_fwd kernels summed in, so fused and un-fused results are bit-identical (tests assert exact equality).
+// This is the "in-launch split-K reduction" recipe of cdna_hip_programming.md (sc1 stores + drain + barrier + relaxed
+// ticket; sc1 loads on the reducer): correct for any placement of a tile's workgroups over CUs / XCDs, no spinning (nobody
+// waits for anybody), no cache maintenance next to the co-running trunk pass.  The MFMA accumulator layout gives a lane one
+// COLUMN of 16 rows; the tile is turned into row-major 16-byte vectors through the (now idle) operand LDS, 16 rows per wave
+// and pass.  Slab images are padded scratch (ldc % 64 == 0, whole tiles): no edge handling on the slab side.
+// =============================================================================================
+constexpr int kEpiPitch = 36;                       // floats per LDS row of the transpose scratch
+constexpr int kEpiScratch = 4 * 16 * kEpiPitch;     // floats (4 waves x 16 rows); one more int behind it = the "I am last" flag
+constexpr int kSc1 = 16;                            // buffer aux bits: sc1 (write-through store / L1-bypassing load)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, kSc1));
+}
+__device__ __forceinline__ float ld1_sc1(__amdgpu_buffer_rsrc_t r, long float_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(float_off * 4), 0, kSc1));
+}
+
+// accumulators of wave (wm, wn) -> slab tile rows m0 + wm*32 .., columns n0 + wn*32 .. as 16-byte sc1 stores
+__device__ __forceinline__ void store_tile_sc1(float* C, long ldc, int m0, int n0, const f32x16& acc, float* scratch, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  float* S = scratch + wave * 16 * kEpiPitch;
+  const __amdgpu_buffer_rsrc_t rs = rsrc_of(C);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int r = 8 * p; r < 8 * p + 8; ++r) S[(8 * ((r >> 2) & 1) + 4 * lh + (r & 3)) * kEpiPitch + li] = acc[r];
+    __builtin_amdgcn_wave_barrier();   // (wave-private scratch: LDS ops of one wave execute in order)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = (lane >> 3) + 8 * h, c4 = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(S + row * kEpiPitch + 4 * c4);
+      const long off = (long)(m0 + wm * 32 + 16 * p + row) * ldc + n0 + wn * 32 + 4 * c4;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)(off * 4), 0, kSc1);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// every wave has drained its sc1 stores -> one ticket; true in the workgroup that arrived last (which re-zeroes the counter)
+__device__ __forceinline__ bool arrive_is_last(int* ctr, int total, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int last = old == total - 1;
+    if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// N(0,1) draw number i of stream `seed` (the element's position in the GLOBAL tensor: the same for whichever rank owns it)
+__device__ __forceinline__ float hash_normal(uint64_t seed, uint64_t i) {
+  const uint64_t r = mix64(seed ^ mix64(i));
+  const float u1 = ((float)(uint32_t)(r >> 40) + 1.0f) * (1.0f / 16777217.0f);
+  const float u2 = (float)(uint32_t)((r >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// LayerNorm(eps 1e-6, fast variance) + tanh of ONE row of 256 by one wave (mlp.py:24-31, resnet_v1.py:371-374, encoding.py:66-68):
+// pre = bias[g] + sum_s slab[s][row] (slabs read in index order);  y = tanh(gamma[g]*xhat + beta[g]).  LIVE: the slabs were
+// written by other workgroups of THIS launch (sc1 loads); otherwise plain loads (the separate ln_tanh_fwd kernel).
+template <bool LIVE>
+__device__ __forceinline__ void ln_tanh_row256(const LnFwdArgs& a, int row, int lane) {
+  constexpr int D = 256;
+  const int grp = row / a.rows_per_group;
+  const long lrow = row - grp * a.rows_per_group;
+  const long base = (long)grp * a.S * a.slab_stride + lrow * D + lane * 4;
+  const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.slabs);
+  float4 acc4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long)grp * a.pstride + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto slab = [&](int s) -> f32x4 {
+    if (LIVE) return ld_sc1(rs, base + (long)s * a.slab_stride);
+    return *reinterpret_cast<const f32x4*>(a.slabs + base + (long)s * a.slab_stride);
+  };
+  int s = 0;
+  for (; s + 4 <= a.S; s += 4) {   // 4 independent slab reads in flight, added in index order
+    const f32x4 x0 = slab(s), x1 = slab(s + 1), x2 = slab(s + 2), x3 = slab(s + 3);
+    acc4.x += x0[0]; acc4.y += x0[1]; acc4.z += x0[2]; acc4.w += x0[3];
+    acc4.x += x1[0]; acc4.y += x1[1]; acc4.z += x1[2]; acc4.w += x1[3];
+    acc4.x += x2[0]; acc4.y += x2[1]; acc4.z += x2[2]; acc4.w += x2[3];
+    acc4.x += x3[0]; acc4.y += x3[1]; acc4.z += x3[2]; acc4.w += x3[3];
+  }
+  for (; s < a.S; ++s) {
+    const f32x4 x0 = slab(s);
+    acc4.x += x0[0]; acc4.y += x0[1]; acc4.z += x0[2]; acc4.w += x0[3];
+  }
+  const float v[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float mean = s1 * (1.0f / D), mean2 = s2 * (1.0f / D);
+  const float var = fmaxf(mean2 - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-6f);
+  float d = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = lane * 4 + j;
+    const float xh = (v[j] - mean) * rstd;
+    const float pre = xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col];
+    const float y = a.relu ? fmaxf(pre, 0.f) : tanhf(pre);
+    a.y[lrow * a.ld_y + (long)grp * a.y_goff + col] = y;
+    if (a.xhat) a.xhat[(long)row * D + col] = xh;
+    if (a.dot_out) d += y * a.dot_w[(long)grp * a.dot_gstride + col];
+  }
+  if (a.rstd && lane == 0) a.rstd[row] = rstd;
+  if (a.dot_out) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off);
+    if (lane == 0) a.dot_out[row] = d + a.dot_b[(long)grp * a.dot_b_gstride];
+  }
+}
+
+// tanh-Gaussian head of rows [r0, r1) from the head GEMM's slabs (actor_critic_nets.py:179-272): one thread per (row, action)
+template <bool LIVE>
+__device__ __forceinline__ void policy_dist_rows(const PolicyDistArgs& v, int r0, int r1, int tid, int nthreads) {
+  const int A = v.A, B = v.B;
+  const __amdgpu_buffer_rsrc_t rs = rsrc_of(v.slabs);
+  for (int e = r0 * A + tid; e < r1 * A; e += nthreads) {
+    const int b = e / A, j = e - b * A;
+    float mean = v.bias_mean[j], ls = v.bias_ls[j];
+    for (int sp = 0; sp < v.S; ++sp) {   // K-split slabs of the head GEMM: [mean | log_std][split][rows][ld]
+      const long o0 = (long)sp * v.slab_stride + (long)b * v.slab_ld + j, o1 = o0 + (long)v.S * v.slab_stride;
+      mean += LIVE ? ld1_sc1(rs, o0) : v.slabs[o0];
+      ls += LIVE ? ld1_sc1(rs, o1) : v.slabs[o1];
+    }
+    float ep;
+    if (v.eps) ep = v.eps[(long)b * A + j];
+    else { ep = hash_normal(v.seed, (uint64_t)(v.row_offset + b) * (uint64_t)A + (uint64_t)j); v.eps_out[(long)b * A + j] = ep; }
+    v.pre[(long)b * A + j] = mean;
+    v.pre[((long)B + b) * A + j] = ls;
+    const float sd = fminf(fmaxf(expf(ls), v.std_min), v.std_max);
+    const float u = mean + sd * ep;
+    v.act[(long)b * v.ld_act + j] = tanhf(u);
+    v.std_out[(long)b * A + j] = sd;
+  }
+}
+// logp[b] = sum_j(-eps^2/2 - log std - log(2pi)/2) - sum_j 2(log2 - u - softplus(-2u)), in j order (one thread per row)
+__device__ __forceinline__ void policy_logp_rows(const PolicyDistArgs& v, int r0, int r1, int tid, int nthreads) {
+  const int A = v.A;
+  for (int b = r0 + tid; b < r1; b += nthreads) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float e = v.eps ? v.eps[(long)b * A + j] : v.eps_out[(long)b * A + j];
+      const float sd = v.std_out[(long)b * A + j];
+      const float u = v.pre[(long)b * A + j] + sd * e;
+      lp += -0.5f * e * e - logf(sd) - 0.91893853320467274f;
+      lp -= 2.f * (0.69314718055994531f - u - softplusf(-2.f * u));
+    }
+    v.logp[b] = lp;
+  }
+}
+
+// the epilogue proper; `lds` = the kernel's operand LDS (>= kEpiScratch floats + 1 int), idle after the K loop
+__device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& acc, float* C, int z, int batch, int m0, int n0,
+                                              float* lds, int tid) {
+  store_tile_sc1(C, g.ldc, m0, n0, acc, lds, tid);
+  int* flag = reinterpret_cast<int*>(lds + kEpiScratch);
+  const int tiles_m = (g.M + kGBM - 1) / kGBM, tiles_n = (g.N + kGBN - 1) / kGBN;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (g.epi == kEpiReduce) {
+    const int zg = z / g.zred;
+    if (!arrive_is_last(g.ctr + ((long)zg * tiles_m + blockIdx.y) * tiles_n + blockIdx.x, g.zred, flag)) return;
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(g.C + (long)zg * g.zred * g.sCz);
+    float* out = g.out + (long)zg * g.out_gstride;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = m0 + 16 * p + (tid >> 4), n = n0 + 4 * (tid & 15);
+      if (m >= g.M || n >= g.N) continue;
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < g.zred; ++s) sum += ld_sc1(rs, (long)s * g.sCz + (long)m * g.ldc + n);
+      float* o = out + (long)m * g.ld_out + n;
+      if (n + 4 <= g.N) *reinterpret_cast<f32x4u*>(o) = sum;
+      else for (int j = 0; j < g.N - n; ++j) o[j] = sum[j];
+    }
+  } else if (g.epi == kEpiLn) {
+    if (!arrive_is_last(g.ctr + (long)batch * tiles_m + blockIdx.y, tiles_n * g.splitk, flag)) return;
+    const int r_end = min(m0 + kGBM, g.M);
+    for (int r = m0 + wave; r < r_end; r += 4) ln_tanh_row256<true>(g.ln, batch * g.ln.rows_per_group + r, lane);
+  } else {   // kEpiPolicy
+    if (!arrive_is_last(g.ctr + blockIdx.y, g.nbatch * g.splitk * tiles_n, flag)) return;
+    const int r_end = min(m0 + kGBM, g.M);
+    policy_dist_rows<true>(g.pd, m0, r_end, tid, 256);
+    __syncthreads();   // (this workgroup's own global writes of pre / std / eps, read back below)
+    policy_logp_rows(g.pd, m0, r_end, tid, 256);
+    if (blockIdx.y == 0 && tid == 0 && g.pd.alpha_out) g.pd.alpha_out[0] = softplusf(g.pd.lam[0]);
+  }
+}
+
 // Several independent GEMMs in one launch (the chain is latency-bound: one launch per *kind* of work, not per
 // instance): group i owns blockIdx.z in [zend[i-1], zend[i]); the x/y grid is the maximum over the groups.
 struct GemmMulti {
@@ -112,8 +330,10 @@ struct GemmMulti {
 
 template <bool A_KFAST, bool B_KFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
-  __shared__ __attribute__((aligned(16))) float As[kGTile];  // [m][k] (pitch 36) or [k][m] (pitch 68)
-  __shared__ __attribute__((aligned(16))) float Bs[kGTile];  // [n][k]             or [k][n]
+  static_assert(2 * kGTile >= kEpiScratch + 4, "the epilogue's transpose scratch lives in the operand LDS");
+  __shared__ __attribute__((aligned(16))) float ABf[2 * kGTile];
+  float* const As = ABf;            // [m][k] (pitch 36) or [k][m] (pitch 68)
+  float* const Bs = ABf + kGTile;   // [n][k]             or [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int grp = 0;
@@ -153,6 +373,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
       __syncthreads();
     }
   }
+  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, As, tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -330,8 +551,10 @@ struct XLoader {
 template <bool A_KFAST, bool B_KFAST, int BK>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   constexpr int kPlane = kGBM * BK * 2;
-  __shared__ __attribute__((aligned(16))) uint8_t As[3 * kPlane];
-  __shared__ __attribute__((aligned(16))) uint8_t Bs[3 * kPlane];
+  static_assert(6 * kPlane >= (kEpiScratch + 4) * 4, "the epilogue's transpose scratch lives in the operand LDS");
+  __shared__ __attribute__((aligned(16))) uint8_t AB[6 * kPlane];
+  uint8_t* const As = AB;
+  uint8_t* const Bs = AB + 3 * kPlane;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int grp = 0;
@@ -382,6 +605,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
       __syncthreads();
     }
   }
+  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, reinterpret_cast<float*>(AB), tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -463,19 +687,19 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   static const bool exact = []() { const char* e = getenv("SERL_GEMM"); return e && e[0] == 'f'; }();
   if (vec && (!exact || gather)) {   // BK = 16 (12 KB of LDS); BK = 32 (24 KB) was measured 30 us per step slower next to the trunk pass
 
-    if (a_k && b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
-    else if (a_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);
-    else if (b_k) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 16>), grid, dim3(256), 0, stream, mm);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 16>), grid, dim3(256), 0, stream, mm);
+    if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
+    else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);
+    else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16>), grid, dim3(256), 0, stream, mm);
+    else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16>), grid, dim3(256), 0, stream, mm);
   } else if (vec) {
-    if (a_k && b_k) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
-    else if (a_k) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
-    else if (b_k) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, mm);
+    if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
+    else if (a_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
+    else if (b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);
+    else SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, mm);
   } else {
     for (int i = 0; i < n; ++i) {
       const GemmDesc& g = gs[i];
-      hipLaunchKernelGGL(gemm_f32_strided_kernel, dim3(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk), dim3(256), 0,
+      SERL_LAUNCH_CHAIN(gemm_f32_strided_kernel, dim3(cdiv(g.N, kGBN), cdiv(g.M, kGBM), g.nbatch * g.splitk), dim3(256), 0,
                          stream, g);
     }
   }
@@ -505,7 +729,7 @@ int reduce_slabs(const float* slabs, int S, long slab_stride, int groups, int ro
                  long bias_gstride, float* out, long ld_out, long out_gstride, bool accumulate,
                  hipStream_t stream, float scale) {
   dim3 grid(cdiv((long)rows * N, 256), groups);
-  hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, stream, slabs, S, slab_stride, rows, N, bias,
+  SERL_LAUNCH_CHAIN(reduce_slabs_kernel, grid, dim3(256), 0, stream, slabs, S, slab_stride, rows, N, bias,
                      bias_gstride, out, ld_out, out_gstride, accumulate ? 1 : 0, scale);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
@@ -520,38 +744,17 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
   const LnFwdArgs& a = mv.v[blockIdx.y];  // blockIdx.y = independent instance (variant)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= a.rows) return;
+  if (VPL == 4) { ln_tanh_row256<false>(a, row, lane); return; }   // (the same code the fused GEMM epilogue runs)
   const int grp = row / a.rows_per_group;
   constexpr int D = VPL * 64;
   float v[VPL];
-  if (VPL == 4) {  // 16-byte loads, 4 independent slab reads in flight
-    const float* sp = a.slabs + (long)grp * a.S * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + lane * 4;
-    float4 acc4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long)grp * a.pstride + lane * 4)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= a.S; s += 4) {
-      const float4 x0 = *reinterpret_cast<const float4*>(sp + (long)(s + 0) * a.slab_stride);
-      const float4 x1 = *reinterpret_cast<const float4*>(sp + (long)(s + 1) * a.slab_stride);
-      const float4 x2 = *reinterpret_cast<const float4*>(sp + (long)(s + 2) * a.slab_stride);
-      const float4 x3 = *reinterpret_cast<const float4*>(sp + (long)(s + 3) * a.slab_stride);
-      acc4.x += x0.x; acc4.y += x0.y; acc4.z += x0.z; acc4.w += x0.w;
-      acc4.x += x1.x; acc4.y += x1.y; acc4.z += x1.z; acc4.w += x1.w;
-      acc4.x += x2.x; acc4.y += x2.y; acc4.z += x2.z; acc4.w += x2.w;
-      acc4.x += x3.x; acc4.y += x3.y; acc4.z += x3.z; acc4.w += x3.w;
-    }
-    for (; s < a.S; ++s) {
-      const float4 x0 = *reinterpret_cast<const float4*>(sp + (long)s * a.slab_stride);
-      acc4.x += x0.x; acc4.y += x0.y; acc4.z += x0.z; acc4.w += x0.w;
-    }
-    v[0] = acc4.x; v[VPL > 1 ? 1 : 0] = acc4.y; v[VPL > 2 ? 2 : 0] = acc4.z; v[VPL > 3 ? 3 : 0] = acc4.w;
-  } else {
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const int col = lane * VPL + j;
-      float x = a.bias ? a.bias[(long)grp * a.pstride + col] : 0.f;
-      for (int s = 0; s < a.S; ++s)
-        x += a.slabs[(long)(grp * a.S + s) * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + col];
-      v[j] = x;
-    }
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    float x = a.bias ? a.bias[(long)grp * a.pstride + col] : 0.f;
+    for (int s = 0; s < a.S; ++s)
+      x += a.slabs[(long)(grp * a.S + s) * a.slab_stride + (long)(row - grp * a.rows_per_group) * D + col];
+    v[j] = x;
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -561,6 +764,7 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
   const float mean = s1 * (1.0f / D), mean2 = s2 * (1.0f / D);
   const float var = fmaxf(mean2 - mean * mean, 0.f);
   const float rstd = rsqrtf(var + 1e-6f);
+  float d = 0.f;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const int col = lane * VPL + j;
@@ -569,17 +773,10 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(Multi<LnFwdArgs> mv) {
     const float y = a.relu ? fmaxf(pre, 0.f) : tanhf(pre);
     a.y[(long)(row - grp * a.rows_per_group) * a.ld_y + (long)grp * a.y_goff + col] = y;
     if (a.xhat) a.xhat[(long)row * D + col] = xh;
+    if (a.dot_out) d += y * a.dot_w[(long)grp * a.dot_gstride + col];
   }
   if (a.rstd && lane == 0) a.rstd[row] = rstd;
   if (a.dot_out) {
-    float d = 0.f;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const int col = lane * VPL + j;
-      const float xh = (v[j] - mean) * rstd;
-      const float pre = xh * a.gamma[(long)grp * a.pstride + col] + a.beta[(long)grp * a.pstride + col];
-      d += (a.relu ? fmaxf(pre, 0.f) : tanhf(pre)) * a.dot_w[(long)grp * a.dot_gstride + col];
-    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) d += __shfl_xor(d, off);
     if (lane == 0) a.dot_out[row] = d + a.dot_b[(long)grp * a.dot_b_gstride];
@@ -593,8 +790,8 @@ int ln_tanh_fwd_multi(const LnFwdArgs* as, int n, int D, hipStream_t stream) {
   int rows = 0;
   for (int i = 0; i < n; ++i) { mv.v[i] = as[i]; rows = std::max(rows, as[i].rows); }
   dim3 grid(cdiv(rows, 4), n);
-  if (D == 256) hipLaunchKernelGGL(ln_tanh_fwd_kernel<4>, grid, dim3(256), 0, stream, mv);
-  else hipLaunchKernelGGL(ln_tanh_fwd_kernel<1>, grid, dim3(256), 0, stream, mv);
+  if (D == 256) SERL_LAUNCH_CHAIN(ln_tanh_fwd_kernel<4>, grid, dim3(256), 0, stream, mv);
+  else SERL_LAUNCH_CHAIN(ln_tanh_fwd_kernel<1>, grid, dim3(256), 0, stream, mv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -636,8 +833,135 @@ __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(LnBwdArgs a) {
 int ln_tanh_bwd(const LnBwdArgs& a, int D, hipStream_t stream) {
   SERL_REQUIRE(D == 256 || D == 64, "LayerNorm width %d unsupported (64 or 256)", D);
   dim3 grid(cdiv(a.rows, 4));
-  if (D == 256) hipLaunchKernelGGL(ln_tanh_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(ln_tanh_bwd_kernel<1>, grid, dim3(256), 0, stream, a);
+  if (D == 256) SERL_LAUNCH_CHAIN(ln_tanh_bwd_kernel<4>, grid, dim3(256), 0, stream, a);
+  else SERL_LAUNCH_CHAIN(ln_tanh_bwd_kernel<1>, grid, dim3(256), 0, stream, a);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
+// REDQ target of sample b (sac.py:150-176): y = r + discount * mask * min over the selected (or all) target members
+// [- alpha * log pi(a'|s') with backup_entropy, outside the discount as the reference has it]
+__device__ __forceinline__ float redq_target(const LossArgs& L, int b) {
+  float mq;
+  if (L.sel.n > 0) {
+    mq = L.qt[(long)L.sel.idx[0] * L.B + b];
+    for (int k = 1; k < L.sel.n; ++k) mq = fminf(mq, L.qt[(long)L.sel.idx[k] * L.B + b]);
+  } else {
+    mq = L.qt[b];
+    for (int e = 1; e < L.E; ++e) mq = fminf(mq, L.qt[(long)e * L.B + b]);
+  }
+  float y = L.reward[b] + L.discount * L.mask[b] * mq;
+  if (L.logp_next) y -= L.alpha[0] * L.logp_next[b];
+  return y;
+}
+
+// critic loss by ONE workgroup of 256 threads (deterministic reductions); the body of critic_loss_kernel
+__device__ void critic_loss_body(const LossArgs& L, float (*red)[256]) {
+  float s_d2 = 0.f, s_q = 0.f, s_y = 0.f, s_dq = 0.f;
+  float s_e[16];  // per-member sums of dQ (per_member: E <= 16)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s_e[e] = 0.f;
+  for (int b = threadIdx.x; b < L.B; b += 256) {
+    const float y = redq_target(L, b);
+    L.y_out[b] = y;
+    s_y += y;
+    for (int e = 0; e < L.E; ++e) {
+      const float qv = L.q[(long)e * L.B + b];
+      const float d = qv - y;
+      const float g = 2.f * d * L.inv_norm;
+      L.dq[(long)e * L.B + b] = g;
+      s_d2 += d * d;
+      s_q += qv;
+      s_dq += g;
+      if (L.per_member) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k == e) s_e[k] += g;
+      }
+    }
+  }
+  red[0][threadIdx.x] = s_d2; red[1][threadIdx.x] = s_q; red[2][threadIdx.x] = s_y; red[3][threadIdx.x] = s_dq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    L.scalars[0] = red[0][0]; L.scalars[1] = red[1][0]; L.scalars[2] = red[2][0];
+    if (!L.per_member) *L.dbias = red[3][0];
+  }
+  if (L.per_member) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < L.E) {  // (uniform)
+        __syncthreads();
+        red[0][threadIdx.x] = s_e[k];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
+          __syncthreads();
+        }
+        if (threadIdx.x == 0) L.dbias[k] = red[0][0];
+      }
+    }
+  }
+}
+
+template <int VPL>
+__device__ __forceinline__ void ln_tanh_bwd_row(const LnBwdArgs& a, const LossArgs& L, int row, int lane) {
+  const int grp = row / a.rows_per_group;
+  constexpr int D = VPL * 64;
+  float dg[VPL], dxh[VPL], xh[VPL];
+  float s1 = 0.f, s2 = 0.f;
+  const long lr = row - grp * a.rows_per_group;
+  float dqr = 0.f;
+  if (a.dq_w) dqr = a.dq_inline ? 2.f * (L.q[row] - redq_target(L, (int)lr)) * L.inv_norm : (a.dq ? a.dq[row] : a.dq_const);
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    const float y = a.y[lr * a.ld_y + (long)grp * a.y_goff + col];
+    const float dy = a.dq_w ? dqr * a.dq_w[(long)grp * a.dq_w_gstride + col] : a.dy[lr * a.ld_dy + (long)grp * a.dy_goff + col];
+    dg[j] = dy * (1.f - y * y);
+    xh[j] = a.xhat[(long)row * D + col];
+    dxh[j] = dg[j] * a.gamma[(long)grp * a.pstride + col];
+    s1 += dxh[j];
+    s2 += dxh[j] * xh[j];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float m1 = s1 * (1.0f / D), m2 = s2 * (1.0f / D), rstd = a.rstd[row];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int col = lane * VPL + j;
+    a.dx[(long)row * D + col] = rstd * (dxh[j] - m1 - xh[j] * m2);
+    a.dg[(long)row * D + col] = dg[j];
+  }
+}
+
+// blockIdx.y = instance (its own width); the LAST workgroup of instance 0 is the critic-loss rider when loss.on
+__global__ __launch_bounds__(256) void ln_tanh_bwd_multi_kernel(Multi<LnBwdArgs> mv, LossArgs loss) {
+  __shared__ float red[4][256];
+  if (loss.on && blockIdx.y == 0 && blockIdx.x == gridDim.x - 1) { critic_loss_body(loss, red); return; }
+  const LnBwdArgs& a = mv.v[blockIdx.y];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  if (a.D == 256) ln_tanh_bwd_row<4>(a, loss, row, lane);
+  else ln_tanh_bwd_row<1>(a, loss, row, lane);
+}
+
+int ln_tanh_bwd_multi(const LnBwdArgs* as, int n, const LossArgs& loss, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<LnBwdArgs> mv{};
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    SERL_REQUIRE(as[i].D == 256 || as[i].D == 64, "LayerNorm width %d unsupported (64 or 256)", as[i].D);
+    SERL_REQUIRE(!as[i].dq_inline || (loss.on && as[i].dq_w && as[i].rows == loss.E * loss.B && as[i].rows_per_group == loss.B),
+                 "inline dQ needs the loss arguments of the launch");
+    mv.v[i] = as[i];
+    rows = std::max(rows, as[i].rows);
+  }
+  SERL_LAUNCH_CHAIN(ln_tanh_bwd_multi_kernel, dim3(cdiv(rows, 4) + (loss.on ? 1 : 0), n), dim3(256), 0, stream, mv, loss);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -666,7 +990,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* X, const float
 
 int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D, float* out,
            long out_gstride, bool accumulate, hipStream_t stream) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64), groups), dim3(256), 0, stream, X, Y, rows_per_group, D,
+  SERL_LAUNCH_CHAIN(colsum_kernel, dim3(cdiv(D, 64), groups), dim3(256), 0, stream, X, Y, rows_per_group, D,
                      out, out_gstride, accumulate ? 1 : 0);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
@@ -674,26 +998,53 @@ int colsum(const float* X, const float* Y, int groups, int rows_per_group, int D
 
 // fused parameter gradients of one Dense->LN->tanh layer (one pass over dg, xhat, dpre):
 //   dgamma[g][j] = sum_r dg*xhat,  dbeta[g][j] = sum_r dg,  dbias[g][j] = sum_r dpre
-__global__ __launch_bounds__(512) void colsum3_kernel(Multi<Colsum3Args> mv) {
+struct ColsumMulti { Colsum3Args v[kMaxColsum]; };
+__global__ __launch_bounds__(512) void colsum3_kernel(ColsumMulti mv) {
   const Colsum3Args& a = mv.v[blockIdx.z];  // blockIdx.z = layer
   __shared__ float red[3][8][64];
   const int grp = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   if (grp >= a.groups || (int)blockIdx.x * 64 >= a.D) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (a.mode == 2) {   // a vector's sum (loss scalars), in the order policy_dist_fwd_kernel sums log-probs: 256 strided partial
+    float* r1 = &red[0][0][0];   // sums, then a halving tree (fused and un-fused chains agree to the bit)
+    if (threadIdx.x < 256) {
+      for (int r = threadIdx.x; r < a.rows_per_group; r += 256) s1 += a.dg[r];
+      r1[threadIdx.x] = s1;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) r1[threadIdx.x] += r1[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.o_beta[0] = r1[0];
+    return;
+  }
   if (col < a.D) {
     const long base = (long)grp * a.rows_per_group;
-    for (int r = part; r < a.rows_per_group; r += 8) {
-      const long e = (base + r) * a.D + col;
-      const float g = a.dg[e];
-      s0 += g * a.xhat[e];
-      s1 += g;
-      s2 += a.dpre[e];
+    if (a.mode == 1) {   // (four row phases combined as colsum_kernel combines them)
+      if (part < 4)
+        for (int r = part; r < a.rows_per_group; r += 4) s1 += a.dg[(base + r) * a.D + col];
+    } else {
+      for (int r = part; r < a.rows_per_group; r += 8) {
+        const long e = (base + r) * a.D + col;
+        const float g = a.dg[e];
+        s0 += g * a.xhat[e];
+        s1 += g;
+        s2 += a.dpre[e];
+      }
     }
   }
   red[0][part][threadIdx.x & 63] = s0;
   red[1][part][threadIdx.x & 63] = s1;
   red[2][part][threadIdx.x & 63] = s2;
   __syncthreads();
+  if (a.mode == 1) {
+    if (part == 1 && col < a.D) {
+      const int c = threadIdx.x & 63;
+      a.o_beta[(long)grp * a.gstride + col] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+    return;
+  }
   if (part < 3 && col < a.D) {
     const int c = threadIdx.x & 63;
     float t = 0.f;
@@ -705,22 +1056,22 @@ __global__ __launch_bounds__(512) void colsum3_kernel(Multi<Colsum3Args> mv) {
 }
 
 int colsum3_multi(const Colsum3Args* vs, int n, hipStream_t stream) {
-  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad layer count %d", n);
-  Multi<Colsum3Args> mv{};
+  SERL_REQUIRE(n >= 1 && n <= kMaxColsum, "bad layer count %d", n);
+  ColsumMulti mv{};
   int gx = 0, gy = 0;
   for (int i = 0; i < n; ++i) {
     mv.v[i] = vs[i];
     gx = std::max(gx, cdiv(vs[i].D, 64));
     gy = std::max(gy, vs[i].groups);
   }
-  hipLaunchKernelGGL(colsum3_kernel, dim3(gx, gy, n), dim3(512), 0, stream, mv);
+  SERL_LAUNCH_CHAIN(colsum3_kernel, dim3(gx, gy, n), dim3(512), 0, stream, mv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
 
 int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, int rows_per_group, int D,
             float* o_gamma, float* o_beta, float* o_bias, long gstride, hipStream_t stream) {
-  const Colsum3Args v{dg, xhat, dpre, groups, rows_per_group, D, o_gamma, o_beta, o_bias, gstride};
+  const Colsum3Args v{dg, xhat, dpre, groups, rows_per_group, D, o_gamma, o_beta, o_bias, gstride, 0};
   return colsum3_multi(&v, 1, stream);
 }
 
@@ -762,12 +1113,132 @@ int sle_fwd_multi(const SleFwdArgs* vs, int n, float keep_scale, int N, int HW, 
   SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
   Multi<SleFwdArgs> mv{};
   for (int i = 0; i < n; ++i) mv.v[i] = vs[i];
-  hipLaunchKernelGGL(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256), groups, n), dim3(256), 0, stream, mv, keep_scale, N,
+  SERL_LAUNCH_CHAIN(sle_fwd_kernel, dim3(cdiv((long)N * Cc, 256), groups, n), dim3(256), 0, stream, mv, keep_scale, N,
                      HW, Cc, x_gs, k_gs, mask_gs, f_gs);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
 
+
+// proprio branch (encoding.py:55-70) of ONE row by one wave, lane = output feature (also the body of proprio_fwd_kernel)
+__device__ __forceinline__ void proprio_row(const ProprioArgs& a, int S, int row, int lane) {
+  float v = a.b[lane];
+  for (int s0 = 0; s0 < S; s0 += 64) {  // the state row travels once, coalesced, and is broadcast lane by lane
+    const float mine = (s0 + lane < S) ? a.state[(long)row * S + s0 + lane] : 0.f;
+    const int cnt = min(64, S - s0);
+    int s = 0;
+    for (; s + 8 <= cnt; s += 8) {
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = a.W[(s0 + s + j) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += __shfl(mine, s + j) * w[j];
+    }
+    for (; s < cnt; ++s) v += __shfl(mine, s) * a.W[(s0 + s) * 64 + lane];
+  }
+  float s1 = v, s2 = v * v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  const float mean = s1 * (1.0f / 64), var = fmaxf(s2 * (1.0f / 64) - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-6f), xh = (v - mean) * rstd;
+  a.y[(long)row * a.ld_y + lane] = tanhf(xh * a.gamma[lane] + a.beta[lane]);
+  if (a.xhat) a.xhat[(long)row * 64 + lane] = xh;
+  if (a.rstd && lane == 0) a.rstd[row] = rstd;
+  // optional column copy riding along (the batch's actions into the critic input [enc | action])
+  if (a.copy_dst && lane < a.copy_cols) a.copy_dst[(long)row * a.ld_copy_dst + lane] = a.copy_src[(long)row * a.ld_copy_src + lane];
+}
+
+// SpatialLearnedEmbeddings, channel-blocked: a workgroup = 256 channels x kSleNb samples.  The embedding kernel K
+// ([HW][C][8]: 256 KB per camera at 4x4x512) is read ONCE per workgroup, four pixels at a time into registers, instead of
+// once per sample (round 3: 393 MB of L2 reads per update phase, 30 us alone / 160-190 us next to the trunk pass); every
+// sample's 8 outputs stay in registers across the pixel loop (same hw-ascending sum as before: bit-identical).  The Dropout(0.1)
+// keep-mask (resnet_v1.py:351), when not supplied, is hashed from (seed, camera, GLOBAL sample, channel): three 64-bit hashes
+// give the eight 24-bit uniforms of a thread's eight outputs -- no mask tensor, no gen_noise launch.  Workgroups past the SLE
+// range run the proprio branch of the same instance (camera 0 only): one launch instead of two.
+constexpr int kSleNb = 8;
+__global__ __launch_bounds__(256) void sle_proprio_fwd_kernel(Multi<SleFwdArgs> mv, Multi<ProprioArgs> pv, int has_proprio,
+                                                              float keep_scale, unsigned keep_thr, int N, int HW, int Cc,
+                                                              long xs, long ks, long ms, long fs, int S, int nb_sle) {
+  if ((int)blockIdx.x >= nb_sle) {
+    if (!has_proprio || blockIdx.y != 0) return;
+    const int row = ((int)blockIdx.x - nb_sle) * 4 + (threadIdx.x >> 6);
+    if (row < N) proprio_row(pv.v[blockIdx.z], S, row, threadIdx.x & 63);
+    return;
+  }
+  const SleFwdArgs& v = mv.v[blockIdx.z];  // blockIdx.z = instance, blockIdx.y = camera
+  const int cblocks = (Cc + 255) / 256;
+  const int c = ((int)blockIdx.x % cblocks) * 256 + threadIdx.x, n0 = ((int)blockIdx.x / cblocks) * kSleNb;
+  if (c >= Cc) return;
+  const float* x = v.x + blockIdx.y * xs + (long)n0 * HW * Cc + c;
+  const float* K = v.K + blockIdx.y * ks + (long)c * 8;
+  const int ns = min(kSleNb, N - n0);
+  float acc[kSleNb][8];
+#pragma unroll
+  for (int s = 0; s < kSleNb; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+  for (int hw0 = 0; hw0 < HW; hw0 += 4) {
+    float4 k0[4], k1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hw = min(hw0 + i, HW - 1);
+      k0[i] = *reinterpret_cast<const float4*>(K + (long)hw * Cc * 8);
+      k1[i] = *reinterpret_cast<const float4*>(K + (long)hw * Cc * 8 + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < kSleNb; ++s) {
+      if (s < ns) {
+        float xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = (hw0 + i < HW) ? x[((long)s * HW + hw0 + i) * Cc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (hw0 + i < HW) {   // (pixels past HW must not touch the sums: 0 * K would still round -0 / NaN cases differently)
+            acc[s][0] += xv[i] * k0[i].x; acc[s][1] += xv[i] * k0[i].y; acc[s][2] += xv[i] * k0[i].z; acc[s][3] += xv[i] * k0[i].w;
+            acc[s][4] += xv[i] * k1[i].x; acc[s][5] += xv[i] * k1[i].y; acc[s][6] += xv[i] * k1[i].z; acc[s][7] += xv[i] * k1[i].w;
+          }
+        }
+      }
+    }
+  }
+  float* f = v.f + blockIdx.y * fs + (long)n0 * Cc * 8 + (long)c * 8;
+  const uint8_t* mask = v.mask ? v.mask + blockIdx.y * ms + (long)n0 * Cc * 8 + (long)c * 8 : nullptr;
+#pragma unroll
+  for (int s = 0; s < kSleNb; ++s) {
+    if (s >= ns) break;
+    if (mask) {
+      const uint8_t* m = mask + (long)s * Cc * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[s][j] = m[j] ? acc[s][j] * keep_scale : 0.f;
+    } else if (v.gen) {
+      const uint64_t ctr = (((uint64_t)blockIdx.y * (uint64_t)v.rows_global + (uint64_t)(v.row_offset + n0 + s)) * (uint64_t)Cc + (uint64_t)c) * 3ull;
+      const uint64_t h0 = mix64(v.seed ^ mix64(ctr)), h1 = mix64(v.seed ^ mix64(ctr + 1)), h2 = mix64(v.seed ^ mix64(ctr + 2));
+      const unsigned u[8] = {(unsigned)(h0 & 0xFFFFFF), (unsigned)((h0 >> 24) & 0xFFFFFF), (unsigned)((h0 >> 48) | ((h1 & 0xFF) << 16)),
+                             (unsigned)((h1 >> 8) & 0xFFFFFF), (unsigned)((h1 >> 32) & 0xFFFFFF), (unsigned)((h1 >> 56) | ((h2 & 0xFFFF) << 8)),
+                             (unsigned)((h2 >> 16) & 0xFFFFFF), (unsigned)(h2 >> 40)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[s][j] = u[j] < keep_thr ? acc[s][j] * keep_scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(f + (long)s * Cc * 8) = make_float4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
+    *reinterpret_cast<float4*>(f + (long)s * Cc * 8 + 4) = make_float4(acc[s][4], acc[s][5], acc[s][6], acc[s][7]);
+  }
+}
+
+int sle_proprio_fwd_multi(const SleFwdArgs* vs, const ProprioArgs* ps, int n, float keep, int N, int HW, int Cc, int groups, long x_gs,
+                          long k_gs, long mask_gs, long f_gs, int state_dim, hipStream_t stream) {
+  SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
+  Multi<SleFwdArgs> mv{};
+  Multi<ProprioArgs> pv{};
+  for (int i = 0; i < n; ++i) {
+    mv.v[i] = vs[i];
+    if (ps) { pv.v[i] = ps[i]; SERL_REQUIRE(!ps[i].copy_dst || ps[i].copy_cols <= 64, "copy_cols > 64"); }
+  }
+  const int nb_sle = cdiv(Cc, 256) * cdiv(N, kSleNb), nb_prop = ps ? cdiv(N, 4) : 0;
+  SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
+                     1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
 
 // dK partial[split][hw][c][j] = sum_{n in split} x[n][hw][c] * df[n][c*8+j]
 __global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const float* df, float* partial, int N,
@@ -790,9 +1261,56 @@ __global__ __launch_bounds__(256) void sle_bwd_kernel(const float* x, const floa
   *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
+// the same partial sums, then the sum over the batch splits by the LAST workgroup to arrive at its (camera, pixel, channel
+// block) -- see "last-arriver epilogues" above: sc1 partial stores, drain, ticket; sc1 loads in split order on the reducer
+__global__ __launch_bounds__(256) void sle_bwd_fused_kernel(const float* x, const float* df, float* partial, int N, int HW, int Cc,
+                                                           int nsplit, long x_gs, long df_gs, long part_gs, float* out, long out_gs,
+                                                           int* ctr) {
+  __shared__ int s_last;
+  const int c = blockIdx.x * 256 + threadIdx.x, hw = blockIdx.y, sp = blockIdx.z % nsplit, grp = blockIdx.z / nsplit;
+  x += grp * x_gs; df += grp * df_gs; partial += grp * part_gs;  // grp = camera
+  const int per = (N + nsplit - 1) / nsplit;
+  const int nb = sp * per, ne = min(N, nb + per);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < Cc) {
+    for (int n = nb; n < ne; ++n) {
+      const float xv = x[((long)n * HW + hw) * Cc + c];
+      const float4 d0 = *reinterpret_cast<const float4*>(df + (long)n * Cc * 8 + (long)c * 8);
+      const float4 d1 = *reinterpret_cast<const float4*>(df + (long)n * Cc * 8 + (long)c * 8 + 4);
+      acc[0] += xv * d0.x; acc[1] += xv * d0.y; acc[2] += xv * d0.z; acc[3] += xv * d0.w;
+      acc[4] += xv * d1.x; acc[5] += xv * d1.y; acc[6] += xv * d1.z; acc[7] += xv * d1.w;
+    }
+    const __amdgpu_buffer_rsrc_t rs = rsrc_of(partial);
+    const long o = (((long)sp * HW + hw) * Cc + c) * 8;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){acc[0], acc[1], acc[2], acc[3]}), rs, (int)(o * 4), 0, kSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4){acc[4], acc[5], acc[6], acc[7]}), rs, (int)(o * 4 + 16), 0, kSc1);
+  }
+  if (!arrive_is_last(ctr + ((long)grp * HW + hw) * gridDim.x + blockIdx.x, nsplit, &s_last)) return;
+  if (c >= Cc) return;
+  const __amdgpu_buffer_rsrc_t rs = rsrc_of(partial);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s) {
+    const long o = (((long)s * HW + hw) * Cc + c) * 8;
+    s0 += ld_sc1(rs, o);
+    s1 += ld_sc1(rs, o + 4);
+  }
+  float* o = out + grp * out_gs + ((long)hw * Cc + c) * 8;
+  *reinterpret_cast<f32x4*>(o) = s0;
+  *reinterpret_cast<f32x4*>(o + 4) = s1;
+}
+
+int sle_bwd_fused(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
+                  long x_gs, long df_gs, long part_gs, float* out, long out_gs, int* ctr, hipStream_t stream) {
+  SERL_REQUIRE((long)nsplit * HW * Cc * 8 * 4 < (1L << 31), "SLE partial sums exceed 2 GB");
+  SERL_LAUNCH_CHAIN(sle_bwd_fused_kernel, dim3(cdiv(Cc, 256), HW, nsplit * groups), dim3(256), 0, stream, x, df, partial, N,
+                     HW, Cc, nsplit, x_gs, df_gs, part_gs, out, out_gs, ctr);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
+}
+
 int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int Cc, int nsplit, int groups,
             long x_gs, long df_gs, long part_gs, hipStream_t stream) {
-  hipLaunchKernelGGL(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit * groups), dim3(256), 0, stream, x, df, partial, N,
+  SERL_LAUNCH_CHAIN(sle_bwd_kernel, dim3(cdiv(Cc, 256), HW, nsplit * groups), dim3(256), 0, stream, x, df, partial, N,
                      HW, Cc, nsplit, x_gs, df_gs, part_gs);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
@@ -804,70 +1322,9 @@ int sle_bwd(const float* x, const float* df, float* partial, int N, int HW, int 
 //   scalars[0..2] = sum (Q-y)^2, sum Q, sum y   (local sums; the host / all-reduce normalises)
 //   dhead_b = sum dQ  (gradient of the shared head bias)
 // =============================================================================================
-__global__ __launch_bounds__(256) void critic_loss_kernel(const float* qt, const float* q, const float* reward,
-                                                         const float* mask, RedqSel sel, int E, int B,
-                                                         float discount, float inv_norm, float* y_out,
-                                                         float* dq, float* scalars, float* dbias, int per_member,
-                                                         const float* logp_next, const float* alpha) {
+__global__ __launch_bounds__(256) void critic_loss_kernel(LossArgs L) {
   __shared__ float red[4][256];
-  float s_d2 = 0.f, s_q = 0.f, s_y = 0.f, s_dq = 0.f;
-  float s_e[16];  // per-member sums of dQ (per_member: E <= 16)
-#pragma unroll
-  for (int e = 0; e < 16; ++e) s_e[e] = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    float mq;   // minimum over the selected (or all) target members (sac.py:150-161)
-    if (sel.n > 0) {
-      mq = qt[(long)sel.idx[0] * B + b];
-      for (int k = 1; k < sel.n; ++k) mq = fminf(mq, qt[(long)sel.idx[k] * B + b]);
-    } else {
-      mq = qt[b];
-      for (int e = 1; e < E; ++e) mq = fminf(mq, qt[(long)e * B + b]);
-    }
-    float y = reward[b] + discount * mask[b] * mq;
-    if (logp_next) y -= alpha[0] * logp_next[b];   // backup_entropy: outside the discount, as sac.py:174-176 has it
-    y_out[b] = y;
-    s_y += y;
-    for (int e = 0; e < E; ++e) {
-      const float qv = q[(long)e * B + b];
-      const float d = qv - y;
-      const float g = 2.f * d * inv_norm;
-      dq[(long)e * B + b] = g;
-      s_d2 += d * d;
-      s_q += qv;
-      s_dq += g;
-      if (per_member) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k == e) s_e[k] += g;
-      }
-    }
-  }
-  red[0][threadIdx.x] = s_d2; red[1][threadIdx.x] = s_q; red[2][threadIdx.x] = s_y; red[3][threadIdx.x] = s_dq;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o)
-      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    scalars[0] = red[0][0]; scalars[1] = red[1][0]; scalars[2] = red[2][0];
-    if (!per_member) *dbias = red[3][0];
-  }
-  if (per_member) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k < E) {  // (uniform)
-        __syncthreads();
-        red[0][threadIdx.x] = s_e[k];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-          if ((int)threadIdx.x < o) red[0][threadIdx.x] += red[0][threadIdx.x + o];
-          __syncthreads();
-        }
-        if (threadIdx.x == 0) dbias[k] = red[0][0];
-      }
-    }
-  }
+  critic_loss_body(L, red);
 }
 
 int critic_loss(const float* qt, const float* q, const float* reward, const float* mask, RedqSel sel, int E,
@@ -875,8 +1332,8 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
                 hipStream_t stream, bool per_member_bias, const float* logp_next, const float* alpha) {
   SERL_REQUIRE(!per_member_bias || E <= 16, "per-member head bias supports ensembles of at most 16 (got %d)", E);
   SERL_REQUIRE(sel.n >= 0 && sel.n <= 16, "critic_subsample_size %d not in [0, 16]", sel.n);
-  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, stream, qt, q, reward, mask, sel, E, B,
-                     discount, inv_norm, y_out, dq, scalars, dbias, per_member_bias ? 1 : 0, logp_next, alpha);
+  const LossArgs L{1, qt, q, reward, mask, sel, E, B, discount, inv_norm, y_out, dq, scalars, dbias, per_member_bias ? 1 : 0, logp_next, alpha};
+  SERL_LAUNCH_CHAIN(critic_loss_kernel, dim3(1), dim3(256), 0, stream, L);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -887,8 +1344,6 @@ int critic_loss(const float* qt, const float* q, const float* reward, const floa
 //   logp = sum_j(-eps^2/2 - log std - log(2pi)/2) - sum_j 2(log2 - u - softplus(-2u))
 // pre: [2][B][A] (mean slab, log_std slab; biases already added)
 // =============================================================================================
-__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-
 __global__ void policy_dist_fwd_kernel(Multi<PolicyDistArgs> mv, int B, int A, float std_min, float std_max) {
   const PolicyDistArgs& v = mv.v[blockIdx.x];  // one workgroup per instance
   __shared__ float red[256];
@@ -928,7 +1383,7 @@ int policy_dist_fwd_multi(const PolicyDistArgs* vs, int n, int B, int A, float s
   SERL_REQUIRE(n >= 1 && n <= kMaxMulti, "bad instance count %d", n);
   Multi<PolicyDistArgs> mv{};
   for (int i = 0; i < n; ++i) mv.v[i] = vs[i];
-  hipLaunchKernelGGL(policy_dist_fwd_kernel, dim3(n), dim3(256), 0, stream, mv, B, A, std_min, std_max);
+  SERL_LAUNCH_CHAIN(policy_dist_fwd_kernel, dim3(n), dim3(256), 0, stream, mv, B, A, std_min, std_max);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -937,33 +1392,8 @@ int policy_dist_fwd_multi(const PolicyDistArgs* vs, int n, int B, int A, float s
 // proprio branch (encoding.py:55-70): y = tanh(LayerNorm_1e-6(state W + b)), W [S][64]; one wave per row,
 // lane = output feature.  Replaces a GEMM + LN launch pair for this tiny layer.
 __global__ __launch_bounds__(256) void proprio_fwd_kernel(Multi<ProprioArgs> mv, int S, int rows) {
-  const ProprioArgs& a = mv.v[blockIdx.y];
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  float v = a.b[lane];
-  for (int s0 = 0; s0 < S; s0 += 64) {  // the state row travels once, coalesced, and is broadcast lane by lane
-    const float mine = (s0 + lane < S) ? a.state[(long)row * S + s0 + lane] : 0.f;
-    const int cnt = min(64, S - s0);
-    int s = 0;
-    for (; s + 8 <= cnt; s += 8) {
-      float w[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = a.W[(s0 + s + j) * 64 + lane];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v += __shfl(mine, s + j) * w[j];
-    }
-    for (; s < cnt; ++s) v += __shfl(mine, s) * a.W[(s0 + s) * 64 + lane];
-  }
-  float s1 = v, s2 = v * v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-  const float mean = s1 * (1.0f / 64), var = fmaxf(s2 * (1.0f / 64) - mean * mean, 0.f);
-  const float rstd = rsqrtf(var + 1e-6f), xh = (v - mean) * rstd;
-  a.y[(long)row * a.ld_y + lane] = tanhf(xh * a.gamma[lane] + a.beta[lane]);
-  if (a.xhat) a.xhat[(long)row * 64 + lane] = xh;
-  if (a.rstd && lane == 0) a.rstd[row] = rstd;
-  // optional column copy riding along (the batch's actions into the critic input [enc | action])
-  if (a.copy_dst && lane < a.copy_cols) a.copy_dst[(long)row * a.ld_copy_dst + lane] = a.copy_src[(long)row * a.ld_copy_src + lane];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < rows) proprio_row(mv.v[blockIdx.y], S, row, threadIdx.x & 63);
 }
 
 int proprio_fwd_multi(const ProprioArgs* vs, int n, int S, int rows, hipStream_t stream) {
@@ -973,7 +1403,7 @@ int proprio_fwd_multi(const ProprioArgs* vs, int n, int S, int rows, hipStream_t
     mv.v[i] = vs[i];
     SERL_REQUIRE(!vs[i].copy_dst || vs[i].copy_cols <= 64, "copy_cols > 64");
   }
-  hipLaunchKernelGGL(proprio_fwd_kernel, dim3(cdiv(rows, 4), n), dim3(256), 0, stream, mv, S, rows);
+  SERL_LAUNCH_CHAIN(proprio_fwd_kernel, dim3(cdiv(rows, 4), n), dim3(256), 0, stream, mv, S, rows);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1021,7 +1451,7 @@ int policy_dist_bwd(const float* da, long ld_da, const float* act, long ld_act, 
                     const float* stdv, const float* eps, const float* alpha, float coef, int B, int A,
                     float std_min, float std_max, float* dpre, const float* q, int E, float* qmean_out,
                     hipStream_t stream) {
-  hipLaunchKernelGGL(policy_dist_bwd_kernel, dim3(cdiv(B * A, 256) + 1), dim3(256), 0, stream, da, ld_da, act,
+  SERL_LAUNCH_CHAIN(policy_dist_bwd_kernel, dim3(cdiv(B * A, 256) + 1), dim3(256), 0, stream, da, ld_da, act,
                      ld_act, pre, stdv, eps, alpha, coef, B, A, std_min, std_max, dpre, q, E, qmean_out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
@@ -1040,7 +1470,7 @@ int copy_cols_multi(const CopyJob* jobs, int n, int rows, hipStream_t stream) {
   Multi<CopyJob> mv{};
   int cmax = 0;
   for (int i = 0; i < n; ++i) { mv.v[i] = jobs[i]; cmax = std::max(cmax, jobs[i].cols); }
-  hipLaunchKernelGGL(copy_cols_multi_kernel, dim3(cdiv((long)rows * cmax, 256), n), dim3(256), 0, stream, mv, rows);
+  SERL_LAUNCH_CHAIN(copy_cols_multi_kernel, dim3(cdiv((long)rows * cmax, 256), n), dim3(256), 0, stream, mv, rows);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1050,7 +1480,7 @@ __global__ void fill_kernel(float* p, float v, long n) {
   if (e < n) p[e] = v;
 }
 int fill(float* p, float v, long n, hipStream_t stream) {
-  hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, v, n);
+  SERL_LAUNCH_CHAIN(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, p, v, n);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1139,7 +1569,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
   ProfScope prof("adam_ema", stream);
   const bool frozen = a.n_frozen > 0 && (a.ema_on || a.wd_c != 0.f || a.wd_a != 0.f || a.wd_t != 0.f);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(cdiv(a.P + (frozen ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
+  SERL_LAUNCH_CHAIN(adam_ema_kernel, dim3(cdiv(a.P + (frozen ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1160,7 +1590,7 @@ __global__ __launch_bounds__(1024) void grad_norm2_kernel(const float* gc, long 
   if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
 }
 int grad_norm2(const float* g_critic, long nc, const float* g_actor, long na, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(grad_norm2_kernel, dim3(2), dim3(1024), 0, stream, g_critic, nc, g_actor, na, out);
+  SERL_LAUNCH_CHAIN(grad_norm2_kernel, dim3(2), dim3(1024), 0, stream, g_critic, nc, g_actor, na, out);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
@@ -1168,12 +1598,6 @@ int grad_norm2(const float* g_critic, long nc, const float* g_actor, long na, fl
 // =============================================================================================
 // device noise (production mode): counter-based hash -> N(0,1) and Bernoulli(keep) masks
 // =============================================================================================
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __device__ __forceinline__ void gen_one(const NoiseJob& j, long i0) {
   if (i0 >= j.n) return;
   long i = i0;  // position in the global tensor
@@ -1200,7 +1624,7 @@ int gen_noise_multi(const NoiseJob* vs, int n, hipStream_t stream) {
   Multi<NoiseJob> mv{};
   long nmax = 0;
   for (int i = 0; i < n; ++i) { mv.v[i] = vs[i]; nmax = std::max(nmax, vs[i].n); }
-  hipLaunchKernelGGL(gen_noise_kernel, dim3(cdiv(nmax, 256), n), dim3(256), 0, stream, mv);
+  SERL_LAUNCH_CHAIN(gen_noise_kernel, dim3(cdiv(nmax, 256), n), dim3(256), 0, stream, mv);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -74,6 +74,36 @@ int trunk_forward(const TrunkWeights& w, TrunkWorkspace& ws, const uint8_t* fram
 // --------------------------------------------------------------------------------------------
 // small dense building blocks (heads.hip)
 // --------------------------------------------------------------------------------------------
+// rows are grouped (group g = row / rows_per_group) and every group has its own bias/gamma/beta at
+// `pstride` floats apart; the pre-activation is bias + sum of S GEMM slabs laid out [g*S + s][local row][D]
+struct LnFwdArgs {
+  const float* slabs; int S; long slab_stride;
+  const float *bias, *gamma, *beta; long pstride;
+  int rows, rows_per_group;
+  float* y; long ld_y; long y_goff;  // y[local_row*ld_y + group*y_goff + col] (column slices / group blocks)
+  float* xhat;           // [rows][D] or nullptr
+  float* rstd;           // [rows] or nullptr
+  // optional fused row-dot (critic head, actor_critic_nets.py:65-73): dot_out[row] = sum_col y*dot_w + dot_b[0]
+  const float* dot_w; const float* dot_b; float* dot_out;
+  long dot_gstride, dot_b_gstride;  // 0: one head shared by all groups (DrQ critic); else per-group heads (ensemblized Critic)
+  int relu;              // 0: tanh (the MLPs / encoder heads); 1: ReLU (BinaryClassifier, reward_classifier.py:24-26)
+};
+// tanh-Gaussian policy head: slabs = raw head GEMM outputs (mean, log_std); biases added here, result kept in `pre`
+struct PolicyDistArgs {
+  const float* slabs; int S;  // head GEMM output [mean | log_std][S K-splits][B][A]
+  const float* bias_mean; const float* bias_ls; float* pre; const float* eps;
+  float* act; long ld_act; float* logp; float* std_out; float* sum_logp;
+  const float* lam; float* alpha_out;  // optional rider: alpha_out[0] = softplus(lam[0])
+  // fused form only (GemmDesc::epi == kEpiPolicy): eps == nullptr -> N(0,1) draws hashed from (seed, global row, j), kept in eps_out
+  float* eps_out; uint64_t seed; long row_offset;
+  int B, A; float std_min, std_max; long slab_ld, slab_stride;
+};
+
+// Epilogues of the update chain's GEMMs ("last-arriver" fusion, heads.hip): a launch boundary between a K-split GEMM and the
+// small kernel that consumed its slabs is replaced by an arrival counter per output tile -- every workgroup stores its slab
+// tile write-through (sc1), drains, bumps the tile's counter, and the workgroup that draws the last ticket reads the slabs back
+// (sc1 loads) IN INDEX ORDER and finishes the layer.  Same summation order as the separate kernels: bit-identical results.
+enum { kEpiNone = 0, kEpiReduce = 1, kEpiLn = 2, kEpiPolicy = 3 };
 struct GemmDesc {
   const float* A;
   const float* B;
@@ -92,6 +122,17 @@ struct GemmDesc {
   int gseg = 0, gkbias = 0;
   long gpitch = 0;
   int relu = 0;        // C = max(acc, 0) (splitk == 1 only)
+  // ---- last-arriver epilogue (see above).  The slabs C are then a PADDED scratch image: ldc % 64 == 0, whole 64x64 tiles.
+  int epi = kEpiNone;
+  int* ctr = nullptr;        // arrival counters of this GEMM (zero before the launch; the last arriver re-zeroes its counter)
+  // kEpiReduce: out[zg][m][n] = sum of the `zred` consecutive slabs z = zg*zred .. (one counter per 64x64 output tile)
+  int zred = 1;
+  float* out = nullptr; long ld_out = 0, out_gstride = 0;
+  // kEpiLn: one counter per (batch, 64-row tile); the last of its tiles_n * splitk workgroups applies bias + LayerNorm + tanh
+  // kEpiPolicy: one counter per 64-row tile; the last of its nbatch * splitk workgroups samples the tanh-Gaussian
+  union { LnFwdArgs ln; PolicyDistArgs pd; };
+  GemmDesc() : A(nullptr), B(nullptr), C(nullptr), M(0), N(0), K(0), sAm(0), sAk(0), sAb(0), sBk(0), sBn(0), sBb(0), ldc(0), sCz(0),
+               nbatch(0), splitk(0), ln{} {}
 };
 int gemm_f32(const GemmDesc& g, hipStream_t stream);
 

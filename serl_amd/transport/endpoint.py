@@ -171,9 +171,9 @@ class TrainerServer:
     `stop()`; `request_callback(type, payload) -> dict` answers the custom request types."""
 
     def __init__(self, config: TrainerConfig, request_callback: Optional[Callable[[str, dict], dict]] = None,
-                 transport: Optional[str] = None, bind_ip: str = "*"):
+                 transport: Optional[str] = None, bind_ip: str = "127.0.0.1"):
         """transport: "zmq" (TCP sockets; default) or "loopback" (in-process queues).  bind_ip: interface the two sockets
-        listen on ("*" = all, like agentlace).  TRUST MODEL: messages are pickles -- whoever can reach the port can
+        listen on -- "127.0.0.1" by default; "*" (all interfaces, what agentlace does) is an explicit opt-in.  TRUST MODEL: messages are pickles -- whoever can reach the port can
         execute code in the learner process (upstream agentlace has the same property); bind to a private interface or
         "127.0.0.1" unless the network is trusted."""
         self.config, self.request_callback = config, request_callback

@@ -83,17 +83,19 @@ def decompress(frame: bytes) -> bytes:
         raise RuntimeError("LZ4F_createDecompressionContext failed")
     try:
         src = C.create_string_buffer(frame, len(frame))
-        out, pos = [], 0
+        out, pos, rc = [], 0, 1
         chunk = C.create_string_buffer(1 << 20)
         while pos < len(frame):
             dn, sn = C.c_size_t(len(chunk)), C.c_size_t(len(frame) - pos)
             rc = lib.LZ4F_decompress(ctx, chunk, C.byref(dn), C.byref(src, pos), C.byref(sn), None)
             if lib.LZ4F_isError(rc):
                 raise ValueError("corrupt LZ4 frame")
-            out.append(chunk.raw[:dn.value])
+            out.append(C.string_at(chunk, dn.value))
             pos += sn.value
             if rc == 0 and sn.value == 0 and dn.value == 0:
                 break
+        if rc != 0:      # the decoder still expects input: the frame ends early
+            raise ValueError("truncated LZ4 frame")
         return b"".join(out)
     finally:
         lib.LZ4F_freeDecompressionContext(ctx)

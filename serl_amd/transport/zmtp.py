@@ -80,6 +80,8 @@ class _Peer:
         conn.sendall(_ready(sock_type))
         while True:                       # the peer's READY
             fl, body = self._read_frame_blocking()
+            if not body:
+                raise ZMTPError("empty command frame during the handshake")
             if fl & 4 and body[1:1 + body[0]] == b"READY":
                 props, p = {}, 1 + body[0]
                 while p < len(body):
@@ -138,6 +140,31 @@ class _Peer:
     def send(self, data: bytes, timeout: float) -> None:
         with self.slock:
             self._send(data, timeout)
+
+    def send_or_drop(self, data: bytes, budget: float = 0.05) -> bool:
+        """PUB semantics (libzmq never blocks a publisher: it drops WHOLE messages at the high-water mark): if the socket is
+        not writable right now the message is dropped and the stream stays intact; once the first byte of a frame is on the
+        wire the rest must follow within `budget` seconds, otherwise the subscriber's framing is beyond repair and the
+        connection is closed (the SUB side reconnects).  -> True if the message went out."""
+        with self.slock:
+            view, t0 = memoryview(data), None
+            while len(view):
+                try:
+                    n = self.conn.send(view)
+                    view = view[n:]
+                    if t0 is None:
+                        t0 = time.time()
+                except (BlockingIOError, InterruptedError):
+                    if t0 is None:
+                        return False                 # nothing sent yet: drop the whole message
+                    if time.time() - t0 > budget:
+                        self.close()                 # mid-frame stall: never leave a partial frame behind
+                        return False
+                    select.select([], [self.conn], [], 0.005)
+                except OSError:
+                    self.close()
+                    return False
+            return True
 
     def _send(self, data: bytes, timeout: float) -> None:
         view, t0 = memoryview(data), time.time()
@@ -236,10 +263,7 @@ class Socket:
             with self._lock:
                 targets = [p for p in self._peers if p.alive and any(bytes(data).startswith(s) for s in p.subs)]
             for p in targets:
-                try:
-                    p.send(body, timeout)
-                except ZMTPError:
-                    pass                     # a subscriber that went away is dropped, like libzmq does
+                p.send_or_drop(body)         # never blocks the learner; a stalled subscriber loses whole messages or the link
             return
         if self.type == REQ:
             if self._awaiting_reply:
@@ -358,8 +382,8 @@ class Socket:
                 except (BlockingIOError, InterruptedError, OSError):
                     break
                 try:
-                    self._add_peer(_Peer(c, self.type, 5.0))
-                except (ZMTPError, OSError):
+                    self._add_peer(_Peer(c, self.type, 1.0))
+                except Exception:    # noqa: BLE001 -- silent / malformed / half-open connections: close, never leak the socket
                     c.close()
         with self._cv:
             n0 = len(self._inbox)

@@ -169,3 +169,65 @@ def test_client_without_a_server_times_out_cleanly():
     else:
         raise AssertionError("handshake without a server must fail")
     assert time.time() - t0 < 10
+
+
+def test_pub_never_blocks_on_a_stalled_subscriber_and_never_tears_a_frame():
+    """a subscriber that stops reading must cost the publisher whole messages (or the link), never 30 s per
+    send and never a partial frame followed by the next message (zmtp.py PUB path; libzmq drops at the high-water mark)."""
+    from serl_amd.transport import zmtp
+    pub = zmtp.Socket(zmtp.PUB)
+    port, _ = _free_ports()
+    pub.bind(f"tcp://127.0.0.1:{port}")
+    raw = socket.create_connection(("127.0.0.1", port))          # a hand-made SUB that subscribes and then never reads again
+    raw.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4096)
+    raw.sendall(zmtp._GREETING)
+    raw.sendall(zmtp._ready(zmtp.SUB))
+    raw.sendall(zmtp._frame(b"\x01"))                             # ZMTP 3.0 subscription message: subscribe to everything
+    deadline = time.time() + 5
+    while time.time() < deadline and not any(p.subs for p in pub._peers):
+        time.sleep(0.02)
+    assert any(p.subs for p in pub._peers), "the subscription did not arrive"
+    payload = b"x" * (1 << 20)
+    t0 = time.time()
+    for _ in range(64):                                           # 64 MB into a socket nobody drains
+        pub.send(payload)
+    dt = time.time() - t0
+    assert dt < 5.0, f"publisher blocked for {dt:.1f} s on a stalled subscriber"
+    # whatever reached the wire is whole frames: 0xFF-free framing check by parsing everything that can be read
+    raw.settimeout(0.5)
+    buf = bytearray()
+    try:
+        while True:
+            chunk = raw.recv(1 << 20)
+            if not chunk:
+                break
+            buf += chunk
+    except (socket.timeout, OSError):
+        pass
+    buf = buf[64:]                                                 # the publisher's greeting
+    n_msgs, torn = 0, False
+    while len(buf) >= 2:
+        fl = buf[0]
+        size, hdr = (int.from_bytes(buf[1:9], "big"), 9) if fl & 2 else (buf[1], 2)
+        if len(buf) < hdr + size:
+            torn = True                                            # a partial frame is only legal as the LAST thing on a closed link
+            break
+        if not fl & 4:
+            assert bytes(buf[hdr:hdr + size]) == payload
+            n_msgs += 1
+        del buf[:hdr + size]
+    assert not torn or not any(p.alive for p in pub._peers), "a partial frame was left on a live connection"
+    pub.close()
+    raw.close()
+
+
+def test_truncated_lz4_frame_is_an_error():
+    from serl_amd.transport import lz4frame
+    if lz4frame._load() is None:
+        import pytest
+        pytest.skip("liblz4 is not loadable here")
+    frame = lz4frame.compress(bytes(range(256)) * 400)
+    assert lz4frame.decompress(frame) == bytes(range(256)) * 400
+    import pytest
+    with pytest.raises(ValueError):
+        lz4frame.decompress(frame[:len(frame) // 2])
