@@ -97,6 +97,10 @@ struct serl_agent {
   // launches that feed them, the critic loss rides on the LayerNorm backward that consumes dQ, noise is hashed where it is used.
   // SERL_CHAIN_FUSE=0 restores one launch per operation (A/B timing; the fused path is bit-identical on identical noise).
   bool fuse = true;
+  // fused chain, opt-in (SERL_CHAIN_LN_EPI=1): LayerNorm + tanh inside the GEMM launch too (38 instead of 48 launches per
+  // critic + actor pair).  Measured SLOWER in every schedule (profiles/README.md round 4): the last arriver of a 64-row tile
+  // normalises 64 rows on four waves while the separate LayerNorm launch spreads the same rows over the whole chip.
+  bool ln_epi = false;
   int* ctr = nullptr;   // arrival counters: kCtrLanes ranges of kCtrPerLane (zero between launches)
   float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
   static constexpr int kSlots = 3;                                  // pipelined update batches in flight (see serl_mi355.h)
@@ -118,6 +122,11 @@ struct serl_agent {
   // batch of the current update (caller-owned device memory)
   serl_batch cur{};
   bool has_batch = false;
+  // The target copy of the FROZEN trunk takes an EMA step per critic update like every other leaf (common.py:124-134), but no
+  // gradient or weight decay ever reaches those leaves (adamw is refused on pixel agents), so the steps are only counted here
+  // and applied in one pass (frozen_ema: the same rounding sequence) when somebody reads or overwrites the trunk's target
+  // leaves -- 59 MB less HBM traffic per critic step.
+  int64_t trunk_ema_pending = 0;
   // optimizer bookkeeping
   int64_t step = 0;
   uint64_t noise_ctr = 0;
@@ -376,8 +385,7 @@ size_t carve(serl_agent* a, void* base) {
 // K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
-int split_for(int M, int N, int groups, int smax) {
-  constexpr long budget = 512;
+int split_for(int M, int N, int groups, int smax, long budget = 512) {
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -417,7 +425,8 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   GemmDesc gd[3];
   LnFwdArgs lv[3];
   ProprioArgs pv[3];
-  const int S = split_for(cnt, c.bottleneck, c.n_cam * n, 32);  // K = 4096: up to 32 slices of 128
+  static const long enc_budget = []() { const char* e = getenv("SERL_ENC_SPLIT_BUDGET"); return e ? atol(e) : 512L; }();
+  const int S = split_for(cnt, c.bottleneck, c.n_cam * n, 32, enc_budget);  // K = 4096: up to 32 slices of 128
   for (int i = 0; i < n; ++i) {
     const EncJob& j = jobs[i];
     EncBuf& e = *j.e;
@@ -449,7 +458,14 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       pr.copy_cols = c.act_dim;
     }
   }
-  if (a->fuse) {   // LayerNorm + tanh by the last-arriving workgroup of every 64-row tile of the bottleneck GEMM (heads.hip)
+  const bool ln_epi = a->fuse && a->ln_epi;
+  if (a->fuse) {
+    for (int i = 0; i < n; ++i) {
+      sv[i].gen = jobs[i].gen_mask; sv[i].seed = jobs[i].mask_seed;
+      sv[i].row_offset = a->shard_off + off; sv[i].rows_global = a->shard_global ? a->shard_global : Bfull;
+    }
+  }
+  if (ln_epi) {   // LayerNorm + tanh by the last-arriving workgroup of every 64-row tile of the bottleneck GEMM (heads.hip)
     SERL_REQUIRE((long)c.n_cam * cdiv(cnt, 64) <= kCtrPerLane && (long)c.n_cam * S * pad64(cnt) * c.bottleneck <= a->slabs_cap,
                  "encoder GEMM exceeds the fused epilogue's scratch");
     for (int i = 0; i < n; ++i) {
@@ -458,8 +474,6 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       g.epi = kEpiLn; g.ctr = a->ctr + (long)i * kCtrPerLane;
       g.ln = lv[i];
       g.ln.slab_stride = g.sCz;
-      sv[i].gen = jobs[i].gen_mask; sv[i].seed = jobs[i].mask_seed;
-      sv[i].row_offset = a->shard_off + off; sv[i].rows_global = a->shard_global ? a->shard_global : Bfull;
     }
   }
   if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
@@ -477,8 +491,8 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
                      Bfull * a->D, (long)c.batch * a->D, st));
   }
   RC(gemm_f32_multi(gd, n, st));
-  if (a->fuse) return a->small ? proprio_fwd_multi(pv, n, c.state_dim, cnt, st) : SERL_OK;
-  RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
+  if (!ln_epi) RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
+  if (a->fuse && !a->small) return SERL_OK;   // (the proprio branch rode on the SLE launch)
   return proprio_fwd_multi(pv, n, c.state_dim, cnt, st);
 }
 
@@ -517,7 +531,7 @@ int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, 
     l.dot_w = j.dot_w; l.dot_b = j.dot_b; l.dot_out = j.dot_out;
     l.dot_gstride = j.dot_gstride; l.dot_b_gstride = j.dot_b_gstride;
   }
-  if (a->fuse) {
+  if (a->fuse && a->ln_epi) {
     SERL_REQUIRE((long)groups * cdiv(rows_per_group, 64) <= kCtrPerLane && (long)groups * splitk * pad64(rows_per_group) * Hd <= a->slabs_cap,
                  "Dense layer exceeds the fused epilogue's scratch");
     for (int i = 0; i < n; ++i) {
@@ -937,6 +951,7 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   serl_agent* a = new serl_agent();
   a->cfg = *cfg;
   { const char* e = getenv("SERL_CHAIN_FUSE"); a->fuse = !(e && e[0] == '0'); }
+  { const char* e = getenv("SERL_CHAIN_LN_EPI"); a->ln_epi = e && e[0] == '1'; }
   build_layout(a);
   const size_t bytes = carve(a, nullptr);
   hipError_t e = hipMalloc(&a->arena, bytes);
@@ -972,6 +987,15 @@ int serl_agent_leaf_info(serl_agent* a, int i, char* name_out, int name_cap, int
   const Leaf& l = i < nt ? a->theta_leaves[i] : a->trunk_leaves[i - nt];
   snprintf(name_out, name_cap, "%s", l.name.c_str());
   *count = l.count;
+  return SERL_OK;
+}
+
+static int flush_trunk_ema(serl_agent* a) {
+  if (a->trunk_ema_pending > 0 && a->trunk_count > 0) {
+    RC(frozen_ema(a->trunk, a->trunk_t, a->trunk_count, a->cfg.tau, a->trunk_ema_pending, nullptr));
+    SERL_HIP(hipDeviceSynchronize());
+  }
+  a->trunk_ema_pending = 0;
   return SERL_OK;
 }
 
@@ -1013,6 +1037,7 @@ int serl_agent_set(serl_agent* a, const char* section, const char* leaf, const f
   int rc = resolve(a, section, leaf, &p, &n, &zero);
   if (rc) return rc;
   SERL_REQUIRE(n == count, "leaf '%s' has %ld elements, got %lld", leaf, n, (long long)count);
+  if (std::strncmp(leaf, "trunk/", 6) == 0) { SERL_HIP(hipDeviceSynchronize()); RC(flush_trunk_ema(a)); }   // pending EMA steps belong to the old values
   if (zero) {
     for (long i = 0; i < n; ++i)
       SERL_REQUIRE(host[i] == 0.0f, "'%s' of '%s' lies outside the optimizer's support and must be zero", section, leaf);
@@ -1032,6 +1057,7 @@ int serl_agent_get(serl_agent* a, const char* section, const char* leaf, float* 
   SERL_REQUIRE(n == count, "leaf '%s' has %ld elements, got %lld", leaf, n, (long long)count);
   if (zero) { std::memset(host_out, 0, sizeof(float) * n); return SERL_OK; }
   SERL_HIP(hipDeviceSynchronize());
+  if (std::strncmp(leaf, "trunk/", 6) == 0 && std::strcmp(section, "target_params") == 0) RC(flush_trunk_ema(a));
   SERL_HIP(hipMemcpy(host_out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
   return SERL_OK;
 }
@@ -1360,6 +1386,11 @@ int serl_agent_apply(serl_agent* a, int which, float info_weight, void* stream) 
   ad.tau = c.tau; ad.target_entropy = c.target_entropy;
   ad.inv_batch = a->last_global > 0 ? 1.0f / (float)a->last_global : 0.f;
   ad.frozen = a->trunk; ad.frozen_target = a->trunk_t; ad.n_frozen = a->trunk_count;  // common.py:124-134 covers every leaf
+  const bool any_wd = c.tx_weight_decay_on[SERL_TX_ACTOR] || c.tx_weight_decay_on[SERL_TX_CRITIC] || c.tx_weight_decay_on[SERL_TX_TEMPERATURE];
+  if (!any_wd && a->trunk_count > 0) {   // frozen leaves only ever see the EMA: count the step, apply it lazily (flush_trunk_ema)
+    ad.n_frozen = 0;
+    if (crit) a->trunk_ema_pending += 1;
+  }
   ad.wd_a = c.tx_weight_decay_on[SERL_TX_ACTOR] ? c.tx_weight_decay[SERL_TX_ACTOR] : 0.f;
   ad.wd_c = c.tx_weight_decay_on[SERL_TX_CRITIC] ? c.tx_weight_decay[SERL_TX_CRITIC] : 0.f;
   ad.wd_t = c.tx_weight_decay_on[SERL_TX_TEMPERATURE] ? c.tx_weight_decay[SERL_TX_TEMPERATURE] : 0.f;

@@ -122,6 +122,8 @@ struct AdamArgs {
   float info_w, inv_eb;
 };
 int adam_ema(const AdamArgs& a, hipStream_t stream);
+// `steps` target-EMA steps of frozen leaves in one pass (exactly the values `steps` adam_ema launches would have left)
+int frozen_ema(const float* frozen, float* frozen_target, long n, float tau, long steps, hipStream_t stream);
 // out[0] = sum g_critic^2 over [0, nc), out[1] = sum g_actor^2 over [0, na) (deterministic single-block reduction)
 int grad_norm2(const float* g_critic, long nc, const float* g_actor, long na, float* out, hipStream_t stream);
 // kind 0: N(0,1) f32, 1: keep-mask u8.  The tensor is [planes][rows_local][row_elems]; the value of an element is a

@@ -244,6 +244,84 @@ __device__ __forceinline__ void ln_tanh_row256(const LnFwdArgs& a, int row, int 
   }
 }
 
+// The reducer's form of ln_tanh_row256: a wave owns rows row0, row0 + 4, ... (R of them per pass) and keeps the slab loads of
+// ALL of them in flight -- one memory round trip per slab index instead of one per row (a dependent sc1 read costs 1-3 us next
+// to the trunk pass; 16 rows one after the other made the fused GEMMs 35 us longer than GEMM + LayerNorm launch together).
+// Same arithmetic, same order per row as ln_tanh_row256.
+template <int R>
+__device__ __forceinline__ void ln_tanh_rows_live(const LnFwdArgs& a, int grp, int lrow0, int lrow_end, int lane) {
+  constexpr int D = 256;
+  const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.slabs);
+  const long gbase = (long)grp * a.S * a.slab_stride + lane * 4;
+  const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long)grp * a.pstride + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 ga = *reinterpret_cast<const float4*>(a.gamma + (long)grp * a.pstride + lane * 4);
+  const float4 be = *reinterpret_cast<const float4*>(a.beta + (long)grp * a.pstride + lane * 4);
+  float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.dot_out) dw = *reinterpret_cast<const float4*>(a.dot_w + (long)grp * a.dot_gstride + lane * 4);
+  f32x4 acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc[i] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+  for (int s = 0; s < a.S; ++s) {
+    f32x4 x[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int lr = min(lrow0 + 4 * i, lrow_end - 1);   // (rows past the end re-read the last row; never stored)
+      x[i] = ld_sc1(rs, gbase + (long)s * a.slab_stride + (long)lr * D);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] += x[i];
+  }
+  float s1[R], s2[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[i] += acc[i][j]; s2[i] += acc[i][j] * acc[i][j]; }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) { s1[i] += __shfl_xor(s1[i], off); s2[i] += __shfl_xor(s2[i], off); }
+  }
+  float d[R];
+  const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w}, dwv[4] = {dw.x, dw.y, dw.z, dw.w};
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int lr = lrow0 + 4 * i;
+    const float mean = s1[i] * (1.0f / D), mean2 = s2[i] * (1.0f / D);
+    const float var = fmaxf(mean2 - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + 1e-6f);
+    d[i] = 0.f;
+    f32x4 xh4, y4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (acc[i][j] - mean) * rstd;
+      const float pre = xh * gam[j] + bet[j];
+      const float y = a.relu ? fmaxf(pre, 0.f) : tanhf(pre);
+      xh4[j] = xh; y4[j] = y;
+      d[i] += y * dwv[j];
+    }
+    if (lr < lrow_end) {
+      const long row = (long)grp * a.rows_per_group + lr;
+      *reinterpret_cast<f32x4u*>(a.y + (long)lr * a.ld_y + (long)grp * a.y_goff + lane * 4) = y4;
+      if (a.xhat) *reinterpret_cast<f32x4*>(a.xhat + row * D + lane * 4) = xh4;
+      if (a.rstd && lane == 0) a.rstd[row] = rstd;
+    }
+  }
+  if (a.dot_out) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) d[i] += __shfl_xor(d[i], off);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int lr = lrow0 + 4 * i;
+      if (lane == 0 && lr < lrow_end) a.dot_out[(long)grp * a.rows_per_group + lr] = d[i] + a.dot_b[(long)grp * a.dot_b_gstride];
+    }
+  }
+}
+
 // tanh-Gaussian head of rows [r0, r1) from the head GEMM's slabs (actor_critic_nets.py:179-272): one thread per (row, action)
 template <bool LIVE>
 __device__ __forceinline__ void policy_dist_rows(const PolicyDistArgs& v, int r0, int r1, int tid, int nthreads) {
@@ -284,7 +362,10 @@ __device__ __forceinline__ void policy_logp_rows(const PolicyDistArgs& v, int r0
   }
 }
 
-// the epilogue proper; `lds` = the kernel's operand LDS (>= kEpiScratch floats + 1 int), idle after the K loop
+// the epilogue proper; `lds` = the kernel's operand LDS (>= kEpiScratch floats + 1 int), idle after the K loop.
+// WITH_LN: the LayerNorm reducer keeps 8 rows of slabs in flight per wave (~140 VGPRs); the GEMM instantiations that never run
+// it (backward / weight-gradient launches) are compiled without it and keep their ~40-VGPR footprint.
+template <bool WITH_LN>
 __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& acc, float* C, int z, int batch, int m0, int n0,
                                               float* lds, int tid) {
   store_tile_sc1(C, g.ldc, m0, n0, acc, lds, tid);
@@ -307,9 +388,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& a
       else for (int j = 0; j < g.N - n; ++j) o[j] = sum[j];
     }
   } else if (g.epi == kEpiLn) {
+    if (!WITH_LN) __builtin_trap();   // (the host picks the instantiation: cannot happen)
     if (!arrive_is_last(g.ctr + (long)batch * tiles_m + blockIdx.y, tiles_n * g.splitk, flag)) return;
     const int r_end = min(m0 + kGBM, g.M);
-    for (int r = m0 + wave; r < r_end; r += 4) ln_tanh_row256<true>(g.ln, batch * g.ln.rows_per_group + r, lane);
+    if (WITH_LN)
+      for (int r = m0 + wave; r < r_end; r += 32) ln_tanh_rows_live<8>(g.ln, batch, r, r_end, lane);
   } else {   // kEpiPolicy
     if (!arrive_is_last(g.ctr + blockIdx.y, g.nbatch * g.splitk * tiles_n, flag)) return;
     const int r_end = min(m0 + kGBM, g.M);
@@ -328,7 +411,7 @@ struct GemmMulti {
   int n;
 };
 
-template <bool A_KFAST, bool B_KFAST>
+template <bool A_KFAST, bool B_KFAST, bool WITH_LN = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
   static_assert(2 * kGTile >= kEpiScratch + 4, "the epilogue's transpose scratch lives in the operand LDS");
   __shared__ __attribute__((aligned(16))) float ABf[2 * kGTile];
@@ -373,7 +456,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
       __syncthreads();
     }
   }
-  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, As, tid); return; }
+  if (g.epi) { gemm_epilogue<WITH_LN>(g, acc, C, z, batch, m0, n0, As, tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -423,13 +506,14 @@ __device__ __forceinline__ void split3(float v, float w, unsigned& p0, unsigned&
 
 // One operand tile of 64 rows x BK k's per chunk.  KFAST: 16-byte global vectors along k (BK / 16 per thread); otherwise
 // BK / 4 coalesced 4-byte loads per thread: tile row tid & 63, k's (BK / 4) * (tid >> 6) + j.
-template <bool KFAST, int BK>
+template <bool KFAST, int BK, bool GATHER = false>
 struct XLoader {
   static constexpr int NV = KFAST ? BK / 16 : 1;   // global vectors per thread (KFAST)
   static constexpr int NE = BK / 4;                // floats per thread per chunk
   static constexpr int kPlane = kGBM * BK * 2;     // bytes of one bf16 plane
   const float* p[NV];
   int ok[NV];   // this thread's row exists
+  const float* safe = nullptr;   // the operand's first element: where loads of non-existent rows / k's are redirected
   long sK;
   int row0, kq;   // !KFAST: tile row of this thread, first k of its group
   // gather mode (GemmDesc::gtab): the operand is a virtual im2col matrix
@@ -462,6 +546,7 @@ struct XLoader {
   }
   __device__ __forceinline__ void init(const float* X, long sR, long sK_, int r0, int R, int k_begin, int tid) {
     sK = sK_;
+    safe = X;
     if (KFAST) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -477,7 +562,7 @@ struct XLoader {
   }
   // the chunk starting at k0 (elements at k >= k_end are zero); advances to the next chunk
   __device__ __forceinline__ void load(float (&r)[NE], int k0, int k_end) {
-    if (tab && KFAST) {   // gather, forward: a chunk lies inside one kernel row (gseg % BK == 0) or is the bias chunk
+    if (GATHER && tab && KFAST) {   // gather, forward: a chunk lies inside one kernel row (gseg % BK == 0) or is the bias chunk
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int k = k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4));
@@ -492,24 +577,45 @@ struct XLoader {
 #pragma unroll
         for (int i = 0; i < NV; ++i) p[i] += gpitch - gseg;
       }
-    } else if (tab) {     // gather, weight gradient: k runs over the im2col rows
+    } else if (GATHER && tab) {     // gather, weight gradient: k runs over the im2col rows
 #pragma unroll
       for (int j = 0; j < NE; ++j) {
         const int k = k0 + kq + j;
         r[j] = (ok[0] && k < k_end) ? (bias_row ? 1.0f : p[0][tab[k]]) : 0.f;
       }
     } else if (KFAST) {
+      // BRANCH-FREE and UNTOUCHED: the load is always issued (a vector that lies outside the operand is redirected to the
+      // operand's first element) and the raw registers are left alone until store() zeroes the invalid elements -- two chunks
+      // later.  With the loads inside exec-masked branches (round 3), or with the zeroing selects right behind them, hipcc
+      // waits vmcnt(0) in the same iteration and the "prefetch" is synchronous: ~1 us per 16-wide chunk, matrix pipe 10 % busy.
+      // A partially valid vector (K % 4 != 0) reads up to 12 bytes past its row: inside the next row or the 256-byte padding
+      // every arena buffer ends with.
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int krem = k_end - (k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4)));
-        const f32x4 v = ld4(p[i], ok[i] ? krem : 0);
+        const f32x4 v = *reinterpret_cast<const f32x4u*>((ok[i] && krem > 0) ? p[i] : safe);
         r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
         p[i] += BK;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NE; ++j) r[j] = (ok[0] && k0 + kq + j < k_end) ? p[0][(long)j * sK] : 0.f;
+      for (int j = 0; j < NE; ++j) r[j] = *((ok[0] && k0 + kq + j < k_end) ? p[0] + (long)j * sK : safe);
       p[0] += (long)BK * sK;
+    }
+  }
+  // zeroes the elements of chunk k0 that do not exist (rows past the operand, k >= k_end); gather loads arrive clean
+  __device__ __forceinline__ void clean(float (&r)[NE], int k0, int k_end) const {
+    if (GATHER && tab) return;
+    if (KFAST) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int krem = ok[i] ? k_end - (k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4))) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[4 * i + j] = krem > j ? r[4 * i + j] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) r[j] = (ok[0] && k0 + kq + j < k_end) ? r[j] : 0.f;
     }
   }
   __device__ __forceinline__ void store(uint8_t* S, const float (&r)[NE], int tid) const {
@@ -548,7 +654,9 @@ struct XLoader {
 // BK = 16: 12 KB of LDS per workgroup -- the update chain's GEMMs run BESIDE the frozen trunk of the next batch, whose
 // conv workgroups own 131-152 KB of a CU's 160 KB: a 12 KB workgroup fits next to two row-slab (140 KB) or two LDS-DMA
 // (131 KB) conv workgroups instead of waiting for one of them to retire and taking its place.
-template <bool A_KFAST, bool B_KFAST, int BK>
+// GATHER: the SmallEncoder's implicit-GEMM operand (GemmDesc::gtab) is compiled in -- a separate instantiation, because a
+// run-time "gather or not" inside the chunk loop makes every loaded value a phi and hipcc then waits right behind each load
+template <bool A_KFAST, bool B_KFAST, int BK, bool WITH_LN = false, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   constexpr int kPlane = kGBM * BK * 2;
   static_assert(6 * kPlane >= (kEpiScratch + 4) * 4, "the epilogue's transpose scratch lives in the operand LDS");
@@ -571,41 +679,52 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int li = lane & 31, lh = lane >> 5;
   if (k_begin < k_end) {
-    XLoader<A_KFAST, BK> la;
+    XLoader<A_KFAST, BK, GATHER> la;
     XLoader<B_KFAST, BK> lb;
-    if (g.gtab) la.init_gather(g, batch, m0, g.M, k_begin, tid);
+    if (GATHER && g.gtab) la.init_gather(g, batch, m0, g.M, k_begin, tid);
     else la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
     lb.init(g.B + (long)batch * g.sBb, g.sBn, g.sBk, n0, g.N, k_begin, tid);
-    float ra[BK / 4], rb[BK / 4];
-    la.load(ra, k_begin, k_end);
-    lb.load(rb, k_begin, k_end);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      la.store(As, ra, tid);
-      lb.store(Bs, rb, tid);
-      __syncthreads();
-      la.load(ra, k0 + BK, k_end);  // past k_end: zeros, nothing is dereferenced
-      lb.load(rb, k0 + BK, k_end);
+    // TWO chunks in flight (register sets 0 / 1): a chunk is 4 KB per operand, its MFMAs take ~0.2 us, an L2 / Infinity-Cache
+    // round trip next to the trunk pass 1-2 us -- one chunk of look-ahead left the K = 4096 bottleneck GEMM at ~1 us per chunk
+    float ra[2][BK / 4], rb[2][BK / 4];
+    la.load(ra[0], k_begin, k_end);
+    lb.load(rb[0], k_begin, k_end);
+    la.load(ra[1], k_begin + BK, k_end);  // past k_end: zeros, nothing is dereferenced
+    lb.load(rb[1], k_begin + BK, k_end);
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int ao = xswz<BK>(wm * 32 + li, 2 * ks + lh), bo = xswz<BK>(wn * 32 + li, 2 * ks + lh);
-        bf16x8 a[3], b[3];
+      for (int h = 0; h < 2; ++h) {
+        const int kk = k0 + h * BK;
+        if (kk >= k_end) break;   // (uniform)
+        la.clean(ra[h], kk, k_end);
+        lb.clean(rb[h], kk, k_end);
+        la.store(As, ra[h], tid);
+        lb.store(Bs, rb[h], tid);
+        __syncthreads();
+        la.load(ra[h], kk + 2 * BK, k_end);
+        lb.load(rb[h], kk + 2 * BK, k_end);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          a[pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + ao);
-          b[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + bo);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          const int ao = xswz<BK>(wm * 32 + li, 2 * ks + lh), bo = xswz<BK>(wn * 32 + li, 2 * ks + lh);
+          bf16x8 a[3], b[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            a[pl] = *reinterpret_cast<const bf16x8*>(As + pl * kPlane + ao);
+            b[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * kPlane + bo);
+          }
+          // smallest terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
         }
-        // smallest terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
-  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, reinterpret_cast<float*>(AB), tid); return; }
+  if (g.epi) { gemm_epilogue<WITH_LN>(g, acc, C, z, batch, m0, n0, reinterpret_cast<float*>(AB), tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -685,14 +804,28 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   dim3 grid(gx, gy, z);
   // SERL_GEMM=f32: the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) instead of bf16x3 -- A/B timing and parity runs
   static const bool exact = []() { const char* e = getenv("SERL_GEMM"); return e && e[0] == 'f'; }();
+  bool with_ln = false, any_epi = false;
+  for (int i = 0; i < n; ++i) { with_ln = with_ln || gs[i].epi == kEpiLn; any_epi = any_epi || gs[i].epi != kEpiNone; }
+  SERL_REQUIRE(!any_epi || vec, "epilogue GEMMs need a vector layout");
+  // (the forward layers -- the only LayerNorm epilogues -- are A k-contiguous, B n-contiguous)
+  SERL_REQUIRE(!with_ln || (a_k && !b_k), "LayerNorm epilogue on an unexpected operand layout");
   if (vec && (!exact || gather)) {   // BK = 16 (12 KB of LDS); BK = 32 (24 KB) was measured 30 us per step slower next to the trunk pass
-
-    if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
+    bool any_tab = false;
+    for (int i = 0; i < n; ++i) any_tab = any_tab || gs[i].gtab != nullptr;
+    SERL_REQUIRE(!(any_tab && with_ln), "gather GEMM with a LayerNorm epilogue");
+    if (any_tab) {
+      if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16, false, true>), grid, dim3(256), 0, stream, mm);
+      else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, false, true>), grid, dim3(256), 0, stream, mm);
+      else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16, false, true>), grid, dim3(256), 0, stream, mm);
+      else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16, false, true>), grid, dim3(256), 0, stream, mm);
+    } else if (with_ln) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, true>), grid, dim3(256), 0, stream, mm);
+    else if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
     else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);
     else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16>), grid, dim3(256), 0, stream, mm);
     else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16>), grid, dim3(256), 0, stream, mm);
   } else if (vec) {
-    if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
+    if (with_ln) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, stream, mm);
+    else if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
     else if (a_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
     else if (b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);
     else SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, mm);
@@ -1185,18 +1318,20 @@ __global__ __launch_bounds__(256) void sle_proprio_fwd_kernel(Multi<SleFwdArgs> 
       k0[i] = *reinterpret_cast<const float4*>(K + (long)hw * Cc * 8);
       k1[i] = *reinterpret_cast<const float4*>(K + (long)hw * Cc * 8 + 4);
     }
+    // (no branch on the sample count: samples past the end re-read the last one and are never stored -- a branch per sample kept
+    //  the compiler from issuing the 32 pixel loads of a chunk together: 48 us against 36 for the un-blocked kernel)
+    float xv[kSleNb][4];
 #pragma unroll
-    for (int s = 0; s < kSleNb; ++s) {
-      if (s < ns) {
-        float xv[4];
+    for (int s = 0; s < kSleNb; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = (hw0 + i < HW) ? x[((long)s * HW + hw0 + i) * Cc] : 0.f;
+      for (int i = 0; i < 4; ++i) xv[s][i] = x[((long)min(s, ns - 1) * HW + min(hw0 + i, HW - 1)) * Cc];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (hw0 + i < HW) {   // (pixels past HW must not touch the sums: 0 * K would still round -0 / NaN cases differently)
-            acc[s][0] += xv[i] * k0[i].x; acc[s][1] += xv[i] * k0[i].y; acc[s][2] += xv[i] * k0[i].z; acc[s][3] += xv[i] * k0[i].w;
-            acc[s][4] += xv[i] * k1[i].x; acc[s][5] += xv[i] * k1[i].y; acc[s][6] += xv[i] * k1[i].z; acc[s][7] += xv[i] * k1[i].w;
-          }
+    for (int i = 0; i < 4; ++i) {
+      if (hw0 + i < HW) {   // (uniform; pixels past HW must not touch the sums)
+#pragma unroll
+        for (int s = 0; s < kSleNb; ++s) {
+          acc[s][0] += xv[s][i] * k0[i].x; acc[s][1] += xv[s][i] * k0[i].y; acc[s][2] += xv[s][i] * k0[i].z; acc[s][3] += xv[s][i] * k0[i].w;
+          acc[s][4] += xv[s][i] * k1[i].x; acc[s][5] += xv[s][i] * k1[i].y; acc[s][6] += xv[s][i] * k1[i].z; acc[s][7] += xv[s][i] * k1[i].w;
         }
       }
     }
@@ -1564,6 +1699,28 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
   const float p = p0 + ((ua + uc) + ut);
   a.theta[i] = p;
   if (a.ema_on) a.theta_target[i] = p * a.tau + a.theta_target[i] * (1.f - a.tau);
+}
+
+// `steps` deferred target-EMA steps of the frozen trunk leaves at once (common.py:124-134 on leaves no gradient or weight decay
+// ever touches): t <- p*tau + t*(1-tau), repeated -- the same expression, hence the same rounding sequence, as adam_ema_kernel
+// applies step by step.  The iteration stops at its fixed point (t no longer changes), which a constant p reaches after a few steps.
+__global__ __launch_bounds__(256) void frozen_ema_kernel(const float* frozen, float* frozen_target, long n, float tau, long steps) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float p = frozen[i];
+  float t = frozen_target[i];
+  for (long k = 0; k < steps; ++k) {
+    const float u = p * tau + t * (1.f - tau);
+    if (u == t) break;
+    t = u;
+  }
+  frozen_target[i] = t;
+}
+int frozen_ema(const float* frozen, float* frozen_target, long n, float tau, long steps, hipStream_t stream) {
+  if (n <= 0 || steps <= 0) return SERL_OK;
+  SERL_LAUNCH_CHAIN(frozen_ema_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, frozen, frozen_target, n, tau, steps);
+  SERL_HIP(hipGetLastError());
+  return SERL_OK;
 }
 
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
