@@ -309,13 +309,25 @@ def main():
             ent["frac_hbm"] = ent["TBps"] / PEAK_HBM
         per_kernel[tag] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ent.items()}
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch of the family from the PMC counters.  NOT measured by this process: rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE passes (scripts/collect_evidence.sh, serial schedule, possibly another box) leave them in profiles/pmc_traffic.json;
+    # `traffic_source` says so in the line.  The rocprof-derived fraction (profiles/r04_frac_from_stats.txt) rides along the same way.
+    traffic, traffic_source, frac_rocprof = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(f"conv_igemm_{args.trunk}_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes (serial schedule), not this run"
         except Exception:
             traffic = None
+    try:
+        import re as _re
+        txt = open(os.path.join(ROOT, "profiles", "r04_frac_from_stats.txt")).read()
+        vals = [float(m) for m in _re.findall(r"frac ([0-9.]+)", txt)]     # line 1: pipelined schedule, line 2: serial
+        frac_rocprof = dict(zip(("pipelined", "serial"), vals))
+        frac_rocprof["source"] = "profiles/r04_frac_from_stats.txt (rocprofv3 --kernel-trace --stats CSVs, scripts/frac_from_stats.py), not this run"
+    except Exception:
+        frac_rocprof = None
     n_launch = max(1, sum(c for t, (m, c) in prof.items() if t.startswith("conv_igemm")))
     # executed-MFMA fraction per stage (b0: row-patch kernel, b1..b3: LDS-DMA kernel + 1x1 projection)
     frac_by_stage = {}
@@ -330,10 +342,14 @@ def main():
         # 3x the algorithmic FLOPs, and that executed rate is what the fp16-MFMA roofline bounds
         executed = 3.0 * achieved
         roofline = {"bound": "mfma",
-                    "kernel": "block convs of the frozen trunk: conv_dma_f16x3_kernel (stages 1-3) + conv3x3_rowpatch_f16x3_kernel (stage 0) + "
-                              "conv_igemm_f16x3_kernel (1x1 projections); split-fp16 MFMA implicit GEMM, fp32 accumulate; 11 launches per trunk pass",
+                    "kernel": ("block convs of the frozen trunk, 11 launches per pass: conv3x3_rowslab_f16x3_kernel (both stage-0 convs and "
+                               "b1_conv1) + conv_dma_f16x3_kernel (every other 3x3 conv and the three 1x1 projections)" if Bl * len(KEYS) * 2 >= 1024 else
+                               "block convs of the frozen trunk, 11 launches per pass: conv3x3_rowslab_f16x3_kernel (stage 0, b1_conv1), "
+                               "conv_dma_f16x3_kernel where at least 512 128-row tiles exist, conv_igemm_f16x3_kernel (64x64 tiles) otherwise") +
+                              "; split-fp16 MFMA implicit GEMM, fp32 accumulate",
                     "achieved": round(executed, 3), "peak": PEAK_F16_MFMA, "unit": "TFLOP/s",
-                    "frac": round(executed / PEAK_F16_MFMA, 4), "traffic": traffic,
+                    "frac": round(executed / PEAK_F16_MFMA, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac_from_rocprof_csv": frac_rocprof,
                     "algorithmic_tflops": round(achieved, 3),
                     "algorithmic_vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA, 4),
                     "note": "achieved = 3 x algorithmic fp32 conv FLOP/s (executed fp16 MFMA work); "
@@ -349,6 +365,20 @@ def main():
                     "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic,
                     "flop_per_launch_avg": tot_flop / n_launch, "per_kernel": per_kernel}
+    if not small:
+        # the WHOLE step against the same peak: algorithmic FLOPs of one grad step (trunk 2 passes + heads / MLPs)
+        # and the FLOPs the matrix pipes execute for them (3 fp16 products per block-conv FLOP, 2 per conv_init FLOP, 6 bf16
+        # products per update-chain FLOP), both over the measured step time
+        trunk_alg = 2.0 * sum(macs.values()) * n_img
+        ci_alg = 2.0 * macs["conv_init"] * n_img
+        chain_alg = 10.15e9 * (Bl / 256.0) * (len(KEYS) / 2.0)
+        mult = 3.0 if args.trunk == "f16x3" else 1.0
+        step_s = dt / grad_steps
+        alg = (trunk_alg + chain_alg) / step_s / 1e12
+        exe = ((trunk_alg - ci_alg) * mult + ci_alg * (2.0 if args.trunk == "f16x3" else 1.0) + chain_alg * 6.0) / step_s / 1e12
+        roofline["whole_step"] = {"algorithmic_tflops": round(alg, 2), "executed_tflops": round(exe, 2),
+                                  "frac": round(exe / (PEAK_F16_MFMA if args.trunk == "f16x3" else PEAK_F32_MFMA), 4),
+                                  "note": "per grad step of this rank: (trunk 2 passes + ~10.15 GFLOP of heads / MLPs at B=256) / ms_per_step"}
     if small:
         roofline = small_encoder_roofline(prof, per_kernel, Bl, len(KEYS))
     if "gather_crop" in per_kernel:

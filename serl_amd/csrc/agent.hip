@@ -385,7 +385,9 @@ size_t carve(serl_agent* a, void* base) {
 // K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
-int split_for(int M, int N, int groups, int smax, long budget = 512) {
+int split_for(int M, int N, int groups, int smax, long budget = 0) {
+  static const long env_budget = []() { const char* e = getenv("SERL_SPLIT_BUDGET"); return e ? atol(e) : 512L; }();
+  if (budget <= 0) budget = env_budget;
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -425,7 +427,7 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   GemmDesc gd[3];
   LnFwdArgs lv[3];
   ProprioArgs pv[3];
-  static const long enc_budget = []() { const char* e = getenv("SERL_ENC_SPLIT_BUDGET"); return e ? atol(e) : 512L; }();
+  static const long enc_budget = []() { const char* e = getenv("SERL_ENC_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
   const int S = split_for(cnt, c.bottleneck, c.n_cam * n, 32, enc_budget);  // K = 4096: up to 32 slices of 128
   for (int i = 0; i < n; ++i) {
     const EncJob& j = jobs[i];

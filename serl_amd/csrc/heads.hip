@@ -1288,7 +1288,9 @@ __device__ __forceinline__ void proprio_row(const ProprioArgs& a, int S, int row
 // keep-mask (resnet_v1.py:351), when not supplied, is hashed from (seed, camera, GLOBAL sample, channel): three 64-bit hashes
 // give the eight 24-bit uniforms of a thread's eight outputs -- no mask tensor, no gen_noise launch.  Workgroups past the SLE
 // range run the proprio branch of the same instance (camera 0 only): one launch instead of two.
-constexpr int kSleNb = 8;
+// kSleNb samples per workgroup; a rank's share of a data-parallel batch (<= 64 samples) takes 2, which keeps 4x more workgroups
+// in flight (96 workgroups of 8 samples each took 64 us next to the trunk pass at 32 samples)
+template <int kSleNb>
 __global__ __launch_bounds__(256) void sle_proprio_fwd_kernel(Multi<SleFwdArgs> mv, Multi<ProprioArgs> pv, int has_proprio,
                                                               float keep_scale, unsigned keep_thr, int N, int HW, int Cc,
                                                               long xs, long ks, long ms, long fs, int S, int nb_sle) {
@@ -1368,9 +1370,14 @@ int sle_proprio_fwd_multi(const SleFwdArgs* vs, const ProprioArgs* ps, int n, fl
     mv.v[i] = vs[i];
     if (ps) { pv.v[i] = ps[i]; SERL_REQUIRE(!ps[i].copy_dst || ps[i].copy_cols <= 64, "copy_cols > 64"); }
   }
-  const int nb_sle = cdiv(Cc, 256) * cdiv(N, kSleNb), nb_prop = ps ? cdiv(N, 4) : 0;
-  SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
-                     1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
+  const int nb = N <= 64 ? 2 : 8;
+  const int nb_sle = cdiv(Cc, 256) * cdiv(N, nb), nb_prop = ps ? cdiv(N, 4) : 0;
+  if (nb == 2)
+    SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel<2>, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
+                      1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
+  else
+    SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel<8>, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
+                      1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

@@ -1025,6 +1025,7 @@ struct ConvInitArgsB {
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
   int chunk;            // tiles per scheduling chunk (divides tiles_y * tiles_x)
   int* ticket;          // chunk ticket (zeroed per pass)
+  int stagger;          // s_sleep(127) periods the second workgroup of every CU waits before its first tile (see the kernel)
 };
 
 constexpr int kCbPatch = 37;     // input rows/cols per 16x16 output tile
@@ -1125,6 +1126,13 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   // workgroup that cannot become resident at once (the update chain's kernels own some wave slots when the two streams
   // overlap) starts its whole share late and the kernel takes up to twice as long (measured 259 us alone, 485 us
   // co-running); with tickets a late workgroup simply takes fewer chunks.
+  // ANTI-PHASE: the persistent workgroups all start together and every tile takes the same time, so the chip tends to move
+  // through a tile's phases in lockstep -- everybody fills patches, everybody runs MFMAs (HBM idle), everybody writes pooled
+  // outputs (matrix pipe idle).  The second workgroup of every CU (blocks gridDim.x / 2 ..) starts half a tile late, which puts
+  // its output phase under its partner's MFMA phase.  Same-call A/B: conv_init 306 -> 296 us alone, step -0.8 % (serial and
+  // pipelined); the phases' times mostly still add up (their cost is issue slots / latency inside a wave, not a shared unit).
+  if (a.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   __shared__ int s_next_chunk;
   const int nchunks = a.total_tiles / a.chunk;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
@@ -1402,6 +1410,8 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   const int tpi = a.tiles_y * a.tiles_x;
   a.chunk = (pool_gamma && complete_pool) ? tpi : (tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1));
   a.ticket = ticket;
+  static const int stagger = []() { const char* e = getenv("SERL_CINIT_STAGGER"); return e ? atoi(e) : 2; }();   // 2 x ~4 us = half a tile
+  a.stagger = stagger;
   // 2 persistent workgroups per CU
   const int grid = std::min(a.total_tiles / a.chunk, 512);
   ProfScope prof("conv_init", stream);
