@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): official bench line and its variants, the BASELINE configs 2-4, rocprofv3 kernel stats, PMC
 # passes (HBM traffic, MFMA busy, LDS bank conflicts -- each counter group in its own pass, --kernel-trace only), timeline.
-# Outputs land in gpurun_out/evidence/ ; scripts/refresh_profiles.py copies the summaries into profiles/ as r03_*.
+# Outputs land in gpurun_out/evidence/ ; scripts/refresh_profiles.py copies the summaries into profiles/ as r04_*.
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; rm -rf $O; mkdir -p $O
 cd $R
@@ -16,9 +16,13 @@ for w in 2 4 8; do timeout 200 python bench.py $NB --emulate-world $w > $O/bench
 for w in drq_demos peg fwbw; do timeout 300 python bench.py --workload $w --steps 40 --warmup 5 --repeats 3 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 timeout 300 python bench.py --no-cpu-baseline --steps 40 --repeats 3 --encoder small > $O/bench_small_encoder.json 2> $O/bench_small.err
 timeout 200 python bench.py $NB --force-collective > $O/bench_collective_1rank.json 2> /dev/null
-timeout 200 python bench.py $NB --emulate-world 8 --overlap-reduce on > $O/bench_emulate_world8_overlap_on.json 2> /dev/null
 timeout 200 python bench.py $NB --emulate-world 8 --force-collective > $O/bench_emulate_world8_collective.json 2> /dev/null
-timeout 200 python bench.py $NB --emulate-world 8 --force-collective --overlap-reduce on > $O/bench_emulate_world8_collective_overlap_on.json 2> /dev/null
+# update-chain variants, same call: one launch per operation (round-3 schedule) and the opt-in LayerNorm epilogues
+for m in "" "--emulate-world 8" "--no-pipeline"; do
+  t=$(echo $m | tr -d ' -')
+  SERL_CHAIN_FUSE=0 timeout 200 python bench.py $NB $m > $O/bench_chain_unfused$t.json 2> /dev/null
+  SERL_CHAIN_LN_EPI=1 timeout 200 python bench.py $NB $m > $O/bench_chain_lnepi$t.json 2> /dev/null
+done
 timeout 200 python bench.py --workload actor_latency > $O/actor_latency.json 2> /dev/null
 timeout 300 python bench.py --workload sac_state --steps 200 > $O/sac_state.json 2> /dev/null
 timeout 200 python scripts/probes/replay_race.py 1500 48 > $O/replay_race.txt 2>&1
@@ -28,6 +32,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python $R/bench
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_serial -o s -- python $R/bench.py $PB --no-pipeline > $O/stats_serial.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_small -o s -- python $R/bench.py $PB --steps 8 --encoder small --no-pipeline > $O/stats_small.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python $R/bench.py $PB --steps 12 > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_serial -o t -- python $R/bench.py $PB --steps 12 --no-pipeline > $O/trace_serial.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_e8 -o t -- python $R/bench.py $PB --steps 12 --emulate-world 8 > $O/trace_e8.log 2>&1
 BA="--no-cpu-baseline --no-verify --no-pipeline --fill 1500 --steps 6 --warmup 2 --repeats 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py $BA > $O/pmc_$c.log 2>&1
@@ -42,5 +48,8 @@ python scripts/pmc_wait.py $O/pmc_wait $O/wait_counters.json
 for t in stats stats_serial stats_small; do python scripts/rocprof_summary.py $(find $O/$t -name '*results.db' | head -1) $O/kernel_$t.csv || true; done
 python scripts/frac_from_stats.py $O/kernel_stats.csv > $O/frac_from_stats.txt; python scripts/frac_from_stats.py $O/kernel_stats_serial.csv >> $O/frac_from_stats.txt; cat $O/frac_from_stats.txt
 python scripts/timeline_full.py $O/trace > $O/timeline.txt 2>&1
+python scripts/chain_trace.py $O/trace > $O/launches_pipelined.txt 2>&1
+python scripts/chain_trace.py $O/trace_serial > $O/launches_serial.txt 2>&1
+python scripts/chain_trace.py $O/trace_e8 > $O/launches_emulate_world8.txt 2>&1
 find $O -name '*.csv' -size +2M -delete; find $O -name '*.db' -delete
 ls -R $O | head -80

@@ -480,8 +480,15 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   }
   if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
     const size_t fbytes = (size_t)c.H * c.W * 3;
+    // (no Dropout on this encoder -- pool "avg" -- so two instances with the same parameters and observation side are the same
+    //  pass: the actor step's critic-side and policy-side encodings of obs.  The LAST instance always runs: the backward pass
+    //  reads the activations of the forward pass that ran last.)
     for (int i = 0; i < n; ++i) {
       const EncJob& j = jobs[i];
+      int dup = -1;
+      for (int k = i + 1; k < n; ++k)
+        if (jobs[k].P == j.P && jobs[k].which == j.which) dup = k;
+      if (dup >= 0) { gd[i].A = jobs[dup].e->f; continue; }
       const uint8_t* fr = a->cur.frames + (((size_t)j.which * c.n_cam) * Bfull + off) * fbytes;
       RC(small_forward(a->sws, j.P, o.cam[0].conv, o.cam_stride, fr, Bfull, c.n_cam, cnt, j.e->f, (long)c.batch * a->D, st));
     }

@@ -38,6 +38,7 @@ struct TrunkPlan {
 };
 struct TrunkWorkspace {
   TrunkPlan plan{};
+  bool fuse_pass = false;   // the pass in flight uses the fused GroupNorm epilogues (decided by its first piece)
   int max_images = 0;
   TrunkDims d{};
   float* raw_init = nullptr;  // [N][h0][w0][64]

@@ -17,6 +17,7 @@
 // (row>>2)&3 -> conflict-free ds_read_b128 MFMA fragments).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "prof.h"
 #include "trunk_common.h"
@@ -1845,6 +1846,35 @@ static GnRef gn_ref_b(const double* stats, const float* gamma, const float* beta
   return g;
 }
 
+// ONE fused pass at a time per process.  The fused GroupNorm epilogues WAIT for other workgroups of their launch, and their
+// forward-progress argument (FuseArgs) counts on every resident workgroup that waits belonging to THIS launch.  Two agents
+// whose passes run concurrently on two streams break that: the CUs can fill up with waiters of both launches while the
+// workgroups they wait for cannot start -- a deadlock the spin bound turns into a trap (found by round 4's 2000-step stress
+// test, which keeps a second and a third agent's passes running on other streams).  A pass therefore claims the fused path
+// only if the previous fused pass was issued on the same stream (in order: no overlap) or has completed (event query);
+// otherwise it runs the separate elementwise passes (same results, ~10 % slower, no waiting of any kind).  Passes of OTHER
+// processes on the same GPU cannot be seen from here: run one learner process per GPU, or set SERL_GN_FUSE=0.
+static std::mutex g_fused_mu;
+static hipStream_t g_fused_stream = nullptr;
+static hipEvent_t g_fused_done = nullptr;
+static bool g_fused_any = false, g_fused_open = false;   // open: a pass issued in pieces has not issued its last piece yet
+static bool claim_fused_pass(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  if (g_fused_any && g_fused_stream != stream &&
+      (g_fused_open || (g_fused_done && hipEventQuery(g_fused_done) == hipErrorNotReady))) return false;
+  (void)hipGetLastError();
+  g_fused_stream = stream;
+  g_fused_any = g_fused_open = true;
+  return true;
+}
+static void fused_pass_issued(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  if (g_fused_stream != stream) return;
+  g_fused_open = false;
+  if (!g_fused_done && hipEventCreateWithFlags(&g_fused_done, hipEventDisableTiming) != hipSuccess) { g_fused_done = nullptr; return; }
+  (void)hipEventRecord(g_fused_done, stream);
+}
+
 // Trunk forward in split-fp16 arithmetic.  Activations between kernels live in the split16 layout;
 // raw conv outputs (pre-GroupNorm) and the final features stay fp32.
 int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& pk, const uint8_t* frames, int N,
@@ -1862,10 +1892,16 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
       SERL_HIP(hipMemsetAsync(ws.stats, 0, ws.stats_sync_bytes, stream));
     }
   }
+  // fused epilogues for this pass?  SERL_GN_FUSE is read per pass (tests flip it inside one process); the claim is taken by the
+  // piece that starts the pass and remembered in the workspace for the pieces that follow
+  if (stage_begin < 0) {
+    const char* e = getenv("SERL_GN_FUSE");
+    ws.fuse_pass = !(e && e[0] == '0') && claim_fused_pass(stream);
+  }
+  const bool fuse_on = ws.fuse_pass;
   auto fuse_of = [&](int layer, int mode) {
     FuseArgs f{};
-    const char* e = getenv("SERL_GN_FUSE");   // read per pass: tests flip it inside one process
-    f.mode = (e && e[0] == '0') ? 0 : mode;
+    f.mode = fuse_on ? mode : 0;
     f.sync = ws.sync + (size_t)layer * ((size_t)ws.max_images * kSyncPerImage + kSyncTickets);
     f.ticket = f.sync + (size_t)ws.max_images * kSyncPerImage;
     return f;
@@ -1877,7 +1913,6 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
   // Needs: full 16x16 conv_init tiles, at least 2 images per persistent workgroup, block 0 on the row-slab kernel with its
   // fused epilogue available.  Decided from shapes only, so that a pass issued in pieces decides the same way every time.
   const bool fuse_pool = d.h[0] % 16 == 0 && d.w[0] % 16 == 0;   // full 16 x 16 conv_init tiles: pooling fused into conv_init
-  const bool fuse_on = [] { const char* e = getenv("SERL_GN_FUSE"); return !(e && e[0] == '0'); }();
   const int P0 = d.h[2] * d.w[2];
   const bool complete_pool = fuse_pool && N >= 512 && N % 512 == 0;
   const bool raw_b0 = complete_pool && fuse_on && kStageStride[0] == 1 && w.blk[0].proj == nullptr &&
@@ -1977,6 +2012,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     x = ws.blk[i].out;
     cin = f;
   }
+  if (fuse_on && stage_end == kTrunkStages - 1) fused_pass_issued(stream);
   return SERL_OK;
 }
 

@@ -161,3 +161,33 @@ def test_fused_chain_hand_off_survives_2000_steps_under_load(gpu):
                 _assert_state_bits(cfg, fused, plain, (B, it), leaves=check)
         torch.cuda.synchronize()
         _assert_state_bits(cfg, fused, plain, (B, "final"))
+
+
+def test_two_agents_trunk_passes_on_two_streams_neither_deadlock_nor_differ(gpu):
+    """Two agents in one process, their frozen-trunk passes issued concurrently on two streams (fw / bw learners sharing a GPU).
+    The fused GroupNorm epilogues spin-wait for workgroups of their own launch; with two such launches resident at once the CUs
+    can fill with waiters of both (the 2000-step test above found the trap).  trunk_f16x3.hip now lets only ONE pass at a time
+    take the fused path (claim_fused_pass); the other runs the separate elementwise passes.  Features must equal the ones of
+    passes issued alone."""
+    cfg = O.Config(image_keys=("front", "wrist"), H=128, W=128, S=24, A=6)
+    B = 256
+    _, a0 = AH.make_pair(cfg, B, agent_seed=1)
+    _, a1 = AH.make_pair(cfg, B, agent_seed=2)
+    batches = [AH.batch_to_device(cfg, AH.synth_batch(cfg, B, seed=900 + i)) for i in range(2)]
+    n = 2 * cfg.n_cam * B * 16 * 512
+    ref = []
+    for ag, db in ((a0, batches[0]), (a1, batches[1])):      # alone, one after the other
+        ag.encode_slot(db, 0)
+        ag.select_slot(0)
+        torch.cuda.synchronize()
+        ref.append(ag.debug("feats", n).copy())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for it in range(60):
+        for ag, db, st in ((a0, batches[0], streams[0]), (a1, batches[1], streams[1])):
+            with torch.cuda.stream(st):
+                ag.encode_slot(db, 0)
+    torch.cuda.synchronize()
+    for k, ag in enumerate((a0, a1)):
+        got = ag.debug("feats", n)
+        err = float(np.max(np.abs(got - ref[k])) / np.max(np.abs(ref[k])))
+        assert err < 2e-6, (k, err)     # fused and un-fused passes differ by fp32 round-off only
