@@ -1,11 +1,11 @@
-"""Rewrites the measured numbers of DESIGN.md (section 5 table) and README.md from profiles/r03_*.json.
+"""Rewrites the measured numbers of DESIGN.md (section 5 table) and README.md from profiles/r04_*.json.
 Run after scripts/refresh_profiles.py."""
 import json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = lambda n: json.load(open(os.path.join(R, "profiles", n)))
-b, se, un = L("r03_bench.json"), L("r03_bench_serial.json"), L("r03_bench_unfused_gn.json")
-e2, e4, e8 = L("r03_bench_emulate_world2.json"), L("r03_bench_emulate_world4.json"), L("r03_bench_emulate_world8.json")
-mc = L("r03_mfma_counters.json")
+b, se, un = L("r04_bench.json"), L("r04_bench_serial.json"), L("r04_bench_unfused_gn.json")
+e2, e4, e8 = L("r04_bench_emulate_world2.json"), L("r04_bench_emulate_world4.json"), L("r04_bench_emulate_world8.json")
+mc = L("r04_mfma_counters.json")
 r, cb = b["roofline"], b["cpu_baseline"]
 
 
@@ -26,9 +26,9 @@ s = between(s, "<!-- scaling-table-begin -->", "<!-- scaling-table-end -->", f""
 open(p, "w").write(s)
 p = os.path.join(R, "README.md")
 s = open(p).read()
-s = between(s, "<!-- numbers-begin -->", "<!-- numbers-end -->", f"""Round-3 numbers on one MI355X (details, history and rejected experiments in `profiles/README.md`): **{b['value']} grad-steps/s** at
-batch 256, 2×128×128×3 cameras ({b['ms_per_step']} ms per step, median of 3 × 200 steps; {b['value']/cb['value']:.0f}× the CPU port on {cb['cores']} cores; round 1: 296.5, round 2: 354.2);
-BASELINE configs 2-4 (two replay buffers, CAR 8 / 8 / 4): {L("r03_bench_drq_demos.json")['value']} / {L("r03_bench_peg.json")['value']} / {L("r03_bench_fwbw.json")['value']} grad-steps/s; trainable SmallEncoder: {L("r03_bench_small_encoder.json")['value']} grad-steps/s;
+s = between(s, "<!-- numbers-begin -->", "<!-- numbers-end -->", f"""Round-4 numbers on one MI355X (details, history and rejected experiments in `profiles/README.md`): **{b['value']} grad-steps/s** at
+batch 256, 2×128×128×3 cameras ({b['ms_per_step']} ms per step, median of 3 × 200 steps; {b['value']/cb['value']:.0f}× the CPU port on {cb['cores']} cores; round 1: 296.5, round 2: 354.2, round 3: 377.8);
+BASELINE configs 2-4 (two replay buffers, CAR 8 / 8 / 4): {L("r04_bench_drq_demos.json")['value']} / {L("r04_bench_peg.json")['value']} / {L("r04_bench_fwbw.json")['value']} grad-steps/s; trainable SmallEncoder: {L("r04_bench_small_encoder.json")['value']} grad-steps/s;
 block convs {r['achieved']:.0f} TFLOP/s of executed fp16 MFMA = {100*r['frac']:.0f} % of peak including the GroupNorm epilogues they now carry
 ({100*un['roofline']['frac']:.0f} % with the epilogues switched off, at a {un['ms_per_step']} ms step); matrix pipe busy per SIMD (PMC): LDS-DMA convs
 {mc.get('conv_dma_f16x3', {}).get('mfma_util_per_simd')}, row-slab convs {mc.get('conv3x3_rowslab_f16x3', {}).get('mfma_util_per_simd')}; sample + augmentation kernel {se['roofline']['sample_aug_hbm']['achieved']} TB/s alone;

@@ -466,16 +466,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
 }
 
 // =============================================================================================
-// The same GEMM on the bf16 matrix pipe: "bf16x3".  Every fp32 operand is split EXACTLY into three bf16 pieces
-//     x = x0 + x1 + x2,   x0 = trunc16(x), x1 = trunc16(x - x0), x2 = x - x0 - x1
-// (bf16 keeps fp32's exponent and 8 significant bits: three truncations peel off all 24 bits of the significand, and
-// each remainder is exact in fp32), and the product a*b is taken as the six piece products with i + j <= 2
+// The same GEMM on the bf16 matrix pipe: "bf16x3".  Every fp32 operand is split into three bf16 pieces
+//     x = x0 + x1 + x2,   x0 = rn16(x), x1 = rn16(x - x0), x2 = rn16(x - x0 - x1)          (split3 below)
+// (bf16 keeps fp32's exponent and 8 significant bits: three pieces cover the 24-bit significand) and the product a*b is taken
+// as the six piece products with i + j <= 2
 //     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)
-// on v_mfma_f32_32x32x16_bf16, accumulated in fp32; the three dropped products are below 3 * 2^-24 |a b|, i.e. at fp32
-// round-off.  Unlike the trunk's split-fp16 scheme this needs NO operand scaling (bf16 has the range of fp32), so it takes
-// activations, weights and back-propagated gradients (1e-3 .. 1e-9) alike: 6 MFMAs of 32 cycles per 32x32x16 block
-// instead of 8 of 64 -- 2.7x less time on the matrix pipe, which the update chain shares with the frozen trunk of the
-// next batch on the other stream.  Same descriptor, grid, K-split and epilogue as gemm_f32_kernel (drop-in).
+// on v_mfma_f32_32x32x16_bf16, accumulated in fp32; the dropped products a1 b2 + a2 b1 + a2 b2 are below 2^-23 |a b| and of
+// either sign -- fp32 round-off class.  Unlike the trunk's split-fp16 scheme this needs NO operand scaling (bf16 has the
+// range of fp32), so it takes activations, weights and back-propagated gradients (1e-3 .. 1e-9) alike: 6 MFMAs of 32 cycles
+// per 32x32x16 block instead of 8 of 64 -- 2.7x less time on the matrix pipe, which the update chain shares with the frozen
+// trunk of the next batch on the other stream.  Same descriptor, grid, K-split and epilogue as gemm_f32_kernel (drop-in);
+// SERL_GEMM=f32 keeps the exact kernel as the reference arithmetic.
 // LDS: per operand three planes [64 rows][32 k] bf16 (64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3:
 // conflict-free ds_read_b128 fragments, as in the trunk kernels).  A k-contiguous operand arrives as 16-byte global
 // vectors (4 k of one row -> one 8-byte store per plane); a row-contiguous operand as eight coalesced 4-byte loads per
@@ -493,15 +494,20 @@ __device__ __forceinline__ int xswz(int row, int slot) {
   return BK == 32 ? row * 64 + ((slot ^ ((row >> 2) & 3)) << 4) : row * 32 + ((slot ^ ((row >> 3) & 1)) << 4);
 }
 
-// two fp32 values -> their three bf16 pieces, packed (first value in the low half)
+// two fp32 values -> their three bf16 pieces, packed (first value in the low half).  ROUND-TO-NEAREST pieces (v_cvt_pk_bf16_f32):
+// x0 = rn(x), x1 = rn(x - x0), x2 = rn(x - x0 - x1); both differences are exact in fp32 and |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|
+// (x2 itself is exact unless x - x0 needs 17 bits, then it is off by < 2^-25 |x|).  Round 3 split by TRUNCATION: remainders twice
+// as large and all of x's sign, so the dropped products a1 b2 + a2 b1 reached 2^-20 |a b| and biased every dot product
+// towards zero; with rounded pieces they are <= 2^-23 |a b| and sign-symmetric.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3(float v, float w, unsigned& p0, unsigned& p1, unsigned& p2) {
-  const unsigned a0 = __builtin_bit_cast(unsigned, v) & 0xffff0000u, b0 = __builtin_bit_cast(unsigned, w) & 0xffff0000u;
-  const float r1 = v - __builtin_bit_cast(float, a0), s1 = w - __builtin_bit_cast(float, b0);
-  const unsigned a1 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u, b1 = __builtin_bit_cast(unsigned, s1) & 0xffff0000u;
-  const float r2 = r1 - __builtin_bit_cast(float, a1), s2 = s1 - __builtin_bit_cast(float, b1);
-  p0 = __builtin_amdgcn_perm(b0, a0, 0x07060302u);
-  p1 = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-  p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s2), __builtin_bit_cast(unsigned, r2), 0x07060302u);
+  const f32x2_t x = {v, w};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+  const f32x2_t r1 = x - (f32x2_t){__builtin_bit_cast(float, p0 << 16), __builtin_bit_cast(float, p0 & 0xffff0000u)};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+  const f32x2_t r2 = r1 - (f32x2_t){__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
 }
 
 // One operand tile of 64 rows x BK k's per chunk.  KFAST: 16-byte global vectors along k (BK / 16 per thread); otherwise

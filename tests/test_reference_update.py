@@ -106,6 +106,24 @@ def test_live_reference_matches_oracle():
 
 
 @needs_ref
+def test_live_reference_on_jax_key_chain(monkeypatch):
+    """The same with the stand-in jax.random drawing through JAX's own threefry2x32 key chain (oracle/jaxshim/jax/threefry.py,
+    pinned in tests/test_threefry_oracle.py): the reference's split / fold_in / randint / normal / bernoulli calls then consume
+    the numbers a real JAX run draws for these keys; the oracle, fed the recorded draws, still agrees."""
+    monkeypatch.setenv("SERL_JAXSHIM_PRNG", "threefry")
+    cfg = O.Config(image_keys=("front",), H=64, W=64, S=7, A=4)
+    sched = [("critics",), ("high_utd", 1)]
+    res = RR.run_reference(cfg, 4, sched, param_seed=3, batch_seed=11)
+    st, infos = _run_oracle(cfg, res["steps"], 3)
+    for info, step in zip(infos, res["steps"]):
+        for k, v in info.items():
+            assert abs(v - step["info"][k]) <= F64_TOL * max(1.0, abs(step["info"][k])), (k, v, step["info"][k])
+    f = res["final"]
+    for k in st.params:
+        assert np.abs(st.params[k].numpy().reshape(-1) - f["params"][k]).max() <= F64_TOL * (np.abs(f["params"][k]).max() + 1e-30), k
+
+
+@needs_ref
 def test_reference_random_crop_equals_the_oracle_shift():
     """vision/data_augmentations.py:7-36 (edge pad 4 + dynamic_slice) run from the reference == oracle random_shift."""
     jax = RS.install(True)
