@@ -53,6 +53,7 @@ def declare(lib):
         "serl_agent_get": [vp, C.c_char_p, C.c_char_p, vp, i64],
         "serl_agent_set_step": [vp, i64],
         "serl_agent_set_trunk_mode": [vp, i32],
+        "serl_agent_set_chain_budget": [vp, i32],
         "serl_agent_update_critics": [vp, P(SerlBatch), P(SerlNoise), vp],
         "serl_agent_update_high_utd": [vp, P(SerlBatch), i32, P(SerlNoise), vp],
         "serl_agent_read_info": [vp, P(SerlInfo), vp],

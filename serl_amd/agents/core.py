@@ -86,6 +86,10 @@ class AgentCore:
         """'f32' = exact fp32 MFMA convs, 'f16x3' = split-fp16 convs (default)."""
         _lib.check(self.L.serl_agent_set_trunk_mode(self._h, {"f32": 0, "f16x3": 1}[mode]))
 
+    def set_chain_budget(self, workgroups: int):
+        """Scheduling hint (no effect on results): workgroup budget of the update's K-split GEMM launches, 0 = default."""
+        _lib.check(self.L.serl_agent_set_chain_budget(self._h, int(workgroups)))
+
     def load_flat(self, section: str, tree: Dict[str, np.ndarray]):
         for k, v in tree.items():
             self.set(section, k, v)

@@ -321,6 +321,8 @@ class DrQAgent:
         from ..parallel import TorchPipelineSchedule
         if self._sched is None:
             self._sched = TorchPipelineSchedule(self.core.device, prioritise_update=False)
+            if self.core.cfg.batch >= 128:
+                self.core.set_chain_budget(256)      # the chain now runs beside the trunk pass (see parallel.py)
         sch, B = self._sched, batch.batch_size
         key = self._lazy_key(batch)
         if self._prefetched is not None and self._prefetched[0] == key:

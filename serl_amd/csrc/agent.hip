@@ -101,6 +101,11 @@ struct serl_agent {
   // critic + actor pair).  Measured SLOWER in every schedule (profiles/README.md round 4): the last arriver of a 64-row tile
   // normalises 64 rows on four waves while the separate LayerNorm launch spreads the same rows over the whole chip.
   bool ln_epi = false;
+  // K-split budget of the chain's GEMMs (workgroups per launch): 512 by default; 256 when the caller overlaps the chain with the
+  // next batch's trunk pass at a large per-rank batch (serl_agent_set_chain_budget) -- fewer workgroups queue for CU slots
+  // between conv workgroups (same call: pipelined 2.605 -> 2.570 ms, conv_init next to the chain 455 -> 372 us; alone the
+  // chain is 2 % slower with it, and 1024 - 2048 would be 3 - 4 % faster alone)
+  long split_budget = 0;
   int* ctr = nullptr;   // arrival counters: kCtrLanes ranges of kCtrPerLane (zero between launches)
   float* feats = nullptr;  // current slot: [2][n_cam][B][HW][512]
   static constexpr int kSlots = 3;                                  // pipelined update batches in flight (see serl_mi355.h)
@@ -385,9 +390,10 @@ size_t carve(serl_agent* a, void* base) {
 // K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
+long g_split_budget = 0;   // the running agent's budget (set at the top of every phase: the chain of one agent is issued by one thread)
 int split_for(int M, int N, int groups, int smax, long budget = 0) {
-  static const long env_budget = []() { const char* e = getenv("SERL_SPLIT_BUDGET"); return e ? atol(e) : 512L; }();
-  if (budget <= 0) budget = env_budget;
+  static const long env_budget = []() { const char* e = getenv("SERL_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
+  if (budget <= 0) budget = env_budget > 0 ? env_budget : (g_split_budget > 0 ? g_split_budget : 512L);
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -1077,6 +1083,12 @@ int serl_agent_set_trunk_mode(serl_agent* a, int mode) {
   return SERL_OK;
 }
 
+int serl_agent_set_chain_budget(serl_agent* a, int workgroups) {
+  SERL_REQUIRE(a && workgroups >= 0 && workgroups <= 8192, "bad K-split budget");
+  a->split_budget = workgroups;
+  return SERL_OK;
+}
+
 int serl_agent_set_step(serl_agent* a, int64_t step) {
   SERL_REQUIRE(a && step >= 0, "bad argument");
   a->step = step;
@@ -1203,6 +1215,7 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   for (int k = 0; k < m_sub; ++k) SERL_REQUIRE(sel.idx[k] >= 0 && sel.idx[k] < c.ensemble, "REDQ index out of range");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
+  g_split_budget = a->split_budget;
   const int A = c.act_dim;
   if (a->fuse) {
     const FusedNoise fz = fetch_noise_fused(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0);
@@ -1277,6 +1290,7 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   SERL_REQUIRE(global_count >= cnt, "global_count < local batch");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
+  g_split_budget = a->split_budget;
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
   hipStream_t s0 = st;
   if (a->fuse) {

@@ -148,6 +148,10 @@ class DataParallelLearner:
         if world > 1 and hasattr(core, "set_shard"):
             core.set_shard(rank * self.Bl, self.B)   # device noise indexed by the global sample id
         self._next_slot = 0
+        # the update chain co-runs with the next batch's trunk pass: at a large per-rank batch the trunk is the critical path and
+        # the chain has slack, so its GEMM launches use fewer workgroups (profiles/README.md round 4: 2.605 -> 2.570 ms)
+        if self.sched.slots > 1 and self.Bl >= 128 and hasattr(core, "set_chain_budget"):
+            core.set_chain_budget(256)
         # overlap_reduce=True: bucketed, overlapped gradient all-reduce (DDP-style): the critic phase publishes [ensemble | head |
         # proprio | scalars] before it starts the encoder-head backward; that bucket is reduced on a communication stream while
         # the encoder heads' weight gradients are still being computed, the second bucket follows, and only `apply` waits.
