@@ -240,7 +240,8 @@ class AgentCore:
             k, v = tok.split("=")
             if "/" in v:
                 kern, cfg, pm, fz = v.split("/")
-                out[k] = (kern, int(cfg), int(pm), int(fz[1:]))
+                fz, _, ks = fz.partition("k")      # "f<fused>[k<K-split>]"
+                out[k] = (kern, int(cfg), int(pm), int(fz[1:])) + ((int(ks),) if ks else ())
             else:
                 out[k] = int(v)
         return out

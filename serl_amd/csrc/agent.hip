@@ -1538,7 +1538,7 @@ int serl_agent_trunk_plan(serl_agent* a, char* out, int cap) {
       const TrunkPlan::L& l = p.conv[i][k];
       if (!l.kern) continue;
       s += " b" + std::to_string(i) + "_" + kNames[k] + "=" + std::string(1, l.kern) + "/" + std::to_string(l.cfg) + "/" +
-           std::to_string(l.pmode) + "/f" + std::to_string(l.fused);
+           std::to_string(l.pmode) + "/f" + std::to_string(l.fused) + (l.ksplit > 1 ? "k" + std::to_string(l.ksplit) : std::string());
     }
   snprintf(out, cap, "%s", s.c_str());
   return SERL_OK;

@@ -27,6 +27,7 @@ struct TrunkDims {
 TrunkDims trunk_dims(int H, int W);
 
 constexpr int kSyncPerImage = 8, kSyncTickets = 16;
+constexpr int kKsplitTiles = 1024;   // partial tiles (workgroups) a K-split conv launch may use: 16 MB of scratch
 // Which kernels the last split-fp16 pass selected (introspection for the parity tests: the shapes a data-parallel rank runs
 // choose other kernels than the full batch does).  kern: 'S' row-slab, 'D' LDS-DMA, 'R' register-staged implicit GEMM,
 // 0 = layer absent; cfg: tile configuration of launch_conv_f16x3; fused: GroupNorm epilogue inside the conv (1 exchange, 2 local).
@@ -34,7 +35,7 @@ struct TrunkPlan {
   int images = 0;
   int pool = 0;      // 0: separate GroupNorm + max-pool pass, 1: pooled in conv_init + pool_finish, 2: completed in conv_init
   int raw_b0 = 0;    // block 0 reads conv_init's raw pooled tensor (RAWIN)
-  struct L { char kern = 0; int cfg = 0, pmode = 0, fused = 0; } conv[kTrunkStages][3];
+  struct L { char kern = 0; int cfg = 0, pmode = 0, fused = 0, ksplit = 1; } conv[kTrunkStages][3];
 };
 struct TrunkWorkspace {
   TrunkPlan plan{};
@@ -46,6 +47,10 @@ struct TrunkWorkspace {
   struct B {
     float *raw0, *raw1, *rawp, *out, *norm0;
   } blk[kTrunkStages]{};
+  // K-split scratch of the small-M conv kernel (trunk_f16x3.hip): kKsplitTiles partial 64x64 tiles + one arrival counter per
+  // output tile (zero between launches: the last arriver re-zeroes its counter)
+  float* kslab = nullptr;
+  int* kctr = nullptr;
   double* stats = nullptr;  // 13 GN layers x [N][4][2]
   int* sync = nullptr;      // directly behind `stats` (one memset): 13 layers x (kSyncPerImage arrival counters per image + kSyncTickets ints)
   size_t stats_sync_bytes = 0;

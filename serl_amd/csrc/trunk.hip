@@ -455,6 +455,8 @@ static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int 
     blk[i].out = (float*)take(e);
     blk[i].norm0 = (float*)take(e);
   }
+  float* kslab = (float*)take((size_t)kKsplitTiles * 64 * 64 * 4);
+  int* kctr = (int*)take((size_t)kKsplitTiles * sizeof(int));
   const size_t stats_bytes = al256((size_t)kGnLayers * N * kGnGroups * 2 * sizeof(double));
   const size_t sync_bytes = (size_t)kGnLayers * ((size_t)N * kSyncPerImage + kSyncTickets) * sizeof(int);
   double* stats = (double*)take(stats_bytes + sync_bytes);
@@ -464,6 +466,7 @@ static size_t trunk_layout(TrunkWorkspace* ws, uint8_t* base, int N, int H, int 
     ws->max_images = N; ws->d = d; ws->raw_init = raw_init; ws->pool = pool;
     for (int i = 0; i < kTrunkStages; ++i) ws->blk[i] = blk[i];
     ws->stats = stats; ws->base = base; ws->bytes = off;
+    ws->kslab = kslab; ws->kctr = kctr;
   }
   return off;
 }

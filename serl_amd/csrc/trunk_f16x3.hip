@@ -17,6 +17,7 @@
 // (row>>2)&3 -> conflict-free ds_read_b128 MFMA fragments).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "prof.h"
@@ -65,6 +66,13 @@ struct ConvArgsB {
   const uint16_t* wslab; // row-slab kernel: the planes in its fetch order (pack_slab_order_f16x3) or nullptr
   const uint16_t* wdma;  // LDS-DMA kernel: the planes in its piece order (pack_dma_order_f16x3) or nullptr
   int K;
+  // K-split of the small-M register-staged kernel (a rank's share of a data-parallel batch): `ksplit` workgroups per 64x64
+  // tile, each over a contiguous range of K chunks; partial tiles go to `kslab` [tile][split][4 waves][4 quads][64 lanes][4]
+  // (the accumulator registers as they are: 16-byte write-through stores) and the workgroup that arrives last at `kctr[tile]`
+  // adds them in split order and runs the ordinary epilogue (raw store + statistics)
+  int ksplit;
+  float* kslab;
+  int* kctr;
 };
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -279,7 +287,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int S = ab.ksplit > 1 ? ab.ksplit : 1;
+  const int gid = xcd_remap(blockIdx.x, gridDim.x);   // (a tile's splits are neighbours: same XCD, shared operands in L2)
+  const int id = gid / S, split = gid - id * S;
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
   // per-thread im2col rows: element offset of the always-valid centre tap (pixel (oy*s, ox*s)) and a
@@ -303,8 +313,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
       }
     }
   }
-  const int nchunks = a.KH * a.KW * (a.Cin >> 5);
-  constexpr int cb = 0;   // first chunk
+  const int nchunks_all = a.KH * a.KW * (a.Cin >> 5);
+  const int cper = nchunks_all / S;                     // (the host picks S | nchunks_all)
+  const int cb = split * cper;                          // first chunk of this workgroup
+  const int nchunks = cb + cper;                        // one past its last chunk
   // (native vector types: HIP's uint4 struct copies lower to memcpy and keep the arrays out of registers)
   u32x4 ra[AI], rb[BI], ra2[DEEP >= 2 ? AI : 1], rb2[DEEP >= 2 ? BI : 1], ra3[DEEP >= 3 ? AI : 1], rb3[DEEP >= 3 ? BI : 1];
   unsigned okmask = 0, okmask2 = 0, okmask3 = 0;
@@ -435,6 +447,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+  if (S > 1) {
+    // K-split: publish this partial tile -- the accumulator registers as they are, four per 16-byte WRITE-THROUGH store (1 KB
+    // per wave instruction, contiguous) -- drain, take a ticket; the last arriver re-reads all partials IN SPLIT ORDER with
+    // L1-bypassing loads into the same registers and carries on below: the in-launch split-K recipe of
+    // cdna_hip_programming.md (no fence, no spinning: nobody waits).  (4-byte partial stores, round 4's first build, are one
+    // fabric write each and cost more than the K range saved: b3_conv1 85 -> 99 us.)
+    constexpr int kSc1 = 16;
+    constexpr int WAVE_FLOATS = TM * TN * 16 * 64;
+    const size_t tile_floats = (size_t)4 * WAVE_FLOATS;
+    // (ONE workgroup-uniform buffer descriptor for the tile's S partials; split, wave and lane go into the byte offset -- a
+    //  descriptor whose base depends on the wave index lands in VGPRs and hipcc wraps every access in a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ab.kslab + (size_t)id * S * tile_floats, 0, 0x7fffffff, 0x00020000);
+    const int wl_off = (wave * WAVE_FLOATS + lane * 4) * 4;   // this lane's 16 bytes inside a quad block of its wave's region
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          typedef float f32x4s_t __attribute__((ext_vector_type(4)));
+          const f32x4s_t vf = {acc[tm][tn][4 * q4], acc[tm][tn][4 * q4 + 1], acc[tm][tn][4 * q4 + 2], acc[tm][tn][4 * q4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vf), rs, split * (int)(tile_floats * 4) + wl_off + ((tm * TN + tn) * 4 + q4) * 1024, 0, kSc1);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smemb);   // (the operand LDS is idle: every wave passed the barrier above)
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(ab.kctr + id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int last = old == S - 1;
+      if (last) __hip_atomic_store(ab.kctr + id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+          for (int sp = 0; sp < S; ++sp)
+            sum += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                       rs, sp * (int)(tile_floats * 4) + wl_off + ((tm * TN + tn) * 4 + q4) * 1024, 0, kSc1));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[tm][tn][4 * q4 + j] = sum[j];
+        }
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1724,7 +1785,8 @@ static bool fused_can_wait(hipStream_t stream, int G) { return resident_workgrou
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
                              hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
-                             const RawInput* raw_in = nullptr, TrunkPlan::L* plan = nullptr) {
+                             const RawInput* raw_in = nullptr, TrunkPlan::L* plan = nullptr, float* kslab = nullptr,
+                             int* kctr = nullptr) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -1753,6 +1815,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   int pmode = (a.P % wrows == 0) ? 0 : (a.P == 32 ? 1 : (a.P == 16 ? 2 : 3));
   if (cfg == 2 && pmode == 1) pmode = 3;
   dim3 grid(a.tiles_m * a.tiles_n), block(256);
+  if (plan) plan->ksplit = 1;
   {
     ProfScope prof(tag, stream);
 #define SERL_LAUNCH_CONV(WM, WN, TM, TN, DEEP)                                                                                 \
@@ -1805,7 +1868,27 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2, 0);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2, 0);
     else if (cfg == 4) SERL_LAUNCH_CONV(2, 2, 2, 1, 3);
-    else SERL_LAUNCH_CONV(2, 2, 1, 1, 3);
+    else {
+      // small M (a rank's share of a data-parallel batch): fewer than 512 64x64 tiles leave CUs idle and every workgroup walks
+      // the whole K range at global-load latency (b3_conv1 at 128 images: 256 workgroups x 144 chunks = 85-91 us).  K-SPLIT: 2 or
+      // 4 workgroups per tile, partial tiles summed by the last arriver (conv_igemm_f16x3_kernel) -- no extra launch
+      const int tiles = a.tiles_m * a.tiles_n, nch = ksz * ksz * (Cin >> 5);
+      static const int ks_env = []() { const char* e = getenv("SERL_CONV_KSPLIT"); return e ? atoi(e) : -1; }();
+      int S = 1;
+      // OPT-IN (SERL_CONV_KSPLIT=n >= 2: at most n workgroups per tile).  Measured at 128 / 256 images (profiles/README.md round
+      // 4): two workgroups per tile speed the KERNELS up while the split launch still fits one round of the chip (b3 at 128
+      // images, 256 tiles: conv0 57 -> 48 us, conv1 89 -> 61 us); with 512 tiles already (b2 at 128 images, b3 at 256) the extra
+      // workgroups only queue (37 -> 51 us), four per tile never paid -- and the B/8 STEP did not move (0.765 -> 0.773 ms, two
+      // same-call pairs): at that size the update chain, not the trunk stream, bounds the step.
+      if (kslab && kctr && ks_env >= 2) {
+        const int fit = 512;
+        while (S < ks_env && tiles * S * 2 <= fit && nch % (S * 2) == 0 && nch / (S * 2) >= 8) S *= 2;
+      }
+      ab.ksplit = S; ab.kslab = kslab; ab.kctr = kctr;
+      grid = dim3(tiles * S);
+      SERL_LAUNCH_CONV(2, 2, 1, 1, 3);
+      if (plan) plan->ksplit = S;
+    }
     // (K-split of the small-M convs -- 2..8 workgroups per 64x64 tile, slabs reduced by the statistics kernel -- halved
     //  b3_conv1 at a per-rank batch of 32 but needed a statistics launch per conv: the step got slower; removed in round 3)
 #undef SERL_LAUNCH_CONV
@@ -1972,11 +2055,11 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     const bool raw_in = i == 0 && raw_b0;
     const RawInput rin{ws.raw_init, gn_init};
     if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
-                                raw_in ? &rin : nullptr, &ws.plan.conv[i][0]))) return rc;
+                                raw_in ? &rin : nullptr, &ws.plan.conv[i][0], ws.kslab, ws.kctr))) return rc;
     SERL_REQUIRE(!raw_in || fz0.mode, "block 0 was planned on the fused row-slab path");
     if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero, nullptr,
-                                  nullptr, &ws.plan.conv[i][2]))) return rc;
+                                  nullptr, &ws.plan.conv[i][2], ws.kslab, ws.kctr))) return rc;
     const long tot = (long)N * P * (f / 4);
     if (!fz0.mode) {
       ProfScope prof("gn_relu_split", stream);
@@ -1998,7 +2081,7 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
     if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1,
-                                nullptr, &ws.plan.conv[i][1]))) return rc;
+                                nullptr, &ws.plan.conv[i][1], ws.kslab, ws.kctr))) return rc;
     SERL_REQUIRE(!raw_in || fz1.mode, "block 0 was planned on the fused row-slab path");
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
