@@ -21,7 +21,7 @@ long small_conv_offset(int layer);   // offset of layer's kernel inside that blo
 struct SmallWorkspace {
   SmallDims d{};
   int max_images = 0;             // images per pass (all cameras together)
-  float* col[kSmallLayers]{};     // layer 0 only: explicit im2col [rows_0][ldk_0] of the u8 frames (ones column appended)
+  float* col[kSmallLayers]{};     // (unused since round 4: layer 0 reads the u8 frames directly)
   int* tab[kSmallLayers]{};       // layers 1..3: offset of every im2col row's patch in the layer's NHWC input (implicit GEMM)
   bool tab_ready = false;
   float* act[kSmallLayers]{};     // ReLU outputs [rows_l][cout_l]
@@ -30,6 +30,9 @@ struct SmallWorkspace {
   float* dcol = nullptr;          // gradient wrt an im2col matrix
   float* slabs = nullptr;         // split-K partials of the weight-gradient GEMMs
   long slabs_cap = 0;
+  // layer 0 runs directly on the u8 frames (no im2col matrix): the backward pass re-reads the frames of the last forward pass
+  const uint8_t* last_frames = nullptr;
+  long last_frame_cam_stride = 0;
   size_t bytes = 0;
 };
 size_t small_workspace_bytes(int max_images, int H, int W);

@@ -9,7 +9,8 @@
 // GEMMs: the im2col matrix is never written -- the GEMM's operand loader gathers a patch row from the NHWC activations (one
 // kernel row = 3*cin contiguous floats; GemmDesc::gtab holds every row's patch offset), forward and weight gradient alike, and
 // ReLU is the forward GEMM's epilogue.  (Round 2 wrote explicit im2col matrices: 1.2 GB per pass, 46 % of the step.)  Layer 0
-// (u8 frames, K = 27) keeps its explicit im2col; the input gradient is dcol = dy x W^T followed by a col2im gather.
+// (u8 frames, K = 27) runs on the frames directly with fp32 FMAs, forward and weight gradient (round 4: small_conv0_*_kernel);
+// the input gradient of layers 1..3 is dcol = dy x W^T followed by a col2im gather.
 #include <algorithm>
 
 #include "heads.h"
@@ -35,6 +36,7 @@ long small_conv_offset(int layer) {
 }
 long small_conv_params() { return small_conv_offset(kSmallLayers); }
 
+constexpr int kConv0Chunks = 256, kSmallMaxCams = 4;   // layer 0's weight gradient: row chunks per camera / cameras
 static int ldk(int l) { return (9 * kSmallFeat[l] + 1 + 3) & ~3; }   // row pitch of col_l: K + 1 rounded up to 4 floats
 static long rows_of(const SmallDims& d, int l, long n_img) { return n_img * d.h[l + 1] * d.w[l + 1]; }
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -47,8 +49,7 @@ static size_t carve(SmallWorkspace& ws, uint8_t* base, int max_images, int H, in
   long max_act = 0, max_col = 0;
   for (int l = 0; l < kSmallLayers; ++l) {
     const long r = rows_of(ws.d, l, max_images);
-    if (l == 0) ws.col[l] = take((size_t)r * ldk(l));
-    else ws.tab[l] = reinterpret_cast<int*>(take((size_t)r));
+    if (l > 0) ws.tab[l] = reinterpret_cast<int*>(take((size_t)r));
     ws.act[l] = take((size_t)r * kSmallFeat[l + 1]);
     max_act = std::max(max_act, r * kSmallFeat[l + 1]);
     if (l > 0) max_col = std::max(max_col, r * ldk(l));
@@ -57,7 +58,7 @@ static size_t carve(SmallWorkspace& ws, uint8_t* base, int max_images, int H, in
   ws.dact = take(max_act);
   ws.dact2 = take(max_act);
   ws.dcol = take(max_col);
-  ws.slabs_cap = 64L * (9 * 128 + 1) * 256;   // up to 64 K-slices of the largest [K+1][cout] gradient
+  ws.slabs_cap = std::max(64L * (9 * 128 + 1) * 256, (long)kConv0Chunks * kSmallMaxCams * 28 * 32);   // up to 64 K-slices of the largest [K+1][cout] gradient / layer 0's row chunks
   ws.slabs = take(ws.slabs_cap);
   ws.bytes = off;
   return off;
@@ -102,6 +103,100 @@ __global__ __launch_bounds__(256) void small_im2col_kernel(const void* xin, floa
     const float* p = static_cast<const float*>(xin) + src;
     for (int c = 0; c < cin; c += 4) *reinterpret_cast<float4*>(dst + tap * cin + c) = *reinterpret_cast<const float4*>(p + c);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer 0 (3 -> 32 channels, K = 27) directly on the u8 frames, fp32 FMAs: no im2col matrix (round 3 wrote and re-read 450 MB
+// of it per forward pass: an im2col launch of 120 us + a K = 28 GEMM whose bf16 split costs more than its MFMAs).
+// Forward: a thread = (output pixel, 8 output channels); the 28 x 32 parameter block ([27 taps][32] kernel + bias row) sits in
+// LDS, a thread reads its 3 x 9 bytes with three 8-byte + three 1-byte loads.  act = relu(bias + sum_t px_t / 255 * w_t).
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) U64Unaligned { unsigned long long v; };
+
+__global__ __launch_bounds__(256) void small_conv0_fwd_kernel(const uint8_t* frames, const float* P, long cam_stride, float* act,
+                                                             long rows_cam, int n_per_cam, long frame_cam_stride, int hi, int wi,
+                                                             int ho, int wo) {
+  __shared__ float Ws[28 * 32];
+  const int cam = blockIdx.y, tid = threadIdx.x;
+  const float* Wg = P + (long)cam * cam_stride;
+  for (int i = tid; i < 28 * 32; i += 256) Ws[i] = Wg[i];
+  __syncthreads();
+  const long e = (long)blockIdx.x * 256 + tid;
+  const long m = e >> 2;
+  const int cg = (int)(e & 3) * 8;
+  if (m >= rows_cam) return;
+  const long n = m / ((long)ho * wo);
+  const int rem = (int)(m - n * (long)ho * wo), oy = rem / wo, ox = rem - oy * wo;
+  const uint8_t* px = frames + ((((long)cam * frame_cam_stride + n) * hi + 2 * oy) * wi + 2 * ox) * 3;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = Ws[27 * 32 + cg + j];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const uint8_t* q = px + (long)ky * wi * 3;
+    const unsigned long long lo = reinterpret_cast<const U64Unaligned*>(q)->v;
+    const unsigned b8 = q[8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float x = (float)(t < 8 ? (unsigned)((lo >> (8 * t)) & 0xffu) : b8) / 255.0f;   // small_encoders.py:23
+      const float* w = Ws + (ky * 9 + t) * 32 + cg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += x * w[j];
+    }
+  }
+  float* o = act + ((long)cam * rows_cam + m) * 32 + cg;
+  *reinterpret_cast<float4*>(o) = make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+  *reinterpret_cast<float4*>(o + 4) = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
+}
+
+// Layer 0's parameter gradient [27 taps + bias][32] = sum over the rows of (patch / 255 | 1)^T x dy, per camera: a workgroup
+// walks a contiguous chunk of rows, 32 at a time through LDS (patch values and dy rows), thread (k-group, 4 output channels)
+// accumulates four k's x ... ; per-chunk partials are added in chunk order by reduce_slabs (deterministic).
+__global__ __launch_bounds__(256) void small_conv0_wgrad_kernel(const uint8_t* frames, const float* dy, float* part, long rows_cam,
+                                                               int n_per_cam, long frame_cam_stride, int hi, int wi, int ho, int wo,
+                                                               int chunks) {
+  __shared__ float sx[32][29];
+  __shared__ __attribute__((aligned(16))) float sdy[32][32];
+  const int cam = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const long per = (rows_cam + chunks - 1) / chunks;
+  const long r0 = (long)chunk * per, r1 = min(rows_cam, r0 + per);
+  const int co4 = (tid & 7) * 4, kg = tid >> 3;   // thread: output channels co4..co4+3, patch column kg (0..27 used)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long rb = r0; rb < r1; rb += 32) {
+    __syncthreads();
+    {  // stage 32 rows: thread -> (row tid >> 3, four values): dy as one float4, patch columns 4 * (tid & 7) .. + 3
+      const int r = tid >> 3, c4 = (tid & 7) * 4;
+      const long m = rb + r;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      float xv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (m < r1) {
+        d = *reinterpret_cast<const float4*>(dy + ((long)cam * rows_cam + m) * 32 + c4);
+        const long n = m / ((long)ho * wo);
+        const int rem = (int)(m - n * (long)ho * wo), oy = rem / wo, ox = rem - oy * wo;
+        const uint8_t* px = frames + ((((long)cam * frame_cam_stride + n) * hi + 2 * oy) * wi + 2 * ox) * 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = c4 + j;   // patch column: ky * 9 + (kx * 3 + c); 27 = the ones column
+          if (k < 27) xv[j] = (float)px[(long)(k / 9) * wi * 3 + (k % 9)] / 255.0f;
+          else if (k == 27) xv[j] = 1.0f;
+        }
+      }
+      *reinterpret_cast<float4*>(&sdy[r][c4]) = d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c4 + j < 28) sx[r][c4 + j] = xv[j];
+    }
+    __syncthreads();
+    if (kg < 28) {
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) {
+        const float x = sx[r][kg];
+        const float4 d = *reinterpret_cast<const float4*>(&sdy[r][co4]);
+        acc[0] += x * d.x; acc[1] += x * d.y; acc[2] += x * d.z; acc[3] += x * d.w;
+      }
+    }
+  }
+  if (kg < 28) *reinterpret_cast<float4*>(part + (((long)cam * chunks + chunk) * 28 + kg) * 32 + co4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // tab[m] = offset (floats) of the first element of im2col row m = (image, oy, ox) in the layer's NHWC input
@@ -191,12 +286,14 @@ int small_forward(SmallWorkspace& ws, const float* P, long conv_off, long cam_st
     const int cin = kSmallFeat[l], cout = kSmallFeat[l + 1], K = 9 * cin + 1, pitch = ldk(l);
     const long rows = rows_of(d, l, n_img), rows_cam = rows_of(d, l, n);
     GemmDesc g{};   // act[cam] = relu(col[cam] ([rows_cam][K+1]) x [kernel ; bias]_cam ([K+1][cout]))
-    if (l == 0) {
-      const long tot = rows * 10;
-      hipLaunchKernelGGL(small_im2col_kernel<true>, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const void*)frames, ws.col[0],
-                         rows, d.h[0], d.w[0], d.h[1], d.w[1], cin, pitch, n, frame_cam_stride);
+    if (l == 0) {   // directly on the u8 frames, fp32 FMAs (no im2col matrix, no GEMM)
+      SERL_REQUIRE(n_cam <= kSmallMaxCams, "SmallEncoder: at most %d cameras", kSmallMaxCams);
+      hipLaunchKernelGGL(small_conv0_fwd_kernel, dim3(cdiv(rows_cam * 4, 256), n_cam), dim3(256), 0, stream, frames,
+                         P + conv_off, cam_stride, ws.act[0], rows_cam, n, frame_cam_stride, d.h[0], d.w[0], d.h[1], d.w[1]);
       SERL_HIP(hipGetLastError());
-      g.A = ws.col[0]; g.sAm = pitch; g.sAk = 1; g.sAb = rows_cam * pitch;
+      ws.last_frames = frames; ws.last_frame_cam_stride = frame_cam_stride;
+      (void)rows; (void)pitch;
+      continue;
     } else {
       g.A = ws.act[l - 1]; g.sAm = 0; g.sAk = 1; g.sAb = 0;
       g.gtab = ws.tab[l]; g.gseg = 3 * cin; g.gkbias = 9 * cin; g.gpitch = (long)d.w[l] * cin;
@@ -228,13 +325,21 @@ int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_s
   for (int l = kSmallLayers - 1; l >= 0; --l) {
     const int cin = kSmallFeat[l], cout = kSmallFeat[l + 1], K = 9 * cin + 1, pitch = ldk(l);
     const long rows_cam = rows_of(d, l, n);
+    if (l == 0) {   // straight from the u8 frames of the forward pass: per-chunk partial sums, added in chunk order
+      SERL_REQUIRE(ws.last_frames != nullptr, "small_backward without a forward pass");
+      const int chunks = (int)std::min<long>(kConv0Chunks, std::max<long>(1, rows_cam / 256));
+      hipLaunchKernelGGL(small_conv0_wgrad_kernel, dim3(chunks, n_cam), dim3(256), 0, stream, ws.last_frames, dy, ws.slabs, rows_cam, n,
+                         ws.last_frame_cam_stride, d.h[0], d.w[0], d.h[1], d.w[1], chunks);
+      SERL_HIP(hipGetLastError());
+      int rc = reduce_slabs(ws.slabs, chunks, 28L * 32, n_cam, 28, 32, nullptr, 0, G + conv_off, 32, cam_stride, false, stream);
+      if (rc) return rc;
+      break;   // the pixels need no gradient
+    }
     {  // [dkernel ; dbias]_cam = col_cam^T x dy_cam, K-split over the rows, written into the gradient arena
       int S = (int)std::min<long>(64, std::max<long>(1, rows_cam / 2048));
       while (S > 1 && (long)S * n_cam * K * cout > ws.slabs_cap) S >>= 1;
       GemmDesc g{};
-      if (l == 0) {
-        g.A = ws.col[0]; g.sAm = 1; g.sAk = pitch; g.sAb = rows_cam * pitch;
-      } else {   // col_l^T gathered from the layer's input activations (still in the workspace)
+      {   // col_l^T gathered from the layer's input activations (still in the workspace)
         g.A = ws.act[l - 1]; g.sAm = 1; g.sAk = 0; g.sAb = 0;
         g.gtab = ws.tab[l]; g.gseg = 3 * cin; g.gkbias = 9 * cin; g.gpitch = (long)d.w[l] * cin;
       }

@@ -1873,7 +1873,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       // the whole K range at global-load latency (b3_conv1 at 128 images: 256 workgroups x 144 chunks = 85-91 us).  K-SPLIT: 2 or
       // 4 workgroups per tile, partial tiles summed by the last arriver (conv_igemm_f16x3_kernel) -- no extra launch
       const int tiles = a.tiles_m * a.tiles_n, nch = ksz * ksz * (Cin >> 5);
-      static const int ks_env = []() { const char* e = getenv("SERL_CONV_KSPLIT"); return e ? atoi(e) : -1; }();
+      const char* ks_e = getenv("SERL_CONV_KSPLIT");   // (read per launch: the parity test flips it inside one process)
+      const int ks_env = ks_e ? atoi(ks_e) : -1;
       int S = 1;
       // OPT-IN (SERL_CONV_KSPLIT=n >= 2: at most n workgroups per tile).  Measured at 128 / 256 images (profiles/README.md round
       // 4): two workgroups per tile speed the KERNELS up while the split launch still fits one round of the chip (b3 at 128

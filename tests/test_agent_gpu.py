@@ -33,6 +33,24 @@ def test_trunk_forward(gpu, H, W, n, mode):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("ksplit", [2, 4])
+def test_trunk_forward_with_the_opt_in_conv_k_split(gpu, ksplit, monkeypatch):
+    """SERL_CONV_KSPLIT: 2 / 4 workgroups per 64x64 tile of the small-M conv kernel, partial tiles summed by the last arriver
+    (trunk_f16x3.hip; a rank's share of a data-parallel batch).  Same 5e-6 bound, and the plan must show the split."""
+    monkeypatch.setenv("SERL_CONV_KSPLIT", str(ksplit))
+    for H, n in ((64, 6), (128, 70)):
+        cfg = O.Config(image_keys=("a",), H=H, W=H, S=4, A=2)
+        st, core = AH.make_pair(cfg, B=max(n, 4), trunk_mode="f16x3")
+        img = np.random.default_rng(1).integers(0, 256, (n, H, H, 3), dtype=np.uint8)
+        ref = O.trunk_forward(st.trunk, torch.tensor(img), torch.float64).numpy()
+        got = core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+        plan = core.trunk_plan()
+        assert any(len(v) == 5 and v[4] >= 2 for v in plan.values() if isinstance(v, tuple)), plan
+        err = AH.rel_err(got, ref)
+        print(f"trunk f16x3 {H}x{H} n={n} K-split {ksplit}: rel err vs fp64 = {err:.2e}")
+        assert err < 5e-6, err
+
+
 def _pretrained_like_trunk(trunk, seed=3):
     """Weight statistics a trained ImageNet ResNet with GroupNorm shows and kaiming-normal init does not: a wide
     per-output-channel spread of kernel magnitudes (nearly dead channels and a few very strong ones), first-layer
