@@ -12,6 +12,7 @@
 // (u8 frames, K = 27) runs on the frames directly with fp32 FMAs, forward and weight gradient (round 4: small_conv0_*_kernel);
 // the input gradient of layers 1..3 is dcol = dy x W^T followed by a col2im gather.
 #include <algorithm>
+#include <cstdlib>
 
 #include "heads.h"
 #include "prof.h"
@@ -36,7 +37,7 @@ long small_conv_offset(int layer) {
 }
 long small_conv_params() { return small_conv_offset(kSmallLayers); }
 
-constexpr int kConv0Chunks = 256, kSmallMaxCams = 4;   // layer 0's weight gradient: row chunks per camera / cameras
+constexpr int kConv0Chunks = 1024, kSmallMaxCams = 4;   // layer 0's weight gradient: row chunks per camera / cameras
 static int ldk(int l) { return (9 * kSmallFeat[l] + 1 + 3) & ~3; }   // row pitch of col_l: K + 1 rounded up to 4 floats
 static long rows_of(const SmallDims& d, int l, long n_img) { return n_img * d.h[l + 1] * d.w[l + 1]; }
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -117,9 +118,11 @@ __global__ __launch_bounds__(256) void small_conv0_fwd_kernel(const uint8_t* fra
                                                              long rows_cam, int n_per_cam, long frame_cam_stride, int hi, int wi,
                                                              int ho, int wo) {
   __shared__ float Ws[28 * 32];
+  __shared__ float lut[256];   // byte -> byte / 255.0f (the division's exact result, once per workgroup instead of 27x per thread)
   const int cam = blockIdx.y, tid = threadIdx.x;
   const float* Wg = P + (long)cam * cam_stride;
   for (int i = tid; i < 28 * 32; i += 256) Ws[i] = Wg[i];
+  lut[tid] = (float)tid / 255.0f;
   __syncthreads();
   const long e = (long)blockIdx.x * 256 + tid;
   const long m = e >> 2;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void small_conv0_fwd_kernel(const uint8_t* fra
     const unsigned b8 = q[8];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float x = (float)(t < 8 ? (unsigned)((lo >> (8 * t)) & 0xffu) : b8) / 255.0f;   // small_encoders.py:23
+      const float x = lut[t < 8 ? (unsigned)((lo >> (8 * t)) & 0xffu) : b8];   // x / 255 (small_encoders.py:23)
       const float* w = Ws + (ky * 9 + t) * 32 + cg;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] += x * w[j];
@@ -149,54 +152,85 @@ __global__ __launch_bounds__(256) void small_conv0_fwd_kernel(const uint8_t* fra
   *reinterpret_cast<float4*>(o + 4) = make_float4(fmaxf(acc[4], 0.f), fmaxf(acc[5], 0.f), fmaxf(acc[6], 0.f), fmaxf(acc[7], 0.f));
 }
 
-// Layer 0's parameter gradient [27 taps + bias][32] = sum over the rows of (patch / 255 | 1)^T x dy, per camera: a workgroup
-// walks a contiguous chunk of rows, 32 at a time through LDS (patch values and dy rows), thread (k-group, 4 output channels)
-// accumulates four k's x ... ; per-chunk partials are added in chunk order by reduce_slabs (deterministic).
+// Layer 0's parameter gradient [27 taps + bias][32] = sum over the rows of (patch / 255 | 1)^T x dy, per camera, on the EXACT
+// fp32 matrix pipe (v_mfma_f32_32x32x2_f32: D[32 x 32] += A[32 x 2] B[2 x 32]): one MFMA takes TWO rows -- lane l supplies
+// A[i = l & 31][k = l >> 5] = patch value i of row k (a byte through the LUT; i = 27 is the ones column, i > 27 zero) and
+// B[k][j = l & 31] = dy[row k][j] -- so there is no LDS staging and no operand split at all.  A wave walks its share of the
+// rows; the four waves of a workgroup add their 32 x 32 accumulators through LDS in wave order; per-workgroup partials are added
+// in workgroup order by small_reduce_chunks_kernel.  (The first round-4 version staged 32 rows at a time through LDS for fp32
+// FMAs: LDS-bound, 296 us + 60 us for a serial 256-slab reduce_slabs.)
+typedef float f32x16s __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void small_conv0_wgrad_kernel(const uint8_t* frames, const float* dy, float* part, long rows_cam,
                                                                int n_per_cam, long frame_cam_stride, int hi, int wi, int ho, int wo,
                                                                int chunks) {
-  __shared__ float sx[32][29];
-  __shared__ __attribute__((aligned(16))) float sdy[32][32];
-  const int cam = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  const long per = (rows_cam + chunks - 1) / chunks;
+  __shared__ float lut[256];
+  __shared__ float red[3][32 * 32];
+  const int cam = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  lut[tid] = (float)tid / 255.0f;
+  __syncthreads();
+  const long per = ((rows_cam + chunks - 1) / chunks + 7) & ~7L;       // rows per workgroup, a multiple of 8 (2 per MFMA x 4 waves)
   const long r0 = (long)chunk * per, r1 = min(rows_cam, r0 + per);
-  const int co4 = (tid & 7) * 4, kg = tid >> 3;   // thread: output channels co4..co4+3, patch column kg (0..27 used)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long rb = r0; rb < r1; rb += 32) {
-    __syncthreads();
-    {  // stage 32 rows: thread -> (row tid >> 3, four values): dy as one float4, patch columns 4 * (tid & 7) .. + 3
-      const int r = tid >> 3, c4 = (tid & 7) * 4;
-      const long m = rb + r;
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      float xv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (m < r1) {
-        d = *reinterpret_cast<const float4*>(dy + ((long)cam * rows_cam + m) * 32 + c4);
-        const long n = m / ((long)ho * wo);
-        const int rem = (int)(m - n * (long)ho * wo), oy = rem / wo, ox = rem - oy * wo;
-        const uint8_t* px = frames + ((((long)cam * frame_cam_stride + n) * hi + 2 * oy) * wi + 2 * ox) * 3;
+  const int i = lane & 31, kk = lane >> 5;
+  const int poff = i < 27 ? (i / 9) * wi * 3 + (i % 9) : 0;            // byte offset of patch value i inside the patch
+  f32x16s acc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = c4 + j;   // patch column: ky * 9 + (kx * 3 + c); 27 = the ones column
-          if (k < 27) xv[j] = (float)px[(long)(k / 9) * wi * 3 + (k % 9)] / 255.0f;
-          else if (k == 27) xv[j] = 1.0f;
-        }
-      }
-      *reinterpret_cast<float4*>(&sdy[r][c4]) = d;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // this lane's rows: r0 + 2 * wave + kk, + 8, + 16, ...; (image, oy, ox) are carried along instead of divided out per row,
+  // and eight rows' loads are in flight before their eight MFMAs
+  long m = r0 + 2 * wave + kk;
+  const long hw = (long)ho * wo;
+  long n = min(m, rows_cam - 1) / hw;
+  int rem = (int)(min(m, rows_cam - 1) - n * hw), oy = rem / wo, ox = rem - oy * wo;
+  const uint8_t* img = frames + (long)cam * frame_cam_stride * hi * wi * 3 + poff;
+  const float* dyc = dy + (long)cam * rows_cam * 32 + i;
+  while (m - kk < r1) {   // (wave-uniform: both half-waves advance together)
+    float a[8], b[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c4 + j < 28) sx[r][c4 + j] = xv[j];
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = m < r1;
+      const long pix = ((n * hi + 2 * oy) * (long)wi + 2 * ox) * 3;
+      a[u] = (ok && i < 27) ? lut[img[ok ? pix : 0]] : ((ok && i == 27) ? 1.0f : 0.f);
+      b[u] = ok ? dyc[m * 32] : 0.f;
+      m += 8; ox += 8;
+      if (ox >= wo) { ox -= wo; if (++oy >= ho) { oy = 0; ++n; } }
     }
-    __syncthreads();
-    if (kg < 28) {
-#pragma unroll 8
-      for (int r = 0; r < 32; ++r) {
-        const float x = sx[r][kg];
-        const float4 d = *reinterpret_cast<const float4*>(&sdy[r][co4]);
-        acc[0] += x * d.x; acc[1] += x * d.y; acc[2] += x * d.z; acc[3] += x * d.w;
-      }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  // C layout: acc[r] = D[row (r & 3) + 8 (r >> 2) + 4 kk][col i]; waves 1..3 hand theirs over, wave 0 adds them in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][((r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* o = part + ((long)cam * chunks + chunk) * 28 * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      const float v = ((acc[r] + red[0][row * 32 + i]) + red[1][row * 32 + i]) + red[2][row * 32 + i];
+      if (row < 28) o[row * 32 + i] = v;
     }
   }
-  if (kg < 28) *reinterpret_cast<float4*>(part + (((long)cam * chunks + chunk) * 28 + kg) * 32 + co4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// out[cam][e] = sum over the S per-workgroup partials part[cam][s][e], in a fixed order: sixteen waves take the partials
+// s = w, w + 16, ... each, then wave 0 adds the sixteen sums in wave order (deterministic; the generic reduce_slabs walks all S
+// one after the other: 60 us for 256 partials)
+__global__ __launch_bounds__(1024) void small_reduce_chunks_kernel(const float* part, int S, int n_elem, float* out, long out_cam_stride) {
+  __shared__ float red[16][64];
+  const int cam = blockIdx.y, l = threadIdx.x & 63, e = blockIdx.x * 64 + l, w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < n_elem)
+    for (int k = w; k < S; k += 16) s += part[((long)cam * S + k) * n_elem + e];
+  red[w][l] = s;
+  __syncthreads();
+  if (w == 0 && e < n_elem) {
+    float t = red[0][l];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][l];
+    out[(long)cam * out_cam_stride + e] = t;
+  }
 }
 
 // tab[m] = offset (floats) of the first element of im2col row m = (image, oy, ox) in the layer's NHWC input
@@ -327,15 +361,17 @@ int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_s
     const long rows_cam = rows_of(d, l, n);
     if (l == 0) {   // straight from the u8 frames of the forward pass: per-chunk partial sums, added in chunk order
       SERL_REQUIRE(ws.last_frames != nullptr, "small_backward without a forward pass");
-      const int chunks = (int)std::min<long>(kConv0Chunks, std::max<long>(1, rows_cam / 256));
+      const int chunks = (int)std::min<long>(kConv0Chunks, std::max<long>(1, rows_cam / 256));   // one workgroup per chunk (latency-bound: many)
       hipLaunchKernelGGL(small_conv0_wgrad_kernel, dim3(chunks, n_cam), dim3(256), 0, stream, ws.last_frames, dy, ws.slabs, rows_cam, n,
                          ws.last_frame_cam_stride, d.h[0], d.w[0], d.h[1], d.w[1], chunks);
       SERL_HIP(hipGetLastError());
-      int rc = reduce_slabs(ws.slabs, chunks, 28L * 32, n_cam, 28, 32, nullptr, 0, G + conv_off, 32, cam_stride, false, stream);
-      if (rc) return rc;
+      hipLaunchKernelGGL(small_reduce_chunks_kernel, dim3(cdiv(28 * 32, 64), n_cam), dim3(1024), 0, stream, ws.slabs, chunks, 28 * 32,
+                         G + conv_off, cam_stride);
+      SERL_HIP(hipGetLastError());
       break;   // the pixels need no gradient
     }
     {  // [dkernel ; dbias]_cam = col_cam^T x dy_cam, K-split over the rows, written into the gradient arena
+      // (deeper splits -- 512 or 256 rows per workgroup instead of 2048 -- were measured neutral in round 4: 5.84 / 5.87 / 5.89 ms)
       int S = (int)std::min<long>(64, std::max<long>(1, rows_cam / 2048));
       while (S > 1 && (long)S * n_cam * K * cout > ws.slabs_cap) S >>= 1;
       GemmDesc g{};
