@@ -1088,6 +1088,7 @@ struct ConvInitArgsB {
   int chunk;            // tiles per scheduling chunk (divides tiles_y * tiles_x)
   int* ticket;          // chunk ticket (zeroed per pass)
   int stagger;          // s_sleep(127) periods the second workgroup of every CU waits before its first tile (see the kernel)
+  int ablate;           // TIMING EXPERIMENTS ONLY (SERL_CINIT_ABLATE, results are wrong): 1 no patch fill, 2 no MFMAs, 4 no pooling epilogue, 8 no pixel fetch
 };
 
 constexpr int kCbPatch = 37;     // input rows/cols per 16x16 output tile
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   uint8_t* w_hi = smemb;
   uint8_t* w_lo = smemb + kC8WBytes;
   uint8_t* patch = smemb + 2 * kC8WBytes;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: `wave == 3` is a uniform branch)
   const int li = lane & 31, lh = lane >> 5;
   for (int v = tid; v < 2 * 64 * (kC8K / 8); v += 256) {   // resident weights: 64 rows x 28 16-byte slots per plane
     const int plane = v / (64 * 28), r = (v / 28) % 64, sl = v % 28;
@@ -1167,20 +1168,24 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       if (aligned) {                                                                                    \
         _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                 \
           const long o_ = min(max(off_ + 4 * d, 0L), img_bytes - 4);                                    \
-          pre[q][d] = m_ ? *reinterpret_cast<const uint32_t*>(a.img + o_) : 0u;                         \
+          pre[q][d] = *reinterpret_cast<const uint32_t*>(a.img + o_);  /* branch-free, see below */     \
         }                                                                                               \
       } else {                                                                                          \
         _Pragma("unroll") for (int d = 0; d < 3; ++d) {                                                 \
           uint32_t w_ = 0;                                                                              \
           _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
             const long o_ = min(max(off_ + 4 * d + e, 0L), img_bytes - 1);                              \
-            w_ |= (m_ ? (uint32_t)a.img[o_] : 0u) << (8 * e);                                           \
+            w_ |= (uint32_t)a.img[o_] << (8 * e);                                                       \
           }                                                                                             \
           pre[q][d] = w_;                                                                               \
         }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
   }
+  // (The fetch is BRANCH-FREE: every address is clamped into the image batch and pixels outside the image are zeroed by pmask
+  // when the patch is filled.  With `m_ ? load : 0` hipcc put every load into its own exec-masked region and an
+  // `s_waitcnt vmcnt(0)` in front of the first one -- which also waits for the previous tile's pooled STORES: the prefetch
+  // cost 42 us per pass in a timing ablation.)
   // Tiles are handed out in CHUNKS of a.chunk consecutive tiles of one image (a.chunk divides tiles_per_img): the
   // GroupNorm partial sums stay in registers across a chunk and are flushed once per chunk (per-tile fp64 atomics of 16
   // workgroups on the same 8 words cost 40 us per pass), and neighbouring tiles share their halo in L2.  The first chunk
@@ -1199,6 +1204,8 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   const int nchunks = a.total_tiles / a.chunk;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
   const float winv[2] = {a.winv[li], a.winv[32 + li]};
+  float sgn[2] = {1.f, 1.f};   // sign of the channel's GroupNorm scale (POOL)
+  if (POOL) { sgn[0] = a.gamma[li] < 0.f ? -1.f : 1.f; sgn[1] = a.gamma[32 + li] < 0.f ? -1.f : 1.f; }
   int chunk = blockIdx.x, next_chunk = 0;
   int tile = chunk * a.chunk, t_end = tile + a.chunk;
   if (chunk < nchunks) SERL_C8_FETCH(tile);
@@ -1216,7 +1223,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = tid + 256 * q;
-      if (t < kTasks) {
+      if (t < kTasks && !(a.ablate & 1)) {
         const int r = t / kGroups, g = t - r * kGroups;
         // bytes 0..11 = pixels 0..3 x (c0,c1,c2); patch column of pixel j = 4g - 1 + j (column -1 is not stored)
         const uint32_t d0 = pre[q][0], d1 = pre[q][1], d2 = pre[q][2];
@@ -1237,9 +1244,38 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       }
     }
     __syncthreads();
-    if (first_of_chunk) next_chunk = s_next_chunk;   // written before this tile's first barrier
+    if (first_of_chunk) next_chunk = __builtin_amdgcn_readfirstlane(s_next_chunk);   // written before this tile's first barrier; scalar, so that
+                                                                                      // everything derived from the tile index stays uniform
     // next tile's bytes (the first tile of the next chunk after the last one of this chunk), in flight under the MFMAs
-    SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
+    if (!(a.ablate & 8)) SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
+    // POOL == 2: the neighbours' first column / first row (raw values written by this workgroup at earlier tiles), fetched HERE so
+    // that their L2 round trip lies under the MFMAs.  Branch-free (a tile without that neighbour reads its own slot and ignores
+    // the values; `wave == 3` is a scalar branch): loads inside an exec-masked region get an `s_waitcnt vmcnt(0)` right behind them.
+    float nb_col[2][4], nb_row[2][4][3];
+    const bool has_right = POOL == 2 && tx + 1 < a.tiles_x, has_below = POOL == 2 && ty + 1 < a.tiles_y;
+    if (POOL == 2) {
+      {
+        const float* fcn = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + min(tx + 1, a.tiles_x - 1)) * 64 + li;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nb_col[tn][i] = fcn[(size_t)i * a.tiles_x * 64 + tn * 32];
+      }
+      if (wave == 3) {   // (uniform)
+        const float* frn = a.first_rows + (((size_t)n * a.tiles_y + min(ty + 1, a.tiles_y - 1)) * a.Wo + ox0) * 64 + li;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) {
+            const int px = 2 * (2 * (sl >> 1) + lh) + (sl & 1);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int x = min(2 * px + dx, a.Wo - 1 - ox0);   // (the clamped duplicate leaves the max unchanged)
+              nb_row[tn][sl][dx] = frn[(size_t)x * 64 + tn * 32];
+            }
+          }
+      }
+    }
     int abase[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -1254,6 +1290,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    if (!(a.ablate & 2))
 #pragma unroll
     for (int ks = 0; ks < kC8K / 16; ++ks) {
       const int aoff = (ks >> 1) * kC8Pitch + (ks & 1) * 32;   // kernel row ky = ks/2, k-blocks 2(ks&1) + lh
@@ -1273,6 +1310,29 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(apx[tm], blo[tn], acc[tm][tn], 0, 0, 0);
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(apx[tm], bhi[tn], acc[tm][tn], 0, 0, 0);
         }
+    }
+    // Every load of this tile is collected HERE, before the epilogue issues its stores: gfx9 counts loads and stores in one
+    // vmcnt and hipcc waits vmcnt(0) for a load whenever stores are pending too, so a load consumed after the stores (the next
+    // tile's pixels at the next patch fill, the sign of gamma) exposed the stores' whole round trip once per tile.  At this point
+    // the loads are one MFMA loop old; the same wait retires the PREVIOUS tile's stores (first rows / columns included) in front
+    // of this tile's barriers.
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) asm volatile("" : : "v"(pre[q][d]), "v"(acc[1][1][15]));   // (the operand pins it behind the MFMAs)
+    if (POOL == 2) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : : "v"(nb_col[tn][i]), "v"(acc[1][1][15]));
+      if (wave == 3) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) asm volatile("" : : "v"(nb_row[tn][sl][dx]), "v"(acc[1][1][15]));
+      }
     }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -1297,33 +1357,14 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
             q[tn] += v * v;
           }
         }
+    } else if (a.ablate & 4) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) { const float v = acc[tm][tn][r]; s[tn] += v; q[tn] += v * v; }
     } else {  // fused 3x3/2 max-pool (every tile is full)
-      // POOL == 2: the neighbours' first column / first row (raw values written by this workgroup at earlier tiles)
-      float nb_col[2][4], nb_row[2][4][3];
-      const bool has_right = POOL == 2 && tx + 1 < a.tiles_x, has_below = POOL == 2 && ty + 1 < a.tiles_y;
-      if (POOL == 2) {
-        if (has_right && lh) {
-          const float* fcn = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + tx + 1) * 64 + li;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) nb_col[tn][i] = fcn[(size_t)i * a.tiles_x * 64 + tn * 32];
-        }
-        if (has_below && wave == 3) {
-          const float* frn = a.first_rows + (((size_t)n * a.tiles_y + ty + 1) * a.Wo + ox0) * 64 + li;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-              const int px = 2 * (2 * (sl >> 1) + lh) + (sl & 1);
-#pragma unroll
-              for (int dx = 0; dx < 3; ++dx) {
-                const int x = min(2 * px + dx, a.Wo - 1 - ox0);   // (the clamped duplicate leaves the max unchanged)
-                nb_row[tn][sl][dx] = frn[(size_t)x * 64 + tn * 32];
-              }
-            }
-        }
-      }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1359,7 +1400,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       float hrow[2][4][4];   // [tn][row i][px slot = 2q + parity]
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const float sg = a.gamma[tn * 32 + li] < 0.f ? -1.f : 1.f;
+        const float sg = sgn[tn];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float part[2], v0[2];
@@ -1388,7 +1429,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const float sg = a.gamma[tn * 32 + li] < 0.f ? -1.f : 1.f;
+        const float sg = sgn[tn];
         float* orow = a.pooled + (((size_t)n * Hp + (oy0 >> 1) + 2 * wave) * Wp + (ox0 >> 1)) * 64 + tn * 32 + li;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
@@ -1474,8 +1515,10 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   a.ticket = ticket;
   static const int stagger = []() { const char* e = getenv("SERL_CINIT_STAGGER"); return e ? atoi(e) : 2; }();   // 2 x ~4 us = half a tile
   a.stagger = stagger;
+  { const char* e = getenv("SERL_CINIT_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   // 2 persistent workgroups per CU
-  const int grid = std::min(a.total_tiles / a.chunk, 512);
+  static const int max_grid = []() { const char* e = getenv("SERL_CINIT_GRID"); return e ? atoi(e) : 512; }();   // (256 = one workgroup per CU: timing experiments)
+  const int grid = std::min(a.total_tiles / a.chunk, max_grid);
   ProfScope prof("conv_init", stream);
   if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
     SERL_REQUIRE(Ho % 16 == 0 && Wo % 16 == 0, "fused conv_init pooling needs full 16x16 tiles");
