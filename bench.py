@@ -74,7 +74,7 @@ class _DictSp:
         self.spaces = spaces
 
 
-PROFILE_EVERY = 4   # HIP events around every 4th launch of each kernel tag inside the timed region
+PROFILE_EVERY = 4   # HIP events around every 4th launch of each kernel tag inside the timed region (every 16th in long runs: main())
 
 
 def main():
@@ -250,6 +250,12 @@ def main():
         iteration()
     barrier()
     # (SERL_BENCH_NOPROF=1: diagnostic run without the per-kernel HIP events -- measures their overhead)
+    # The timing events are not free: an event pair around a launch serialises it against its neighbours (same call, 100 steps:
+    # 2.535 ms with every 4th launch timed, 2.500 ms with none; profiles/r04_ab_step_boundary.log).  Long runs therefore sample
+    # every 16th launch (>= 20 samples per kernel tag either way).
+    global PROFILE_EVERY
+    if args.steps * max(1, args.repeats) >= 320:
+        PROFILE_EVERY = 16
     _lib.check(_lib.lib().serl_profile_enable(0 if os.environ.get("SERL_BENCH_NOPROF") == "1" else PROFILE_EVERY))
     _lib.check(_lib.lib().serl_profile_reset())
     coll["on"] = True
