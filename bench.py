@@ -236,6 +236,34 @@ def main():
                                   all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on")
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
+    hostprof = {}
+    if os.environ.get("SERL_BENCH_HOSTPROF") == "1":   # diagnostic: where does the HOST spend an iteration (blocked or enqueueing)?
+        def _wrap(obj, name):
+            f = getattr(obj, name)
+            def g(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return f(*a, **k)
+                finally:
+                    e = hostprof.setdefault(name, [0.0, 0])
+                    e[0] += time.perf_counter() - t; e[1] += 1
+            setattr(obj, name, g)
+        for nm in ("wait_consumed", "wait_produced", "produced", "consumed"):
+            if hasattr(sched, nm):
+                _wrap(sched, nm)
+        for nm in ("encode_slot", "select_slot", "begin_update", "critic_grads", "actor_grads", "apply"):
+            _wrap(core, nm)
+        _wrap(learner, "gather")
+        _q = {"ready": 0, "n": 0}
+        if hasattr(sched, "ev_cons"):
+            _wc = sched.wait_consumed
+            def _wc2(slot):
+                ev = sched.ev_cons[slot]
+                if ev is not None:
+                    _q["n"] += 1; _q["ready"] += int(ev.query())
+                return _wc(slot)
+            sched.wait_consumed = _wc2
+        hostprof["_cons_event_ready"] = _q
 
     def iteration():
         learner.iteration(car)
@@ -268,6 +296,9 @@ def main():
         barrier()
         dts.append(time.perf_counter() - t0)
     coll["on"] = False
+    if hostprof:
+        sys.stderr.write("HOSTPROF " + json.dumps({k: (v if isinstance(v, dict) else {"ms_per_call": round(1e3 * v[0] / max(v[1], 1), 4), "calls": v[1]})
+                                                   for k, v in hostprof.items()}) + "\n")
     prof = _lib.profile_read()
     _lib.check(_lib.lib().serl_profile_enable(0))
     torch.cuda.synchronize()
