@@ -1249,20 +1249,23 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     // next tile's bytes (the first tile of the next chunk after the last one of this chunk), in flight under the MFMAs
     if (!(a.ablate & 8)) SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
     // POOL == 2: the neighbours' first column / first row (raw values written by this workgroup at earlier tiles), fetched HERE so
-    // that their L2 round trip lies under the MFMAs.  Branch-free (a tile without that neighbour reads its own slot and ignores
-    // the values; `wave == 3` is a scalar branch): loads inside an exec-masked region get an `s_waitcnt vmcnt(0)` right behind them.
+    // that their L2 round trip lies under the MFMAs.  Branch-free (a tile without that neighbour reads elsewhere and ignores the
+    // values; `wave == 3` is a scalar branch): loads inside an exec-masked region get an `s_waitcnt vmcnt(0)` right behind them.
     float nb_col[2][4], nb_row[2][4][3];
     const bool has_right = POOL == 2 && tx + 1 < a.tiles_x, has_below = POOL == 2 && ty + 1 < a.tiles_y;
     if (POOL == 2) {
+      // (a tile WITHOUT that neighbour reads the resident weights instead -- never a first_rows / first_cols slot that this
+      //  workgroup is still going to write: the CU's L1 must not hold a pre-write copy of a line a later tile reads back)
+      const float* dummy = reinterpret_cast<const float*>(a.whi) + li;   // >= 7168 floats; offsets below stay under 1100
       {
-        const float* fcn = a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + min(tx + 1, a.tiles_x - 1)) * 64 + li;
+        const float* fcn = has_right ? a.first_cols + (((size_t)n * a.Ho + oy0 + wave * 4) * a.tiles_x + tx + 1) * 64 + li : dummy;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) nb_col[tn][i] = fcn[(size_t)i * a.tiles_x * 64 + tn * 32];
+          for (int i = 0; i < 4; ++i) nb_col[tn][i] = fcn[has_right ? (size_t)i * a.tiles_x * 64 + tn * 32 : (size_t)(i * 64 + tn * 32)];
       }
       if (wave == 3) {   // (uniform)
-        const float* frn = a.first_rows + (((size_t)n * a.tiles_y + min(ty + 1, a.tiles_y - 1)) * a.Wo + ox0) * 64 + li;
+        const float* frn = has_below ? a.first_rows + (((size_t)n * a.tiles_y + ty + 1) * a.Wo + ox0) * 64 + li : dummy;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
