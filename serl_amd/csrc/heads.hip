@@ -527,9 +527,12 @@ struct XLoader {
   int gseg = 0, gkbias = 0, gcnt = 0;
   long gpitch = 0;
   bool bias_row = false;      // !KFAST: this thread's tile row is the bias column (all ones)
+  int tpre[BK / 4];           // !KFAST: row offsets of the chunk the NEXT load() call fetches (read one call ahead: the pixel loads
+  int tlast = 0;              //         depend on them, and a dependent pair inside one call would make the fetch synchronous)
   // KFAST (forward): tile rows are im2col rows, k runs along a patch; !KFAST (weight gradient): tile rows are patch columns
   __device__ __forceinline__ void init_gather(const GemmDesc& g, int batch, int r0, int R, int k_begin, int tid) {
     gseg = g.gseg; gkbias = g.gkbias; gpitch = g.gpitch; sK = 1;
+    safe = g.A;
     if (KFAST) {
       tab = g.gtab + (long)batch * g.M;
       const int ky = k_begin / gseg;
@@ -542,12 +545,15 @@ struct XLoader {
       }
     } else {
       tab = g.gtab + (long)batch * g.K;
+      tlast = g.K - 1;
       row0 = tid & 63; kq = NE * (tid >> 6);
       const int kcol = r0 + row0;
       ok[0] = kcol < R;
       bias_row = kcol == gkbias;
       const int ky = min(kcol, gkbias - 1) / gseg;
       p[0] = g.A + (long)ky * gpitch + (min(kcol, gkbias - 1) - ky * gseg);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) tpre[j] = tab[min(k_begin + kq + j, tlast)];   // row offsets of the FIRST chunk
     }
   }
   __device__ __forceinline__ void init(const float* X, long sR, long sK_, int r0, int R, int k_begin, int tid) {
@@ -568,13 +574,14 @@ struct XLoader {
   }
   // the chunk starting at k0 (elements at k >= k_end are zero); advances to the next chunk
   __device__ __forceinline__ void load(float (&r)[NE], int k0, int k_end) {
-    if (GATHER && tab && KFAST) {   // gather, forward: a chunk lies inside one kernel row (gseg % BK == 0) or is the bias chunk
+    // The gather paths are BRANCH-FREE and UNTOUCHED like the plain ones below (round 4: with each load in its own exec-masked
+    // region the SmallEncoder's GEMMs waited vmcnt(0) right behind every load): an element that does not exist is fetched from
+    // the operand's first element and fixed at LDS-store time by clean().
+    if (GATHER && KFAST) {   // gather, forward: a chunk lies inside one kernel row (gseg % BK == 0) or is the bias chunk
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int k = k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4));
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok[i] && k < gkbias) v = *reinterpret_cast<const f32x4u*>(p[i]);
-        else if (ok[i] && k == gkbias && k < k_end) v[0] = 1.0f;
+        const f32x4 v = *reinterpret_cast<const f32x4u*>((ok[i] && k < gkbias) ? p[i] : safe);
         r[4 * i] = v[0]; r[4 * i + 1] = v[1]; r[4 * i + 2] = v[2]; r[4 * i + 3] = v[3];
         p[i] += BK;
       }
@@ -583,12 +590,11 @@ struct XLoader {
 #pragma unroll
         for (int i = 0; i < NV; ++i) p[i] += gpitch - gseg;
       }
-    } else if (GATHER && tab) {     // gather, weight gradient: k runs over the im2col rows
+    } else if (GATHER) {     // gather, weight gradient: k runs over the im2col rows; this chunk's row offsets were read one call ago
 #pragma unroll
-      for (int j = 0; j < NE; ++j) {
-        const int k = k0 + kq + j;
-        r[j] = (ok[0] && k < k_end) ? (bias_row ? 1.0f : p[0][tab[k]]) : 0.f;
-      }
+      for (int j = 0; j < NE; ++j) r[j] = p[0][tpre[j]];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) tpre[j] = tab[min(k0 + BK + kq + j, tlast)];
     } else if (KFAST) {
       // BRANCH-FREE and UNTOUCHED: the load is always issued (a vector that lies outside the operand is redirected to the
       // operand's first element) and the raw registers are left alone until store() zeroes the invalid elements -- two chunks
@@ -609,9 +615,24 @@ struct XLoader {
       p[0] += (long)BK * sK;
     }
   }
-  // zeroes the elements of chunk k0 that do not exist (rows past the operand, k >= k_end); gather loads arrive clean
+  // zeroes the elements of chunk k0 that do not exist (rows past the operand, k >= k_end) and sets the gather operand's ones
   __device__ __forceinline__ void clean(float (&r)[NE], int k0, int k_end) const {
-    if (GATHER && tab) return;
+    if (GATHER && KFAST) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int k = k0 + 4 * ((threadIdx.x + 256 * i) % (BK / 4));
+        const bool live = ok[i] && k < gkbias, one = ok[i] && k == gkbias && k < k_end;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[4 * i + j] = live ? r[4 * i + j] : 0.f;
+        r[4 * i] = one ? 1.0f : r[4 * i];
+      }
+      return;
+    }
+    if (GATHER) {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) r[j] = (ok[0] && k0 + kq + j < k_end) ? (bias_row ? 1.0f : r[j]) : 0.f;
+      return;
+    }
     if (KFAST) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   if (k_begin < k_end) {
     XLoader<A_KFAST, BK, GATHER> la;
     XLoader<B_KFAST, BK> lb;
-    if (GATHER && g.gtab) la.init_gather(g, batch, m0, g.M, k_begin, tid);
+    if (GATHER) la.init_gather(g, batch, m0, g.M, k_begin, tid);   // (the launcher: every group of a gather launch gathers)
     else la.init(g.A + (long)batch * g.sAb, g.sAm, g.sAk, m0, g.M, k_begin, tid);
     lb.init(g.B + (long)batch * g.sBb, g.sBn, g.sBk, n0, g.N, k_begin, tid);
     // TWO chunks in flight (register sets 0 / 1): a chunk is 4 KB per operand, its MFMAs take ~0.2 us, an L2 / Infinity-Cache
@@ -819,6 +840,7 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
     bool any_tab = false;
     for (int i = 0; i < n; ++i) any_tab = any_tab || gs[i].gtab != nullptr;
     SERL_REQUIRE(!(any_tab && with_ln), "gather GEMM with a LayerNorm epilogue");
+    for (int i = 0; i < n; ++i) SERL_REQUIRE(!any_tab || gs[i].gtab != nullptr, "a gather launch mixes gathered and plain operands");
     if (any_tab) {
       if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16, false, true>), grid, dim3(256), 0, stream, mm);
       else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, false, true>), grid, dim3(256), 0, stream, mm);
