@@ -115,6 +115,7 @@ struct AdamArgs {
   const float* norm2;               // device [2]: squared global norm of g_critic / g_actor (when a clip is active)
   // frozen (trunk) leaves appended to the index space: target EMA, and weight decay if any optimizer has one
   float* frozen; float* frozen_target; long n_frozen;
+  long n_frozen_live; int vec_ok;   // set by adam_ema(): frozen leaves this launch covers; the 4-wide fast path may be used
   // info rider: 0 = none, 1 = critic step, 2 = actor/temperature step.  Slot order of `scalars` / `info_acc` as in
   // agent.hip (S_* / I_* enums); info_acc has 8 floats.
   int info_mode, info_reset;

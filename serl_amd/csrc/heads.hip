@@ -1661,26 +1661,8 @@ int fill(float* p, float v, long n, hipStream_t stream) {
 // A tx that is not in networks_to_update still steps with g = 0 (sac.py:276-277): its moments
 // decay and its momentum keeps moving the parameters.
 // =============================================================================================
-__global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && a.info_mode) {  // info dict of this step (riding along: one launch less on the chain)
-    const float* sc = a.scalars;
-    float* acc = a.info_acc;
-    if (a.info_mode & 1) {  // critic step (sac.py:118-191); weighted mean over UTD minibatches
-      if (a.info_reset)
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-      acc[0] += a.info_w * sc[0] * a.inv_eb;   // critic_loss
-      acc[1] += a.info_w * sc[1] * a.inv_eb;   // predicted_qs
-      acc[2] += a.info_w * sc[2] * a.inv_batch;  // target_qs
-    }
-    if (a.info_mode & 2) {  // actor + temperature step (sac.py:193-234)
-      const float alpha = a.alpha[0];
-      acc[3] = -(sc[3] - alpha * sc[4]) * a.inv_batch;  // actor_loss
-      acc[4] = alpha;                                   // temperature
-      acc[5] = -sc[4] * a.inv_batch;                    // entropy
-      acc[6] = alpha * (-sc[5] * a.inv_batch - a.target_entropy);  // temperature_loss
-    }
-  }
+// one element: the frozen leaves past P, the temperature at P - 1, everything a 4-wide vector cannot take
+__device__ __forceinline__ void adam_elem(const AdamArgs& a, long i, float cs_c, float cs_a) {
   // adamw (optimizers.py:39-42): every optimizer with a weight decay adds -lr*wd*p on EVERY leaf of the tree
   const float wd_total = a.lr_c * a.wd_c + a.lr_a * a.wd_a + a.lr_t * a.wd_t;
   if (i >= a.P) {  // frozen-trunk leaves: no gradient ever reaches them; weight decay and the target EMA still do
@@ -1692,10 +1674,6 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
     }
     return;
   }
-  // clip_by_global_norm (optimizers.py:36-37): g <- g * max_norm / ||g|| when ||g|| >= max_norm
-  float cs_c = 1.f, cs_a = 1.f;
-  if (a.clip_c > 0.f && a.critic_on) { const float n = sqrtf(a.norm2[0]); if (!(n < a.clip_c)) cs_c = a.clip_c / n; }
-  if (a.clip_a > 0.f && a.actor_on) { const float n = sqrtf(a.norm2[1]); if (!(n < a.clip_a)) cs_a = a.clip_a / n; }
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   const float p0 = a.theta[i];
   float ua = 0.f, uc = 0.f, ut = 0.f;
@@ -1736,6 +1714,95 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
   if (a.ema_on) a.theta_target[i] = p * a.tau + a.theta_target[i] * (1.f - a.tau);
 }
 
+// A thread owns FOUR consecutive leaves.  A vector that lies wholly inside or outside each optimizer's support (and does not
+// hold the temperature) takes the fast path: its eight 16-byte loads are issued together, unconditionally (a vector outside a
+// support reads the support's first elements and ignores them), then the arithmetic of adam_elem per element, then the stores.
+// The one-leaf-per-thread kernel of rounds 1-3 put every 4-byte load into its own exec-masked region behind stores that were
+// still in flight (one vmcnt for both): four dependent round trips per thread, 45 us for the critic step.
+__global__ __launch_bounds__(256) void adam_ema_kernel(AdamArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0 && a.info_mode) {  // info dict of this step (riding along: one launch less on the chain)
+    const float* sc = a.scalars;
+    float* acc = a.info_acc;
+    if (a.info_mode & 1) {  // critic step (sac.py:118-191); weighted mean over UTD minibatches
+      if (a.info_reset)
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      acc[0] += a.info_w * sc[0] * a.inv_eb;   // critic_loss
+      acc[1] += a.info_w * sc[1] * a.inv_eb;   // predicted_qs
+      acc[2] += a.info_w * sc[2] * a.inv_batch;  // target_qs
+    }
+    if (a.info_mode & 2) {  // actor + temperature step (sac.py:193-234)
+      const float alpha = a.alpha[0];
+      acc[3] = -(sc[3] - alpha * sc[4]) * a.inv_batch;  // actor_loss
+      acc[4] = alpha;                                   // temperature
+      acc[5] = -sc[4] * a.inv_batch;                    // entropy
+      acc[6] = alpha * (-sc[5] * a.inv_batch - a.target_entropy);  // temperature_loss
+    }
+  }
+  // clip_by_global_norm (optimizers.py:36-37): g <- g * max_norm / ||g|| when ||g|| >= max_norm
+  float cs_c = 1.f, cs_a = 1.f;
+  if (a.clip_c > 0.f && a.critic_on) { const float n = sqrtf(a.norm2[0]); if (!(n < a.clip_c)) cs_c = a.clip_c / n; }
+  if (a.clip_a > 0.f && a.actor_on) { const float n = sqrtf(a.norm2[1]); if (!(n < a.clip_a)) cs_a = a.clip_a / n; }
+  const long i4 = 4 * t;
+  const bool c_all = i4 + 3 < a.Pc, c_none = i4 >= a.Pc;
+  const bool a_all = i4 >= a.Pa0 && i4 + 3 < a.Pa1, a_none = i4 + 3 < a.Pa0 || i4 >= a.Pa1;
+  if (a.vec_ok && i4 + 3 < a.P - 1 && (c_all || c_none) && (a_all || a_none)) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const long ic = c_all ? i4 : 0, ka = a_all ? i4 - a.Pa0 : 0;
+    const float4 p0 = *reinterpret_cast<const float4*>(a.theta + i4);
+    const float4 tt = *reinterpret_cast<const float4*>((a.ema_on ? a.theta_target : a.theta) + i4);
+    const float4 gc = *reinterpret_cast<const float4*>(a.g_critic + ic);
+    const float4 mc = *reinterpret_cast<const float4*>(a.m_c + ic), vc = *reinterpret_cast<const float4*>(a.v_c + ic);
+    // (the actor support starts at an arbitrary leaf offset -- behind the critic head's 1-element bias: its arrays are indexed by
+    //  i - Pa0 and only 4-byte aligned; global 16-byte accesses need no more)
+    const f32x4 ga = *reinterpret_cast<const f32x4u*>(a.g_actor + ka);
+    const f32x4 ma = *reinterpret_cast<const f32x4u*>(a.m_a + ka), va = *reinterpret_cast<const f32x4u*>(a.v_a + ka);
+    const float p0e[4] = {p0.x, p0.y, p0.z, p0.w}, tte[4] = {tt.x, tt.y, tt.z, tt.w};
+    const float gce[4] = {gc.x, gc.y, gc.z, gc.w}, mce[4] = {mc.x, mc.y, mc.z, mc.w}, vce[4] = {vc.x, vc.y, vc.z, vc.w};
+    const float gae[4] = {ga[0], ga[1], ga[2], ga[3]}, mae[4] = {ma[0], ma[1], ma[2], ma[3]}, vae[4] = {va[0], va[1], va[2], va[3]};
+    float pn[4], tn[4], mcn[4], vcn[4], man[4], van[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ua = 0.f, uc = 0.f;
+      {
+        const float g = a.critic_on ? gce[e] * cs_c : 0.f;
+        const float m = b1 * mce[e] + (1.f - b1) * g;
+        const float v = b2 * vce[e] + (1.f - b2) * g * g;
+        mcn[e] = m; vcn[e] = v;
+        if (c_all) uc = -a.lr_c * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
+      }
+      {
+        const float g = a.actor_on ? gae[e] * cs_a : 0.f;
+        const float m = b1 * mae[e] + (1.f - b1) * g;
+        const float v = b2 * vae[e] + (1.f - b2) * g * g;
+        man[e] = m; van[e] = v;
+        if (a_all) ua = -a.lr_a * (m / a.bc1) / (sqrtf(v / a.bc2) + eps);
+      }
+      float ut = 0.f;
+      if (a.wd_a != 0.f) ua -= a.lr_a * a.wd_a * p0e[e];
+      if (a.wd_c != 0.f) uc -= a.lr_c * a.wd_c * p0e[e];
+      if (a.wd_t != 0.f) ut -= a.lr_t * a.wd_t * p0e[e];
+      pn[e] = p0e[e] + ((ua + uc) + ut);
+      tn[e] = pn[e] * a.tau + tte[e] * (1.f - a.tau);
+    }
+    if (c_all) {
+      *reinterpret_cast<float4*>(a.m_c + i4) = make_float4(mcn[0], mcn[1], mcn[2], mcn[3]);
+      *reinterpret_cast<float4*>(a.v_c + i4) = make_float4(vcn[0], vcn[1], vcn[2], vcn[3]);
+    }
+    if (a_all) {
+      *reinterpret_cast<f32x4u*>(a.m_a + ka) = (f32x4){man[0], man[1], man[2], man[3]};
+      *reinterpret_cast<f32x4u*>(a.v_a + ka) = (f32x4){van[0], van[1], van[2], van[3]};
+    }
+    *reinterpret_cast<float4*>(a.theta + i4) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    if (a.ema_on) *reinterpret_cast<float4*>(a.theta_target + i4) = make_float4(tn[0], tn[1], tn[2], tn[3]);
+    return;
+  }
+  const long total = a.P + a.n_frozen_live;
+#pragma unroll 1
+  for (int e = 0; e < 4; ++e)
+    if (i4 + e < total) adam_elem(a, i4 + e, cs_c, cs_a);
+}
+
 // `steps` deferred target-EMA steps of the frozen trunk leaves at once (common.py:124-134 on leaves no gradient or weight decay
 // ever touches): t <- p*tau + t*(1-tau), repeated -- the same expression, hence the same rounding sequence, as adam_ema_kernel
 // applies step by step.  The iteration stops at its fixed point (t no longer changes), which a constant p reaches after a few steps.
@@ -1761,7 +1828,12 @@ int frozen_ema(const float* frozen, float* frozen_target, long n, float tau, lon
 int adam_ema(const AdamArgs& a, hipStream_t stream) {
   ProfScope prof("adam_ema", stream);
   const bool frozen = a.n_frozen > 0 && (a.ema_on || a.wd_c != 0.f || a.wd_a != 0.f || a.wd_t != 0.f);
-  SERL_LAUNCH_CHAIN(adam_ema_kernel, dim3(cdiv(a.P + (frozen ? a.n_frozen : 0), 256)), dim3(256), 0, stream, a);
+  AdamArgs v = a;
+  v.n_frozen_live = frozen ? a.n_frozen : 0;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  v.vec_ok = a.Pc >= 4 && a.Pa1 - a.Pa0 >= 4 && al16(a.theta) && al16(a.theta_target) && al16(a.g_critic) && al16(a.m_c) &&
+             al16(a.v_c) && a.g_critic && a.g_actor && a.m_a && a.v_a;
+  SERL_LAUNCH_CHAIN(adam_ema_kernel, dim3(cdiv(cdiv(a.P + v.n_frozen_live, 4), 256)), dim3(256), 0, stream, v);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }
