@@ -352,30 +352,42 @@ __global__ __launch_bounds__(256) void small_avgpool_bwd_kernel(const float* dpo
 // dx[n][iy][ix][ci] = (x > 0) * sum over taps (ky,kx) with iy-ky = 2*oy, ix-kx = 2*ox in range of dcol[(n,oy,ox)][(ky*3+kx)*cin + ci]
 __global__ __launch_bounds__(256) void small_col2im_kernel(const float* dcol, const float* x, float* dx, long n_img, int hi, int wi,
                                                           int ho, int wo, int cin, int pitch) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  const int c4n = cin / 4;
-  if (e >= n_img * hi * wi * c4n) return;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;   // (the launcher checks that the element count fits 31 bits)
+  const unsigned c4n = cin / 4;
+  if (e >= (unsigned)(n_img * hi * wi) * c4n) return;
   const int c4 = (int)(e % c4n);
-  long t = e / c4n;
-  const int ix = (int)(t % wi);
-  t /= wi;
-  const int iy = (int)(t % hi);
-  const long n = t / hi;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned t = e / c4n;
+  const int ix = (int)(t % (unsigned)wi);
+  t /= (unsigned)wi;
+  const int iy = (int)(t % (unsigned)hi);
+  const long n = t / (unsigned)hi;
+  // Stride 2: a pixel receives from the taps ky = iy mod 2 (+ 2 if that is 0), likewise kx: at most 2 x 2 taps.  All four are
+  // fetched UNCONDITIONALLY from clamped positions and the ones that do not exist are dropped afterwards (same order of
+  // additions as the loop over all nine taps): with a `continue` in front of every load the ten loads of a thread were ten
+  // dependent round trips (125 us per launch on average; profiles/README.md round 4).
+  const float4 a = reinterpret_cast<const float4*>(x)[e];
+  float4 v[2][2];
+  bool ok[2][2];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int y2 = iy - ky;
-    if (y2 < 0 || (y2 & 1) || (y2 >> 1) >= ho) continue;
+  for (int p = 0; p < 2; ++p) {
+    const int ky = (iy & 1) + 2 * p, y2 = iy - ky, oy = y2 >> 1;
+    const bool oky = ky <= 2 && y2 >= 0 && oy < ho;
+    const int oyc = min(max(oy, 0), ho - 1), kyc = min(ky, 2);
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int x2 = ix - kx;
-      if (x2 < 0 || (x2 & 1) || (x2 >> 1) >= wo) continue;
-      const long m = (n * ho + (y2 >> 1)) * wo + (x2 >> 1);
-      const float4 v = *reinterpret_cast<const float4*>(dcol + m * pitch + (ky * 3 + kx) * cin + c4 * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int q = 0; q < 2; ++q) {
+      const int kx = (ix & 1) + 2 * q, x2 = ix - kx, ox = x2 >> 1;
+      ok[p][q] = oky && kx <= 2 && x2 >= 0 && ox < wo;
+      const int oxc = min(max(ox, 0), wo - 1), kxc = min(kx, 2);
+      const long m = (n * ho + oyc) * wo + oxc;
+      v[p][q] = *reinterpret_cast<const float4*>(dcol + m * pitch + (kyc * 3 + kxc) * cin + c4 * 4);
     }
   }
-  const float4 a = reinterpret_cast<const float4*>(x)[e];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (ok[p][q]) { s.x += v[p][q].x; s.y += v[p][q].y; s.z += v[p][q].z; s.w += v[p][q].w; }
   s.x = a.x > 0.f ? s.x : 0.f; s.y = a.y > 0.f ? s.y : 0.f; s.z = a.z > 0.f ? s.z : 0.f; s.w = a.w > 0.f ? s.w : 0.f;
   reinterpret_cast<float4*>(dx)[e] = s;
 }
@@ -504,6 +516,7 @@ int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_s
       if (rc) return rc;
     }
     const long tot = n_img * d.h[l] * d.w[l] * (cin / 4);
+    SERL_REQUIRE(tot < (1L << 31), "SmallEncoder activation too large for 32-bit element indices");
     hipLaunchKernelGGL(small_col2im_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.dcol, ws.act[l - 1], dnext, n_img,
                        d.h[l], d.w[l], d.h[l + 1], d.w[l + 1], cin, pitch);
     SERL_HIP(hipGetLastError());
