@@ -1198,6 +1198,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   // outputs (matrix pipe idle).  The second workgroup of every CU (blocks gridDim.x / 2 ..) starts half a tile late, which puts
   // its output phase under its partner's MFMA phase.  Same-call A/B: conv_init 306 -> 296 us alone, step -0.8 % (serial and
   // pipelined); the phases' times mostly still add up (their cost is issue slots / latency inside a wave, not a shared unit).
+  // Neutral (and off by default) since the epilogue's stores no longer stall the next tile's loads.
   if (a.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
     for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   __shared__ int s_next_chunk;
@@ -1516,7 +1517,8 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   const int tpi = a.tiles_y * a.tiles_x;
   a.chunk = (pool_gamma && complete_pool) ? tpi : (tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1));
   a.ticket = ticket;
-  static const int stagger = []() { const char* e = getenv("SERL_CINIT_STAGGER"); return e ? atoi(e) : 2; }();   // 2 x ~4 us = half a tile
+  // (default off since the load / store reordering of round 4: 247.9 us with 2 periods, 246.4 us with none, same call)
+  static const int stagger = []() { const char* e = getenv("SERL_CINIT_STAGGER"); return e ? atoi(e) : 0; }();   // 2 x ~4 us = half a tile
   a.stagger = stagger;
   { const char* e = getenv("SERL_CINIT_ABLATE"); a.ablate = e ? atoi(e) : 0; }
   // 2 persistent workgroups per CU
