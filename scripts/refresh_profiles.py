@@ -43,17 +43,17 @@ ver = lambda d: (d.get("verify") or {}).get("worst_rel_diff")
 coll = co.get("collective", {})
 rows = f"""| file | what | command |
 |---|---|---|
-| `{RD}_bench.json` | official bench line (replay cap 200k / fill 20k, CAR=1, pipelined, split-fp16 trunk, median of 3 x 200 timed steps: {runs(b)} ms): **{b['value']} grad-steps/s** ({b['ms_per_step']} ms/step). Block-conv family (11 launches per trunk pass, HIP events around every 4th launch inside the timed region, co-running with the update chain; stage-0/1 durations include their fused GroupNorm epilogues): {r['algorithmic_tflops']} algorithmic TFLOP/s = {r['achieved']} TFLOP/s of executed fp16 MFMA = **{100*r['frac']:.1f} %** of the 2.5 PF dense peak (per stage: {r.get('frac_by_stage')}); post-run verification of the co-running fused epilogues: worst relative difference {ver(b):.2e} over {b['verify']['batches_checked']} batches (tolerance {b['verify']['tol']}); `gather_crop_rgb` {r['sample_aug_hbm']['achieved']} TB/s co-running ({se['roofline']['sample_aug_hbm']['achieved']} TB/s alone, `{RD}_bench_serial.json`); CPU port {cb['value']} grad-steps/s on {cb['cores']} cores -> {b['value']/cb['value']:.0f}x | `python bench.py` |
-| `{RD}_bench_serial.json` | no overlap of trunk(i+1) with update(i): {se['value']} grad-steps/s ({se['ms_per_step']} ms = trunk + update chain); per-kernel times here are uncontended: block convs {se['roofline']['achieved']} TFLOP/s executed = {100*se['roofline']['frac']:.1f} % | `python bench.py --no-pipeline --no-cpu-baseline --steps 100` |
-| `{RD}_bench_unfused_gn.json` | official line with the GroupNorm epilogues switched off (separate elementwise passes): {un['value']} grad-steps/s ({un['ms_per_step']} ms); the conv kernels alone then run at {100*un['roofline']['frac']:.1f} % | `SERL_GN_FUSE=0 python bench.py --no-cpu-baseline --steps 100` |
-| `{RD}_bench_gemm_f32.json` | official line with the update chain's GEMMs on the exact fp32 MFMA kernel instead of the bf16x3 one: {gf['value']} grad-steps/s ({gf['ms_per_step']} ms) | `SERL_GEMM=f32 python bench.py --no-cpu-baseline --steps 100` |
+| `{RD}_bench.json` | official bench line (replay cap 200k / fill 20k, CAR=1, pipelined, split-fp16 trunk, median of 3 x 200 timed steps: {runs(b)} ms): **{b['value']} grad-steps/s** ({b['ms_per_step']} ms/step). Block-conv family (11 launches per trunk pass, HIP events around every 16th launch inside the timed region (`roofline.note`), co-running with the update chain; stage-0/1 durations include their fused GroupNorm epilogues): {r['algorithmic_tflops']} algorithmic TFLOP/s = {r['achieved']} TFLOP/s of executed fp16 MFMA = **{100*r['frac']:.1f} %** of the 2.5 PF dense peak (per stage: {r.get('frac_by_stage')}); post-run verification of the co-running fused epilogues: worst relative difference {ver(b):.2e} over {b['verify']['batches_checked']} batches (tolerance {b['verify']['tol']}); `gather_crop_rgb` {r['sample_aug_hbm']['achieved']} TB/s co-running ({se['roofline']['sample_aug_hbm']['achieved']} TB/s alone, `{RD}_bench_serial.json`); CPU port {cb['value']} grad-steps/s on {cb['cores']} cores -> {b['value']/cb['value']:.0f}x | `python bench.py` |
+| `{RD}_bench_serial.json` | no overlap of trunk(i+1) with update(i): {se['value']} grad-steps/s ({se['ms_per_step']} ms = trunk + update chain); per-kernel times here are uncontended: block convs {se['roofline']['achieved']} TFLOP/s executed = {100*se['roofline']['frac']:.1f} % | `python bench.py --no-pipeline --no-cpu-baseline --steps 110` |
+| `{RD}_bench_unfused_gn.json` | official line with the GroupNorm epilogues switched off (separate elementwise passes): {un['value']} grad-steps/s ({un['ms_per_step']} ms); the conv kernels alone then run at {100*un['roofline']['frac']:.1f} % | `SERL_GN_FUSE=0 python bench.py --no-cpu-baseline --steps 110` |
+| `{RD}_bench_gemm_f32.json` | official line with the update chain's GEMMs on the exact fp32 MFMA kernel instead of the bf16x3 one: {gf['value']} grad-steps/s ({gf['ms_per_step']} ms) | `SERL_GEMM=f32 python bench.py --no-cpu-baseline --steps 110` |
 | `{RD}_bench_trunk_f32.json` | exact-fp32 MFMA trunk: {f32['value']} grad-steps/s, conv family {f32['roofline']['achieved']} TFLOP/s = {100*f32['roofline']['frac']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak | `python bench.py --trunk f32 --no-cpu-baseline --steps 40` |
 | `{RD}_bench_car4.json` | critic_actor_ratio 4 (the reference script's default): {c4['value']} grad-steps/s | `python bench.py --car 4 --no-cpu-baseline --steps 50` |
 | `{RD}_bench_drq_demos.json`, `{RD}_bench_peg.json`, `{RD}_bench_fwbw.json` | BASELINE.json configs[2..4] as bench workloads (two HBM replay buffers sampled 50/50 and concatenated on the device; CAR 8 / 8 / 4; batch 256 / 256 / 512; a step = one `update_high_utd` call = CAR grad steps): **{w2['value']} / {w3['value']} / {w4['value']} grad-steps/s** ({w2['ms_per_step']} / {w3['ms_per_step']} / {w4['ms_per_step']} ms per call); verification {ver(w2):.1e} / {ver(w3):.1e} / {ver(w4):.1e} | `python bench.py --workload drq_demos` (`peg`, `fwbw`) |
 | `{RD}_bench_small_encoder.json` | `encoder_type="small"` (trainable SmallEncoder, forward + backward through the encoder every grad step, no frozen trunk): {sm['value']} grad-steps/s ({sm['ms_per_step']} ms); conv stack (implicit GEMMs on the bf16x3 kernel) at {sm['roofline'].get('algorithmic_tflops', sm['roofline']['achieved'])} algorithmic TFLOP/s; round 2 with explicit im2col matrices: 68.0 grad-steps/s | `python bench.py --encoder small --no-cpu-baseline --steps 40` |
-| `{RD}_bench_emulate_world{{2,4,8}}.json` | ONE rank's share (B/N samples, no collective) of an N-GPU data-parallel step on this GPU = upper bound of the strong-scaling step rate before RCCL time: {e2['value']} / {e4['value']} / {e8['value']} grad-steps/s ({e2['ms_per_step']} / {e4['ms_per_step']} / {e8['ms_per_step']} ms) -> {e2['value']/b['value']:.2f}x / {e4['value']/b['value']:.2f}x / {e8['value']/b['value']:.2f}x of 1 GPU | `python bench.py --emulate-world N --steps 100 --no-cpu-baseline` |
-| `{RD}_bench_chain_unfused*.json`, `{RD}_bench_chain_lnepi*.json` | the update chain's variants in the SAME call as the official line (pipelined / one rank's share of 8 / serial): default (fused launches, separate LayerNorm launches: 48 per critic + actor pair) {b['ms_per_step']} / {e8['ms_per_step']} / {se['ms_per_step']} ms; one launch per operation (`SERL_CHAIN_FUSE=0`, the round-3 schedule, 63 launches) {J['bench_chain_unfused']['ms_per_step']} / {J['bench_chain_unfused_emulate_world8']['ms_per_step']} / {J['bench_chain_unfused_serial']['ms_per_step']} ms; LayerNorm + tanh inside the GEMM launches as well (`SERL_CHAIN_LN_EPI=1`, 38 launches) {J['bench_chain_lnepi']['ms_per_step']} / {J['bench_chain_lnepi_emulate_world8']['ms_per_step']} / {J['bench_chain_lnepi_serial']['ms_per_step']} ms; with the RCCL calls really issued on a 1-rank group at B/8: {J['bench_emulate_world8_collective']['ms_per_step']} ms | `SERL_CHAIN_FUSE=0 / SERL_CHAIN_LN_EPI=1 python bench.py [--emulate-world 8] [--no-pipeline] --steps 100 --no-cpu-baseline` |
-| `{RD}_bench_collective_1rank.json` | the N > 1 code path on one rank (RCCL all-reduces really issued, world size 1): {co['value']} grad-steps/s; {coll.get('all_reduces_per_step')} all-reduces per step, {coll.get('bytes_per_step')} bytes; per all-reduce {coll.get('avg_us_by_bytes')} us | `python bench.py --force-collective --no-cpu-baseline --steps 100` |
+| `{RD}_bench_emulate_world{{2,4,8}}.json` | ONE rank's share (B/N samples, no collective) of an N-GPU data-parallel step on this GPU = upper bound of the strong-scaling step rate before RCCL time: {e2['value']} / {e4['value']} / {e8['value']} grad-steps/s ({e2['ms_per_step']} / {e4['ms_per_step']} / {e8['ms_per_step']} ms) -> {e2['value']/b['value']:.2f}x / {e4['value']/b['value']:.2f}x / {e8['value']/b['value']:.2f}x of 1 GPU | `python bench.py --emulate-world N --steps 110 --no-cpu-baseline` |
+| `{RD}_bench_chain_unfused*.json`, `{RD}_bench_chain_lnepi*.json` | the update chain's variants in the SAME call as the official line (pipelined / one rank's share of 8 / serial): default (fused launches, separate LayerNorm launches: 48 per critic + actor pair) {b['ms_per_step']} / {e8['ms_per_step']} / {se['ms_per_step']} ms; one launch per operation (`SERL_CHAIN_FUSE=0`, the round-3 schedule, 63 launches) {J['bench_chain_unfused']['ms_per_step']} / {J['bench_chain_unfused_emulate_world8']['ms_per_step']} / {J['bench_chain_unfused_serial']['ms_per_step']} ms; LayerNorm + tanh inside the GEMM launches as well (`SERL_CHAIN_LN_EPI=1`, 38 launches) {J['bench_chain_lnepi']['ms_per_step']} / {J['bench_chain_lnepi_emulate_world8']['ms_per_step']} / {J['bench_chain_lnepi_serial']['ms_per_step']} ms; with the RCCL calls really issued on a 1-rank group at B/8: {J['bench_emulate_world8_collective']['ms_per_step']} ms | `SERL_CHAIN_FUSE=0 / SERL_CHAIN_LN_EPI=1 python bench.py [--emulate-world 8] [--no-pipeline] --steps 110 --no-cpu-baseline` |
+| `{RD}_bench_collective_1rank.json` | the N > 1 code path on one rank (RCCL all-reduces really issued, world size 1): {co['value']} grad-steps/s; {coll.get('all_reduces_per_step')} all-reduces per step, {coll.get('bytes_per_step')} bytes; per all-reduce {coll.get('avg_us_by_bytes')} us | `python bench.py --force-collective --no-cpu-baseline --steps 110` |
 | `{RD}_kernel_stats.csv`, `{RD}_kernel_stats_serial.csv`, `{RD}_kernel_stats_small_encoder.csv` | `rocprofv3 --kernel-trace --stats` per-kernel summaries of the pipelined, the serial and the SmallEncoder bench commands (`scripts/rocprof_summary.py`) | `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-verify [--no-pipeline] [--encoder small] --fill 3000 --steps 30 --warmup 5 --repeats 1` |
 | `{RD}_frac_from_stats.txt` | `roofline.frac` recomputed from those CSVs alone (`scripts/frac_from_stats.py`): pipelined `{fr[0].split('frac')[-1].strip()}` vs {r['frac']} from the HIP events inside `bench.py`; serial `{fr[1].split('frac')[-1].strip()}` vs {se['roofline']['frac']} | `python scripts/frac_from_stats.py profiles/{RD}_kernel_stats_serial.csv` |
 | `{RD}_mfma_counters.json` | counter-based MFMA utilisation and LDS bank conflicts per kernel family (two `--pmc` passes, serial schedule; `scripts/pmc_counters.py`): matrix pipe busy per SIMD: conv_dma {g(mc,'conv_dma_f16x3').get('mfma_util_per_simd')}, row-slab {g(mc,'conv3x3_rowslab_f16x3').get('mfma_util_per_simd')}, conv_init_u8 {g(mc,'conv_init_u8').get('mfma_util_per_simd')}, gemm_bf16x3 {g(mc,'gemm_bf16x3').get('mfma_util_per_simd')}; LDS cycles lost to bank conflicts: conv_dma {g(mc,'conv_dma_f16x3').get('lds_conflict_frac')}, row-slab {g(mc,'conv3x3_rowslab_f16x3').get('lds_conflict_frac')}, conv_init_u8 {g(mc,'conv_init_u8').get('lds_conflict_frac')}, gemm_bf16x3 {g(mc,'gemm_bf16x3').get('lds_conflict_frac')} | `scripts/collect_evidence.sh` |
