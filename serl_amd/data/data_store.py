@@ -6,6 +6,7 @@ Mirrors (same names, argument meaning and error behaviour):
   serl_launcher/data/data_store.py:83-144                      MemoryEfficientReplayBufferDataStore
   serl_launcher/data/dataset.py:66-74                          seed / np_random
   serl_launcher/utils/train_utils.py:16-31                     concat_batches
+  serl_launcher/data/data_store.py:147-196                     populate_data_store, populate_data_store_with_z_axis_only
 
 Storage and sampling live in libserl_mi355.so (serl_amd/csrc/replay.hip); this file only adapts
 Python dicts to the C ABI.  There is no CPU fallback.
@@ -162,7 +163,8 @@ class MemoryEfficientReplayBufferDataStore(DataStoreBase):
         return out.astype(bool)
 
     # -- insert (memory_efficient_replay_buffer.py:53-89; thread-safe, data_store.py:104-106)
-    def insert(self, data_dict):
+    def insert(self, data):   # (the reference's data stores name the transition `data`, data_store.py:104)
+        data_dict = data
         obs, nobs = data_dict["observations"], data_dict["next_observations"]
         n = len(self.pixel_keys)
         keep = []
@@ -278,7 +280,8 @@ class ReplayBufferDataStore(MemoryEfficientReplayBufferDataStore):
         self._np_random = None
         self._seed = None
 
-    def insert(self, data_dict):  # replay_buffer.py:71-75 under the data store's lock (data_store.py:44-46)
+    def insert(self, data):  # replay_buffer.py:71-75 under the data store's lock (data_store.py:44-46)
+        data_dict = data
         st = np.ascontiguousarray(data_dict["observations"], dtype=np.float32).reshape(-1)
         nst = np.ascontiguousarray(data_dict["next_observations"], dtype=np.float32).reshape(-1)
         act = np.ascontiguousarray(data_dict["actions"], dtype=np.float32).reshape(-1)
@@ -329,3 +332,45 @@ def gather_crop(parts, crop_obs: Optional[np.ndarray], crop_next: Optional[np.nd
     _lib.check(_lib.lib().serl_rb_gather_crop(
         rbs, n, idp, counts, None if co is None else co.ctypes.data,
         None if cn is None else cn.ctypes.data, C.byref(out.cstruct), C.c_void_p(s)))
+
+
+def _demo_transitions(demos_path):
+    """Transitions of the pickled demonstration files (each file: a list of transition dicts, the format the reference's
+    record_demo scripts write).  `demos_path` is a LIST of paths, as at the reference's call sites
+    (examples/bc_policy.py:152-156); a single string is accepted as one path instead of being iterated per character."""
+    import pickle
+    paths = [demos_path] if isinstance(demos_path, (str, bytes)) else list(demos_path)
+    for path in paths:
+        with open(path, "rb") as f:
+            demo = pickle.load(f)
+        for transition in demo:
+            yield transition
+
+
+def populate_data_store(data_store, demos_path):
+    """data_store.py:147-163: insert every transition of the demonstration pickles into `data_store` (any object with
+    insert() and __len__: the HBM stores above or a QueuedDataStore) and return it."""
+    for transition in _demo_transitions(demos_path):
+        data_store.insert(transition)
+    print(f"Loaded {len(data_store)} transitions.")
+    return data_store
+
+
+def _z_axis_only(state: np.ndarray) -> np.ndarray:
+    """data_store.py:180-196: drop the x / y Cartesian components of a [T, D] proprio state -- columns 0..3, column 6 and
+    columns 10.. are kept (the reference concatenates state[:, :4], state[:, 6][None] and state[:, 10:])."""
+    state = np.asarray(state)
+    return np.concatenate((state[:, :4], state[:, 6][None, ...], state[:, 10:]), axis=-1)
+
+
+def populate_data_store_with_z_axis_only(data_store, demos_path):
+    """data_store.py:166-196: as populate_data_store, with the x / y coordinates removed from both observations' state
+    (the caller's transitions are not modified)."""
+    for transition in _demo_transitions(demos_path):
+        t = dict(transition)
+        for side in ("observations", "next_observations"):
+            t[side] = dict(transition[side])
+            t[side]["state"] = _z_axis_only(transition[side]["state"])
+        data_store.insert(t)
+    print(f"Loaded {len(data_store)} transitions.")
+    return data_store

@@ -6,6 +6,7 @@ from typing import Optional
 from ..agents.drq import DrQAgent
 from ..agents.sac import SACAgent
 from ..data.data_store import MemoryEfficientReplayBufferDataStore, ReplayBufferDataStore
+from ..transport.endpoint import make_trainer_config  # noqa: F401  (launcher.py:171-177: the reference exports it from here)
 
 
 def make_drq_agent(seed, sample_obs, sample_action, image_keys=("image",), encoder_type="small",

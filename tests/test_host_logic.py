@@ -1,4 +1,6 @@
 """CPU: host-side logic that needs no GPU (lazy batches, flax tree naming, initialisers, shims)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,3 +198,78 @@ def test_restore_finds_the_trunk_under_any_camera():
         np.testing.assert_array_equal(core.got[("params", "enc/1/sle")], theta["enc/1/sle"])
     with pytest.raises(KeyError, match="pretrained_encoder"):
         load_state_dict(SimpleNamespace(core=Core(), image_keys=keys), {"params": tree(None)})
+
+
+class _ListStore:
+    def __init__(self):
+        self.items = []
+
+    def insert(self, t):
+        self.items.append(t)
+
+    def __len__(self):
+        return len(self.items)
+
+
+def _demo_files(tmp_path, n_files=2, per_file=3, D=14):
+    import pickle
+    rng = np.random.default_rng(5)
+    paths = []
+    for f in range(n_files):
+        demo = []
+        for i in range(per_file):
+            demo.append({"observations": {"state": rng.normal(size=(1, D)).astype(np.float32),
+                                          "wrist": rng.integers(0, 255, (1, 4, 4, 3), dtype=np.uint8)},
+                         "next_observations": {"state": rng.normal(size=(1, D)).astype(np.float32),
+                                               "wrist": rng.integers(0, 255, (1, 4, 4, 3), dtype=np.uint8)},
+                         "actions": rng.normal(size=4).astype(np.float32), "rewards": float(i), "masks": 1.0, "dones": False})
+        p = tmp_path / f"demo{f}.pkl"
+        with open(p, "wb") as fh:
+            pickle.dump(demo, fh)
+        paths.append(str(p))
+    return paths
+
+
+def _reference_functions(names):
+    """The named top-level functions of the reference's data/data_store.py, executed from where they lie (the module itself
+    imports agentlace, which is not installed; these functions only need pickle / numpy / copy)."""
+    import ast
+    path = "/root/reference/serl_launcher/serl_launcher/data/data_store.py"
+    if not os.path.exists(path):
+        pytest.skip("/root/reference not present")
+    tree = ast.parse(open(path).read())
+    mod = ast.Module([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names], type_ignores=[])
+    ns = {"DataStoreBase": object}
+    exec(compile(mod, path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def _same_tree(a, b):
+    if isinstance(a, dict):
+        assert set(a) == set(b)
+        for k in a:
+            _same_tree(a[k], b[k])
+    elif isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+    else:
+        assert a == b
+
+
+def test_populate_data_store_matches_the_reference(tmp_path, capsys):
+    from serl_amd.data.data_store import populate_data_store, populate_data_store_with_z_axis_only
+    from serl_amd.utils import launcher
+    paths = _demo_files(tmp_path)
+    ref_plain, ref_z = _reference_functions(["populate_data_store", "populate_data_store_with_z_axis_only"])
+    for ours, ref in ((populate_data_store, ref_plain), (populate_data_store_with_z_axis_only, ref_z)):
+        a, b = _ListStore(), _ListStore()
+        assert ours(a, paths) is a
+        ref(b, paths)
+        assert len(a) == len(b) == 6
+        for x, y in zip(a.items, b.items):
+            _same_tree(x, y)
+    assert a.items[0]["observations"]["state"].shape == (1, 14 - 5)      # columns 4, 5, 7, 8, 9 dropped
+    assert "Loaded 6 transitions." in capsys.readouterr().out
+    one = populate_data_store(_ListStore(), paths[0])                    # a bare string is one path, not a list of characters
+    assert len(one) == 3
+    cfg = launcher.make_trainer_config()                                 # launcher.py:171-177 exports it too
+    assert (cfg.port_number, cfg.broadcast_port, list(cfg.request_types)) == (5488, 5489, ["send-stats"])
