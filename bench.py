@@ -236,6 +236,10 @@ def main():
                                   all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on")
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
+    if os.environ.get("SERL_BENCH_DIAG") == "noproduced" and hasattr(sched, "ev_prod"):
+        # TIMING-ONLY diagnostic (results are wrong: the update no longer waits for its features): the trunk stream carries no
+        # event-record packet at the end of a pass -- does the idle time in front of the next pass go away?  (profiles/README.md)
+        sched.produced = lambda slot: None
     hostprof = {}
     if os.environ.get("SERL_BENCH_HOSTPROF") == "1":   # diagnostic: where does the HOST spend an iteration (blocked or enqueueing)?
         def _wrap(obj, name):

@@ -1,6 +1,9 @@
-"""Copies gpurun_out/evidence (scripts/collect_evidence.sh) into profiles/ as r03_* and rewrites the 'Round 4, final state'
-table of profiles/README.md from the JSON files (history / rejected-experiment sections are kept as they are)."""
-import json, os, shutil
+"""Copies gpurun_out/evidence (scripts/collect_evidence.sh) into profiles/ as r04_* and rewrites the 'Round 4, final state'
+table of profiles/README.md from the JSON files (history / rejected-experiment sections are kept as they are).
+Extra evidence directories given on the command line (scripts/collect_evidence_min.sh, collect_evidence_rest.sh) are laid over
+it; a file that no directory holds keeps its tracked profiles/ copy and is listed as KEPT (printed, and named in the table's
+last row) so that the table never silently mixes calls."""
+import json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(R, "gpurun_out", "evidence")
 P = os.path.join(R, "profiles")
@@ -16,9 +19,22 @@ pairs = {"bench": "bench", "bench_f32": "bench_trunk_f32", "bench_car4": "bench_
          "bench_chain_lnepi": "bench_chain_lnepi", "bench_chain_lnepiemulateworld8": "bench_chain_lnepi_emulate_world8",
          "bench_chain_lnepinopipeline": "bench_chain_lnepi_serial",
          "actor_latency": "actor_latency", "sac_state": "sac_state"}
+DIRS = [os.path.join(R, "gpurun_out", d) for d in sys.argv[1:]] + [E]
+KEPT = []
+def find(name):
+    for d in DIRS:
+        q = os.path.join(d, name)
+        if os.path.exists(q) and os.path.getsize(q) > 0:
+            return q
+    return None
 J = {}
 for src, dst in pairs.items():
-    d = json.loads(open(os.path.join(E, src + ".json")).read().strip().splitlines()[-1])
+    q = find(src + ".json")
+    if q is None:
+        KEPT.append(f"{RD}_{dst}.json")
+        J[dst] = json.load(open(os.path.join(P, f"{RD}_{dst}.json")))
+        continue
+    d = json.loads(open(q).read().strip().splitlines()[-1])
     json.dump(d, open(os.path.join(P, f"{RD}_{dst}.json"), "w"), indent=1)
     J[dst] = d
 for src, dst in (("kernel_stats.csv", f"{RD}_kernel_stats.csv"), ("kernel_stats_serial.csv", f"{RD}_kernel_stats_serial.csv"),
@@ -27,7 +43,11 @@ for src, dst in (("kernel_stats.csv", f"{RD}_kernel_stats.csv"), ("kernel_stats_
                  ("wait_counters.json", f"{RD}_wait_counters.json"), ("frac_from_stats.txt", f"{RD}_frac_from_stats.txt"),
                  ("timeline.txt", f"{RD}_timeline.txt"), ("launches_pipelined.txt", f"{RD}_launches_pipelined.txt"),
                  ("launches_serial.txt", f"{RD}_launches_serial.txt"), ("launches_emulate_world8.txt", f"{RD}_launches_emulate_world8.txt")):
-    shutil.copy(os.path.join(E, src), os.path.join(P, dst))
+    q = find(src)
+    if q is None:
+        KEPT.append(dst)
+        continue
+    shutil.copy(q, os.path.join(P, dst))
 b, f32, c4, se, un, gf = (J[k] for k in ("bench", "bench_trunk_f32", "bench_car4", "bench_serial", "bench_unfused_gn", "bench_gemm_f32"))
 e2, e4, e8 = J["bench_emulate_world2"], J["bench_emulate_world4"], J["bench_emulate_world8"]
 w2, w3, w4, sm, co = J["bench_drq_demos"], J["bench_peg"], J["bench_fwbw"], J["bench_small_encoder"], J["bench_collective_1rank"]
@@ -63,6 +83,17 @@ rows = f"""| file | what | command |
 | `{RD}_actor_latency.json` | next-row N3: `agent.sample_actions` on ONE observation: {al['host_ms_per_call']} ms per call on the host, {al['device_ms_per_call']} ms of device time -> {al['actions_per_s']} actions/s | `python bench.py --workload actor_latency` |
 | `{RD}_sac_state.json` | BASELINE.json configs[0] `async_sac_state_sim` (state-only SAC, 2048 = 256 x UTD 8 per iteration): {sac['critic_grad_steps_per_s']} critic grad-steps/s ({sac['ms_per_iteration']} ms per iteration) vs {sac['cpu_port']['critic_grad_steps_per_s']} on {sac['cpu_port']['cores']} CPU cores (oracle port) -> {sac['speedup']}x | `python bench.py --workload sac_state --steps 200` |
 """
+sm_pmc = find("mfma_counters_small_encoder.json")
+if sm_pmc:
+    shutil.copy(sm_pmc, os.path.join(P, f"{RD}_mfma_counters_small_encoder.json"))
+    sc = json.load(open(sm_pmc))
+    rows += (f"| `{RD}_mfma_counters_small_encoder.json` | the same two counter passes on the SmallEncoder bench command (`--encoder small`, serial): "
+             + "; ".join(f"{k}: matrix pipe busy {v.get('mfma_util_per_simd')}, LDS conflict share {v.get('lds_conflict_frac')}" for k, v in sc.items() if isinstance(v, dict))
+             + " | `scripts/collect_evidence_rest.sh` |\n")
+if KEPT:
+    rows += ("| (kept) | NOT re-measured by the last evidence call(s) -- these files are from the earlier round-4 call on commit 1dc8a4b "
+             "(before the conv_init load / store reordering, the SmallEncoder loaders and the Adam kernel changed): "
+             + ", ".join(f"`{k}`" for k in KEPT) + " | |\n")
 p = os.path.join(P, "README.md")
 s = open(p).read()
 a = s.index(f"<!-- {RD}-table-begin -->") + len(f"<!-- {RD}-table-begin -->\n")
