@@ -90,6 +90,9 @@ if sm_pmc:
     rows += (f"| `{RD}_mfma_counters_small_encoder.json` | the same two counter passes on the SmallEncoder bench command (`--encoder small`, serial): "
              + "; ".join(f"{k}: matrix pipe busy {v.get('mfma_util_per_simd')}, LDS conflict share {v.get('lds_conflict_frac')}" for k, v in sc.items() if isinstance(v, dict))
              + " | `scripts/collect_evidence_rest.sh` |\n")
+if os.path.exists(os.path.join(P, f"{RD}_pytest_gpu.txt")):
+    head = open(os.path.join(P, f"{RD}_pytest_gpu.txt")).readline().lstrip("# ").strip()
+    rows += f"| `{RD}_pytest_gpu.txt` | {head} | `scripts/collect_evidence_min.sh`, `scripts/collect_evidence_tests.sh` |\n"
 if KEPT:
     rows += ("| (kept) | NOT re-measured by the last evidence call(s) -- these files are from the earlier round-4 call on commit 1dc8a4b "
              "(before the conv_init load / store reordering, the SmallEncoder loaders and the Adam kernel changed): "
