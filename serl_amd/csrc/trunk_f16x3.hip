@@ -73,6 +73,9 @@ struct ConvArgsB {
   int ksplit;
   float* kslab;
   int* kctr;
+  // row-slab kernel, fused epilogue: the SECOND workgroup of every CU (block ids 256..511 of the first round) starts
+  // `stagger` x s_sleep(127) late (before it takes its tile ticket), see the kernel
+  int stagger;
 };
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
@@ -902,6 +905,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   uint8_t* const smA = smemb;
   uint8_t* const smB = smemb + 2 * A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ANTI-PHASE START.  A tile is a matrix-bound main loop followed by an HBM-bound fused epilogue (residual read + split8 write:
+  // 114 of b0_conv1's 351 us), all 512 resident workgroups start together and every tile takes the same time, so the chip
+  // alternates between "all MFMA, HBM idle" and "all HBM at 4.7 TB/s, matrix pipe idle".  Delaying every CU's second
+  // workgroup by about half a tile BEFORE it draws its ticket shifts half of the tiles by half a period for the rest of the
+  // launch (a finished workgroup's slot is refilled at once, tickets are handed out in start order, so the tiles of one image
+  // still start together and wait for nobody longer than before).
+  if (ab.stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)
+    for (int i = 0; i < ab.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;   // 64-channel column tiles of one row tile are neighbours (shared slab in L2)
   const int m0 = bm * BM, n0 = bn * BN;
@@ -1886,6 +1897,10 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       if (fuse && fuse->mode && a.P % 256 == 0 && can_wait(a.P / 256 * a.tiles_n)) {
         ab.fz = *fuse; ab.fz.expected = a.P / 256; ab.fz.group = a.P / 256 * a.tiles_n; fused = true;
       }
+      // 5 x s_sleep(127) ~ 20 us ~ half a tile of the stage-0 convs.  Same-call A/B (profiles/r04_ab_rs_stagger.txt): pipelined
+      // step 2.5762 / 2.5747 -> 2.5523 / 2.5489 ms with 5; 3 and 8 (a quarter / three quarters of a tile) gave nothing
+      static const int rs_stagger = []() { const char* e = getenv("SERL_RS_STAGGER"); return e ? atoi(e) : 5; }();
+      ab.stagger = (fused && a.tiles_m * a.tiles_n >= 1024) ? rs_stagger : 0;
       if (raw_in) {
         a.in = raw_in->raw; a.in_gn = raw_in->gn;
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
