@@ -334,8 +334,17 @@ def main():
     ci_parts = 1
     if "conv_init_pool" in prof and "conv_init" in prof:
         ci_parts = max(1, int(round(prof["conv_init"][1] / max(prof["conv_init_pool"][1], 1))))
+    # SERL_PROJ_FUSE=1 (opt-in): a block's projection rides on its conv0 launch -- no b{i}_proj launch is timed, conv0's
+    # duration covers both, so conv0 is credited with both FLOP counts
+    rider = {f"conv_igemm/b{i}_conv0": f"conv_igemm/b{i}_proj" for i in range(1, 4)
+             if f"conv_igemm/b{i}_proj" in macs and f"conv_igemm/b{i}_proj" not in prof and f"conv_igemm/b{i}_conv0" in prof}
+    macs = dict(macs)
+    for host, rid in rider.items():
+        macs[host] = macs[host] + macs[rid]
     for tag, (ms, cnt) in sorted(prof.items()):
         ent = {"avg_us": 1e3 * ms / cnt, "timed_launches": cnt}
+        if tag in rider:
+            ent["includes"] = rider[tag]
         if tag in ("conv_init", "gn_relu_maxpool") and ci_parts > 1:
             ent["launches_per_pass"] = ci_parts
         if tag in macs:

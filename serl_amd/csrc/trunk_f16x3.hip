@@ -78,6 +78,17 @@ struct ConvArgsB {
   int stagger;
 };
 
+// LDS-DMA kernel, OPT-IN (SERL_PROJ_FUSE=1): the block's 1x1 stride-2 projection computed by the SAME workgroup in front of its
+// 3x3 stride-2 conv0 tile (same input, same output tile: the projection's pixel is conv0's tap (0, 0)).  A separate kernel
+// parameter behind the existing ones, and a separate instantiation (PROJ): the kernels without it keep their code and their
+// argument offsets.
+struct ConvProjB {
+  const uint16_t* wdma;  // the projection's planes in piece order (K = Cin)
+  const float* winv;     // [Cout]
+  float* out;            // raw fp32 [M][Cout]
+  double* stats;         // [N][4][2]
+};
+
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -624,6 +635,63 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
   }
 }
 
+// Raw store + GroupNorm statistics of the FUSED PROJECTION's tile (conv_dma_f16x3_kernel<.., PROJ = true>): the same tile geometry as the
+// conv it rides on, so the same PMODE; never a fused GroupNorm epilogue (its consumer is conv1's residual operand, mode 3).
+template <int TN, int PMODE>
+__device__ __forceinline__ void dma_proj_epilogue(const ConvArgsB& ab, const ConvProjB& pj, f32x16 (&acc)[2][TN], f32x16 (&accx)[2][TN],
+                                                  int m0, int n0, int wm, int wn, int li, int lh) {
+  static_assert(PMODE != 3, "the fused projection takes its statistics in the kernel");
+  constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN;
+  const ConvArgs& a = ab.c;
+  const int wrow0 = m0 + wm * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = pj.winv[n0 + wn * WCOLS + tn * 32 + li];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < a.M) {
+        float* o = pj.out + (size_t)m * a.Cout + n0 + wn * WCOLS + li;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) o[32 * tn] = acc[tm][tn][r];
+      }
+    }
+  const int gsize = a.Cout / kGnGroups;
+  constexpr int ROWS = PMODE == 0 ? WROWS : (PMODE == 1 ? 32 : 16);
+  constexpr int NSLOT = WROWS / ROWS;
+#pragma unroll
+  for (int slot = 0; slot < NSLOT; ++slot) {
+    const int mrow = wrow0 + slot * ROWS;
+    const bool valid = mrow < a.M;
+    const int n = valid ? mrow / a.P : 0;
+    double* stp = pj.stats + (size_t)n * kGnGroups * 2;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tm * 32 + 8 * (r >> 2);
+          if (row / ROWS == slot) {
+            const float v = acc[tm][tn][r];
+            s += v;
+            q += v * v;
+          }
+        }
+      stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+    }
+  }
+}
+
 // LDS-DMA implicit GEMM (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through registers).
 // The register-staged kernel above serialises its phases -- measured on b2_conv1: MFMA-only 164 us, + LDS fragment
 // reads 8, + ds_write staging 34, + global-load waits 57 = 263 us.  Here the K loop advances in 16-channel SLOTS
@@ -650,8 +718,9 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <int TN, int PMODE>
-__global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
+template <int TN, int PMODE, bool PROJ = false>
+__global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page, ConvProjB pj) {
+  static_assert(!PROJ || PMODE != 3, "the fused projection takes its statistics in the kernel");
   constexpr int NS = 4;
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN, BM = 128, BN = 2 * WCOLS;
@@ -685,12 +754,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     }
   }
   const int nslots = ntaps * (a.Cin >> 4);
+  // The K loop below (SERL_RING_RUN) runs over one operand set: `run_nslots` slots of `run_kw`-wide kernel rows with the weight
+  // pieces at wsrc.  Normally once; with a fused projection (PROJ) first over the projection's K = Cin (tap (0, 0) only).
+  // (PROJ is a separate instantiation: the kernels without it compile to the same code as before the projection existed)
+  constexpr bool with_proj = PROJ;
+  int run_nslots = with_proj ? (a.Cin >> 4) : nslots, run_kw = with_proj ? 1 : a.KW;
   // weight pieces (ring-order copy: 4 KB per (64-row block, slot), swizzle baked in): this lane's 16 bytes of piece q
   const uint8_t* wsrc[B_PIECES];
 #pragma unroll
   for (int q = 0; q < B_PIECES; ++q) {
     const int prow = (q * 4 + wave) * 16 + (lane >> 2);
-    wsrc[q] = reinterpret_cast<const uint8_t*>(ab.wdma) + (size_t)((n0 + prow) >> 6) * nslots * 4096 + ((prow & 63) << 6) + ((lane & 3) << 4);
+    wsrc[q] = reinterpret_cast<const uint8_t*>(with_proj ? pj.wdma : ab.wdma) + (size_t)((n0 + prow) >> 6) * run_nslots * 4096 +
+              ((prow & 63) << 6) + ((lane & 3) << 4);
   }
   int l_tap = 0, l_ky = 0, l_kx = 0, l_ci0 = 0, l_slot = 0;   // counters of the next slot to latch (strictly in order)
   const uint8_t* zp = zero_page + (lane & 3) * 16;
@@ -714,10 +789,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   {                                                                                                            \
     nx_tap = l_tap; nx_k = l_slot; nx_ring = (RING);                                                           \
     nx_toff = (((l_ky - a.pad) * a.Wi + (l_kx - a.padw)) * a.Cin + l_ci0) * 4;                                 \
-    if (l_slot + 1 < nslots) {                                                                                 \
+    if (l_slot + 1 < run_nslots) {                                                                             \
       ++l_slot;                                                                                                \
       l_ci0 += 16;                                                                                             \
-      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == a.KW) { l_kx = 0; ++l_ky; } }                    \
+      if (l_ci0 == a.Cin) { l_ci0 = 0; ++l_tap; if (++l_kx == run_kw) { l_kx = 0; ++l_ky; } }                  \
     }                                                                                                          \
   }
   f32x16 acc[TM][TN], accx[TM][TN];
@@ -741,13 +816,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
     bhi_off[tn] = A_BYTES + row * 64 + ((lh ^ sw) << 4);
     blo_off[tn] = A_BYTES + row * 64 + (((2 + lh) ^ sw) << 4);
   }
-  // prologue: NS slots in flight; slot 0's fragments into the first register set
-#pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    SERL_RING_NEXT(p);
-#pragma unroll
-    for (int pi = 0; pi < PIECES; ++pi) SERL_RING_PIECE(pi)
-  }
   constexpr int GROUPS = TM * TN;
   f16x8 fa[2][2 * TM], fb[2][2 * TN];   // [register set][hi/lo per tile]
 #define SERL_RING_READ(SET, ST)                                                                \
@@ -761,9 +829,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
       fb[SET][2 * tn + 1] = *reinterpret_cast<const f16x8*>((ST) + blo_off[tn]);               \
     }                                                                                          \
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PIECES) : "memory");
-  asm volatile("s_barrier" ::: "memory");
-  SERL_RING_READ(0, smemb);
   // iteration c: slot c is in register set CUR; slot c + 1 must have landed (slots c + 2, c + 3 may be in flight) and every
   // wave must be done reading slot c from LDS before its ring position is refilled with slot c + 4
 #define SERL_RING_READ1(SET, ST, I)                                                            \
@@ -804,16 +869,53 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
         accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[CUR][2 * tm], fb[CUR][2 * tn + 1], accx[tm][tn], 0, 0, 0); \
       }                                                                                        \
   }
-  for (int c = 0; c < nslots; c += 2) {   // nslots is even (Cin % 32 == 0)
-    SERL_RING_ITER(c, 0);
-    SERL_RING_ITER(c + 1, 1);
+  // one pass over an operand set: prologue (NS slots in flight, slot 0's fragments into the first register set), the slot loop,
+  // and the drain (the redundant last fetches must land before this LDS is reused or released)
+#define SERL_RING_RUN()                                                                        \
+  {                                                                                            \
+    l_tap = 0; l_ky = 0; l_kx = 0; l_ci0 = 0; l_slot = 0;                                      \
+    _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                           \
+      SERL_RING_NEXT(p);                                                                       \
+      _Pragma("unroll") for (int pi = 0; pi < PIECES; ++pi) SERL_RING_PIECE(pi)                \
+    }                                                                                          \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PIECES) : "memory");                   \
+    asm volatile("s_barrier" ::: "memory");                                                    \
+    SERL_RING_READ(0, smemb);                                                                  \
+    for (int c = 0; c < run_nslots; c += 2) {   /* the slot count is even (Cin % 32 == 0) */   \
+      SERL_RING_ITER(c, 0);                                                                    \
+      SERL_RING_ITER(c + 1, 1);                                                                \
+    }                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
   }
+  if constexpr (PROJ) {
+    {   // the projection's tile first: K = Cin at conv0's tap (0, 0) -- launcher: stride 2, pad 0, 3x3
+      SERL_RING_RUN();
+      dma_proj_epilogue<TN, PMODE>(ab, pj, acc, accx, m0, n0, wm, wn, li, lh);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+      // every wave is done with the ring (its last fragment reads included) before conv0's prologue refills it, and the
+      // projection's stores / statistics atomics have drained: the ring's counted vmcnt waits count DMA pieces only
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      run_nslots = nslots; run_kw = a.KW;
+#pragma unroll
+      for (int q = 0; q < B_PIECES; ++q) {
+        const int prow = (q * 4 + wave) * 16 + (lane >> 2);
+        wsrc[q] = reinterpret_cast<const uint8_t*>(ab.wdma) + (size_t)((n0 + prow) >> 6) * nslots * 4096 + ((prow & 63) << 6) + ((lane & 3) << 4);
+      }
+    }
+  }
+  SERL_RING_RUN();
+#undef SERL_RING_RUN
 #undef SERL_RING_ITER
 #undef SERL_RING_READ
 #undef SERL_RING_READ1
 #undef SERL_RING_PIECE
 #undef SERL_RING_NEXT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (redundant) last fetches must land before this LDS is released
   dma_tile_epilogue<TN, PMODE>(ab, acc, accx, m0, n0, bn, wm, wn, li, lh);
 }
 
@@ -1841,11 +1943,15 @@ static bool rowslab_shape_ok(int N, int Hi, int Wi, int Cin, int Ho, int Wo, int
 // CUs this stream may use at ONE workgroup per CU, else run the separate elementwise pass
 static bool fused_can_wait(hipStream_t stream, int G) { return resident_workgroups(stream) >= 16 * (G - 1) + 1; }
 
+// in/out: a block's 1x1 projection offered to the launch of its conv0 (same input, stride and output shape); `done` comes back
+// true when the kernel chosen for conv0 computed it as well (LDS-DMA kernel, PROJ instantiation)
+struct ProjFuse { PackedConvWeights w; float* out; double* stats; bool done; };
+
 static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvWeights w, float* out, double* stats,
                              int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksz, int stride,
                              hipStream_t stream, const uint8_t* zero_page = nullptr, FuseArgs* fuse = nullptr,
                              const RawInput* raw_in = nullptr, TrunkPlan::L* plan = nullptr, float* kslab = nullptr,
-                             int* kctr = nullptr) {
+                             int* kctr = nullptr, ProjFuse* proj = nullptr) {
   // `fuse` (in/out): the caller's request for the fused GroupNorm epilogue (mode, gn, residual, out_split, sync, ticket);
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
@@ -1920,13 +2026,27 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       }
 #define SERL_LAUNCH_DMA(KERN, TN_, ...)                                                                              \
   do {                                                                                                              \
-    if (pmode == 0) hipLaunchKernelGGL((KERN<TN_, 0 __VA_ARGS__>), g, block, l, stream, ab, zero_page);        \
-    else if (pmode == 1) hipLaunchKernelGGL((KERN<TN_, 1 __VA_ARGS__>), g, block, l, stream, ab, zero_page);   \
-    else if (pmode == 2) hipLaunchKernelGGL((KERN<TN_, 2 __VA_ARGS__>), g, block, l, stream, ab, zero_page);   \
-    else hipLaunchKernelGGL((KERN<TN_, 3 __VA_ARGS__>), g, block, l, stream, ab, zero_page);                   \
+    if (pmode == 0) hipLaunchKernelGGL((KERN<TN_, 0 __VA_ARGS__>), g, block, l, stream, ab, zero_page, pjb);   \
+    else if (pmode == 1) hipLaunchKernelGGL((KERN<TN_, 1 __VA_ARGS__>), g, block, l, stream, ab, zero_page, pjb); \
+    else if (pmode == 2) hipLaunchKernelGGL((KERN<TN_, 2 __VA_ARGS__>), g, block, l, stream, ab, zero_page, pjb); \
+    else hipLaunchKernelGGL((KERN<TN_, 3 __VA_ARGS__>), g, block, l, stream, ab, zero_page, pjb);              \
   } while (0)
-      if (tn == 2) SERL_LAUNCH_DMA(conv_dma_f16x3_kernel, 2);
+      ConvProjB pjb{};
+      const bool with_pj = proj && proj->w.dma && pmode != 3 && ksz == 3 && stride == 2 && a.pad == 0 && a.padw == 0;
+      if (with_pj) {   // projection pixel == conv0's tap (0, 0): pad 0 on both axes ("SAME" padding of an even extent at stride 2)
+        pjb.wdma = proj->w.dma; pjb.winv = proj->w.inv; pjb.out = proj->out; pjb.stats = proj->stats;
+#define SERL_LAUNCH_DMA_PROJ(TN_)                                                                                            \
+  do {                                                                                                                      \
+    if (pmode == 0) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 0, true>), g, block, l, stream, ab, zero_page, pjb);      \
+    else if (pmode == 1) hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 1, true>), g, block, l, stream, ab, zero_page, pjb); \
+    else hipLaunchKernelGGL((conv_dma_f16x3_kernel<TN_, 2, true>), g, block, l, stream, ab, zero_page, pjb);                 \
+  } while (0)
+        if (tn == 2) SERL_LAUNCH_DMA_PROJ(2);
+        else SERL_LAUNCH_DMA_PROJ(1);
+#undef SERL_LAUNCH_DMA_PROJ
+      } else if (tn == 2) SERL_LAUNCH_DMA(conv_dma_f16x3_kernel, 2);
       else SERL_LAUNCH_DMA(conv_dma_f16x3_kernel, 1);
+      if (proj) proj->done = with_pj;
 #undef SERL_LAUNCH_DMA
     } else if (cfg == 0) SERL_LAUNCH_CONV(2, 2, 2, 2, 0);
     else if (cfg == 1) SERL_LAUNCH_CONV(4, 1, 2, 2, 0);
@@ -2118,10 +2238,19 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
     const bool raw_in = i == 0 && raw_b0;
     const RawInput rin{ws.raw_init, gn_init};
+    // OPT-IN (SERL_PROJ_FUSE=1; built at the end of round 4 without GPU time left: NOT yet run on hardware): conv0's workgroups
+    // compute the block's projection tile too -- no projection launch (b1 / b2 / b3_proj: 76 + 46 + 31 us of a 2.5 ms step,
+    // latency-bound two-round launches), one more pass over tap (0, 0) of an input tile that conv0 fetches anyway
+    const char* pf_e = getenv("SERL_PROJ_FUSE");   // (read per pass: the probe / test flips it inside one process)
+    const bool proj_fuse = pf_e && pf_e[0] == '1';
+    ProjFuse pf{pw(2), ws.blk[i].rawp, stats_of(lp), false};
     if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
-                                raw_in ? &rin : nullptr, &ws.plan.conv[i][0], ws.kslab, ws.kctr))) return rc;
+                                raw_in ? &rin : nullptr, &ws.plan.conv[i][0], ws.kslab, ws.kctr, has_proj && proj_fuse ? &pf : nullptr))) return rc;
     SERL_REQUIRE(!raw_in || fz0.mode, "block 0 was planned on the fused row-slab path");
-    if (has_proj)
+    if (has_proj && pf.done) {
+      ws.plan.conv[i][2] = ws.plan.conv[i][0];
+      ws.plan.conv[i][2].kern = 'F'; ws.plan.conv[i][2].fused = 0;   // 'F': rode on conv0's launch
+    } else if (has_proj)
       if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero, nullptr,
                                   nullptr, &ws.plan.conv[i][2], ws.kslab, ws.kctr))) return rc;
     const long tot = (long)N * P * (f / 4);
