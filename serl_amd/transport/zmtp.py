@@ -18,7 +18,7 @@ Wire format implemented
                SUBSCRIBE / CANCEL command frames are understood too
   PING       : answered with PONG (3.1 peers with heartbeats enabled)
 Not implemented: security mechanisms other than NULL, ROUTER/DEALER, multipart application messages (agentlace sends
-single-frame messages), reconnection of an established connection that broke.
+single-frame messages).  A connection this side dialled is dialled again when it breaks (a SUB re-sends its subscriptions).
 """
 from __future__ import annotations
 
@@ -141,26 +141,28 @@ class _Peer:
         with self.slock:
             self._send(data, timeout)
 
-    def send_or_drop(self, data: bytes, budget: float = 0.05) -> bool:
+    def send_or_drop(self, data: bytes, stall: float = 1.0) -> bool:
         """PUB semantics (libzmq never blocks a publisher: it drops WHOLE messages at the high-water mark): if the socket is
-        not writable right now the message is dropped and the stream stays intact; once the first byte of a frame is on the
-        wire the rest must follow within `budget` seconds, otherwise the subscriber's framing is beyond repair and the
-        connection is closed (the SUB side reconnects).  -> True if the message went out."""
+        not writable right now the message is dropped and the stream stays intact.  Once the first byte of a frame is on the
+        wire the rest must follow; the connection is given up only when the subscriber accepts NO byte for `stall` seconds
+        (the timer restarts on every byte of progress, so a slow link or a busy subscriber that keeps reading -- 20 MB of
+        parameters over 1 GbE take 160 ms -- is never cut off); a peer that stopped reading mid-frame cannot be resynchronised,
+        so its connection is closed and the SUB side reconnects (Socket._pump).  -> True if the message went out."""
         with self.slock:
-            view, t0 = memoryview(data), None
+            view, started, last = memoryview(data), False, 0.0
             while len(view):
                 try:
                     n = self.conn.send(view)
                     view = view[n:]
-                    if t0 is None:
-                        t0 = time.time()
+                    if n:
+                        started, last = True, time.time()
                 except (BlockingIOError, InterruptedError):
-                    if t0 is None:
+                    if not started:
                         return False                 # nothing sent yet: drop the whole message
-                    if time.time() - t0 > budget:
-                        self.close()                 # mid-frame stall: never leave a partial frame behind
+                    if time.time() - last > stall:
+                        self.close()                 # mid-frame and no progress at all: never leave a partial frame behind
                         return False
-                    select.select([], [self.conn], [], 0.005)
+                    select.select([], [self.conn], [], 0.02)
                 except OSError:
                     self.close()
                     return False
@@ -362,6 +364,7 @@ class Socket:
             except (ZMTPError, OSError):
                 c.close()
                 continue
+            peer.endpoint = ep                      # a connection WE made: re-made when it breaks (libzmq's reconnect)
             with self._lock:
                 self._pending.remove(ep)
             self._add_peer(peer)
@@ -395,6 +398,9 @@ class Socket:
                     self._peers.remove(p)
                     if self._reply_to is p:
                         self._reply_to = None
+                    ep = getattr(p, "endpoint", None)
+                    if ep is not None and not self.closed and ep not in self._pending:
+                        self._pending.append(ep)    # the connecting side dials again (subscriptions are re-sent by _add_peer)
             if len(self._inbox) != n0:
                 self._cv.notify_all()
 

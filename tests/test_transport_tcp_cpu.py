@@ -220,6 +220,88 @@ def test_pub_never_blocks_on_a_stalled_subscriber_and_never_tears_a_frame():
     raw.close()
 
 
+def test_pub_delivers_large_messages_to_a_slow_but_reading_subscriber():
+    """the mid-frame budget was wall-clock from the first byte (50 ms), so a 20 MB parameter publish to a
+    subscriber that reads slowly (busy threads, 1 GbE) closed the link and the actor kept a stale policy forever.  The stall
+    timer now restarts on every byte of progress: a reader that keeps reading gets every message, however slowly."""
+    from serl_amd.transport import zmtp
+    pub, sub = zmtp.Socket(zmtp.PUB), zmtp.Socket(zmtp.SUB)
+    port, _ = _free_ports()
+    pub.bind(f"tcp://127.0.0.1:{port}")
+    sub.setsockopt(zmtp.SUBSCRIBE, b"")
+    sub.setsockopt(zmtp.RCVTIMEO, 20000)
+    # throttle the subscriber's I/O thread: at most 256 KB per read every 2 ms (~100 MB/s, far below loopback speed), so a
+    # 20 MB frame takes ~200 ms -- four times the old fixed budget -- while bytes keep flowing
+    real_pump = zmtp._Peer.pump
+
+    def slow_pump(self):
+        time.sleep(0.002)
+        try:
+            chunk = self.conn.recv(1 << 18)
+            if not chunk:
+                self.alive = False
+            self.buf += chunk
+        except (BlockingIOError, InterruptedError):
+            pass
+        except OSError:
+            self.alive = False
+        conn, self.conn = self.conn, _NoRead()
+        try:
+            real_pump(self)                      # frame parsing only
+        finally:
+            self.conn = conn
+
+    class _NoRead:
+        def recv(self, n):
+            raise BlockingIOError
+
+    sub.connect(f"tcp://127.0.0.1:{port}")
+    deadline = time.time() + 5
+    while time.time() < deadline and not any(p.subs for p in pub._peers):
+        time.sleep(0.02)
+    assert any(p.subs for p in pub._peers)
+    for p in sub._peers:
+        p.pump = slow_pump.__get__(p)
+    payloads = [bytes([k]) * (20 << 20) for k in range(3)]
+    got = []
+    rx = threading.Thread(target=lambda: [got.append(sub.recv()) for _ in payloads])
+    rx.start()
+    for m in payloads:
+        pub.send(m)
+    rx.join(timeout=60)
+    assert [g[:1] for g in got] == [m[:1] for m in payloads] and all(len(g) == 20 << 20 for g in got)
+    assert any(p.alive for p in pub._peers), "the publisher gave up on a subscriber that was reading"
+    pub.close()
+    sub.close()
+
+
+def test_sub_reconnects_after_the_publisher_dropped_it():
+    """ADVICE r4 (high, second half): a SUB whose connection was closed must dial again and re-send its subscriptions
+    (libzmq does); before, the dead peer was removed and the endpoint never returned to the pending list."""
+    from serl_amd.transport import zmtp
+    pub, sub = zmtp.Socket(zmtp.PUB), zmtp.Socket(zmtp.SUB)
+    port, _ = _free_ports()
+    pub.bind(f"tcp://127.0.0.1:{port}")
+    sub.setsockopt(zmtp.SUBSCRIBE, b"")
+    sub.setsockopt(zmtp.RCVTIMEO, 5000)
+    sub.connect(f"tcp://127.0.0.1:{port}")
+    deadline = time.time() + 5
+    while time.time() < deadline and not any(p.subs for p in pub._peers):
+        time.sleep(0.02)
+    pub.send(b"one")
+    assert sub.recv() == b"one"
+    for p in list(pub._peers):           # the publisher gives the subscriber up (what a mid-frame stall does)
+        p.close()
+    deadline = time.time() + 10
+    while time.time() < deadline and not any(p.alive and p.subs for p in pub._peers):
+        time.sleep(0.05)
+    assert any(p.alive and p.subs for p in pub._peers), "the subscriber did not come back"
+    pub.send(b"two")
+    assert sub.recv() == b"two"
+    pub.close()
+    sub.close()
+
+
 def test_truncated_lz4_frame_is_an_error():
     from serl_amd.transport import lz4frame
     if lz4frame._load() is None:
