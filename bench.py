@@ -472,7 +472,13 @@ def main():
                     + "and one of [scalars | actor grads] per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
     if verify is not None:
         out["verify"] = verify
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    diag = os.environ.get("SERL_BENCH_DIAG") or ("hostprof" if os.environ.get("SERL_BENCH_HOSTPROF") == "1" else "")
+    if diag:
+        # a diagnostic run is never a bench line: no `metric` / `value` / `unit` (SERL_BENCH_DIAG=noproduced runs updates that did
+        # not wait for their features -- its numbers time a wrong computation)
+        out = {"diagnostic": True, "diag": diag, "diagnostic_ms_per_step": out["ms_per_step"],
+               **{k: v for k, v in out.items() if k not in ("metric", "value", "unit", "ms_per_step", "vs_baseline", "higher_is_better")}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not diag:
         out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, KEYS, S, A, B)
     # the JSON line must be the last thing on stdout: librccl prints its version banner through C stdio, which is
     # block-buffered when stdout is a pipe/file and would otherwise surface after this line at exit -- every rank

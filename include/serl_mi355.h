@@ -200,7 +200,8 @@ int serl_agent_set_step(serl_agent* a, int64_t step); /* JaxRLTrainState.step an
  * ("f16x3": x = hi + 2^-11 lo', three fp16 MFMA products per fp32 product, fp32 accumulate; error per
  * product <= ~3*2^-22, i.e. fp32-roundoff class -- DESIGN.md section 4; parity tests run both modes). */
 int serl_agent_set_trunk_mode(serl_agent* a, int mode);
-/* Scheduling hint, no effect on results: the most workgroups a K-split GEMM launch of the update (sac.py:243-299) may use
+/* Scheduling hint (results equal up to fp32 summation order: the K-split depth sets how many partial sums a GEMM adds;
+ * per agent, read by that agent's launches only): the most workgroups a K-split GEMM launch of the update (sac.py:243-299) may use
  * (0 = default 512).  A caller that overlaps the update of batch i with the frozen-trunk pass of batch i+1 at a large per-rank
  * batch sets 256: fewer update workgroups queue for CU slots between the trunk's conv workgroups. */
 int serl_agent_set_chain_budget(serl_agent* a, int workgroups);

@@ -93,14 +93,10 @@ struct serl_agent {
   TrunkWorkspace tws{};
   TrunkPacked tpk{};
   int trunk_mode = 1;  // 0: exact fp32 MFMA convs, 1: split-fp16 (f16x3) convs for the blocks
-  // last-arriver fusion of the update chain (heads.hip): LayerNorm / slab reductions / the tanh-Gaussian head run inside the GEMM
+  // last-arriver fusion of the update chain (heads.hip): slab reductions / the tanh-Gaussian head run inside the GEMM
   // launches that feed them, the critic loss rides on the LayerNorm backward that consumes dQ, noise is hashed where it is used.
   // SERL_CHAIN_FUSE=0 restores one launch per operation (A/B timing; the fused path is bit-identical on identical noise).
   bool fuse = true;
-  // fused chain, opt-in (SERL_CHAIN_LN_EPI=1): LayerNorm + tanh inside the GEMM launch too (38 instead of 48 launches per
-  // critic + actor pair).  Measured SLOWER in every schedule (profiles/README.md round 4): the last arriver of a 64-row tile
-  // normalises 64 rows on four waves while the separate LayerNorm launch spreads the same rows over the whole chip.
-  bool ln_epi = false;
   // K-split budget of the chain's GEMMs (workgroups per launch): 512 by default; 256 when the caller overlaps the chain with the
   // next batch's trunk pass at a large per-rank batch (serl_agent_set_chain_budget) -- fewer workgroups queue for CU slots
   // between conv workgroups (same call: pipelined 2.605 -> 2.570 ms, conv_init next to the chain 455 -> 372 us; alone the
@@ -390,10 +386,11 @@ size_t carve(serl_agent* a, void* base) {
 // K-split of a GEMM launch: as deep as `smax` for latency when the problem is small, but never more
 // workgroups than the budget -- at large per-rank batches the update chain runs beside the trunk of the
 // next batch and every extra workgroup waits for a conv workgroup to retire.
-long g_split_budget = 0;   // the running agent's budget (set at the top of every phase: the chain of one agent is issued by one thread)
-int split_for(int M, int N, int groups, int smax, long budget = 0) {
+// `agent_budget` is the calling agent's own serl_agent_set_chain_budget value (0 = default): no process-global state, so two
+// agents (or sample_actions on another thread) never see each other's budget.
+int split_for(long agent_budget, int M, int N, int groups, int smax, long budget = 0) {
   static const long env_budget = []() { const char* e = getenv("SERL_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
-  if (budget <= 0) budget = env_budget > 0 ? env_budget : (g_split_budget > 0 ? g_split_budget : 512L);
+  if (budget <= 0) budget = env_budget > 0 ? env_budget : (agent_budget > 0 ? agent_budget : 512L);
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -434,7 +431,7 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   LnFwdArgs lv[3];
   ProprioArgs pv[3];
   static const long enc_budget = []() { const char* e = getenv("SERL_ENC_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
-  const int S = split_for(cnt, c.bottleneck, c.n_cam * n, 32, enc_budget);  // K = 4096: up to 32 slices of 128
+  const int S = split_for(a->split_budget, cnt, c.bottleneck, c.n_cam * n, 32, enc_budget);  // K = 4096: up to 32 slices of 128
   for (int i = 0; i < n; ++i) {
     const EncJob& j = jobs[i];
     EncBuf& e = *j.e;
@@ -466,22 +463,10 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
       pr.copy_cols = c.act_dim;
     }
   }
-  const bool ln_epi = a->fuse && a->ln_epi;
   if (a->fuse) {
     for (int i = 0; i < n; ++i) {
       sv[i].gen = jobs[i].gen_mask; sv[i].seed = jobs[i].mask_seed;
       sv[i].row_offset = a->shard_off + off; sv[i].rows_global = a->shard_global ? a->shard_global : Bfull;
-    }
-  }
-  if (ln_epi) {   // LayerNorm + tanh by the last-arriving workgroup of every 64-row tile of the bottleneck GEMM (heads.hip)
-    SERL_REQUIRE((long)c.n_cam * cdiv(cnt, 64) <= kCtrPerLane && (long)c.n_cam * S * pad64(cnt) * c.bottleneck <= a->slabs_cap,
-                 "encoder GEMM exceeds the fused epilogue's scratch");
-    for (int i = 0; i < n; ++i) {
-      GemmDesc& g = gd[i];
-      g.ldc = c.bottleneck; g.sCz = pad64(cnt) * c.bottleneck;
-      g.epi = kEpiLn; g.ctr = a->ctr + (long)i * kCtrPerLane;
-      g.ln = lv[i];
-      g.ln.slab_stride = g.sCz;
     }
   }
   if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
@@ -506,7 +491,7 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
                      Bfull * a->D, (long)c.batch * a->D, st));
   }
   RC(gemm_f32_multi(gd, n, st));
-  if (!ln_epi) RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
+  RC(ln_tanh_fwd_multi(lv, n, c.bottleneck, st));
   if (a->fuse && !a->small) return SERL_OK;   // (the proprio branch rode on the SLE launch)
   return proprio_fwd_multi(pv, n, c.state_dim, cnt, st);
 }
@@ -525,7 +510,7 @@ int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, 
                         hipStream_t st) {
   const int Hd = a->cfg.hidden;
   SERL_REQUIRE(n >= 1 && n <= 3, "bad dense instance count");
-  splitk = split_for(rows_per_group, Hd, groups * n, splitk);
+  splitk = split_for(a->split_budget, rows_per_group, Hd, groups * n, splitk);
   GemmDesc gd[3];
   LnFwdArgs lv[3];
   for (int i = 0; i < n; ++i) {
@@ -545,18 +530,6 @@ int dense_ln_tanh_multi(serl_agent* a, const DenseJob* jobs, int n, int groups, 
     l.xhat = j.xhat; l.rstd = j.rstd;
     l.dot_w = j.dot_w; l.dot_b = j.dot_b; l.dot_out = j.dot_out;
     l.dot_gstride = j.dot_gstride; l.dot_b_gstride = j.dot_b_gstride;
-  }
-  if (a->fuse && a->ln_epi) {
-    SERL_REQUIRE((long)groups * cdiv(rows_per_group, 64) <= kCtrPerLane && (long)groups * splitk * pad64(rows_per_group) * Hd <= a->slabs_cap,
-                 "Dense layer exceeds the fused epilogue's scratch");
-    for (int i = 0; i < n; ++i) {
-      GemmDesc& g = gd[i];
-      g.sCz = pad64(rows_per_group) * Hd;
-      g.epi = kEpiLn; g.ctr = a->ctr + (long)i * kCtrPerLane;
-      g.ln = lv[i];
-      g.ln.slab_stride = g.sCz;
-    }
-    return gemm_f32_multi(gd, n, st);
   }
   RC(gemm_f32_multi(gd, n, st));
   return ln_tanh_fwd_multi(lv, n, Hd, st);
@@ -603,6 +576,7 @@ int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStrea
   RC(dense_ln_tanh_multi(a, d1, n, 1, cnt, a->E, 8, st));
   RC(dense_ln_tanh_multi(a, d2, n, 1, cnt, Hd, 4, st));
   if (a->fuse) {   // the tanh-Gaussian head inside the head GEMM: last arriver of every 64-row tile (heads.hip, kEpiPolicy)
+    SERL_REQUIRE(A <= 64, "the fused policy-head epilogue holds one 64-wide slab row per sample (act_dim %d)", A);
     SERL_REQUIRE(cdiv(cnt, 64) <= kCtrPerLane && 8 * pad64(cnt) * 64 <= a->slabs_cap, "policy head exceeds the fused epilogue's scratch");
     for (int i = 0; i < n; ++i) {
       const PolJob& j = jobs[i];
@@ -966,7 +940,6 @@ int serl_agent_create(const serl_agent_cfg* cfg, serl_agent** out) {
   serl_agent* a = new serl_agent();
   a->cfg = *cfg;
   { const char* e = getenv("SERL_CHAIN_FUSE"); a->fuse = !(e && e[0] == '0'); }
-  { const char* e = getenv("SERL_CHAIN_LN_EPI"); a->ln_epi = e && e[0] == '1'; }
   build_layout(a);
   const size_t bytes = carve(a, nullptr);
   hipError_t e = hipMalloc(&a->arena, bytes);
@@ -1215,7 +1188,6 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   for (int k = 0; k < m_sub; ++k) SERL_REQUIRE(sel.idx[k] >= 0 && sel.idx[k] < c.ensemble, "REDQ index out of range");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
-  g_split_budget = a->split_budget;
   const int A = c.act_dim;
   if (a->fuse) {
     const FusedNoise fz = fetch_noise_fused(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0);
@@ -1290,7 +1262,6 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   SERL_REQUIRE(global_count >= cnt, "global_count < local batch");
   a->pg_ncs = a->pg_nwg = 0;
   a->pg_defer = true;
-  g_split_budget = a->split_budget;
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
   hipStream_t s0 = st;
   if (a->fuse) {

@@ -244,84 +244,6 @@ __device__ __forceinline__ void ln_tanh_row256(const LnFwdArgs& a, int row, int 
   }
 }
 
-// The reducer's form of ln_tanh_row256: a wave owns rows row0, row0 + 4, ... (R of them per pass) and keeps the slab loads of
-// ALL of them in flight -- one memory round trip per slab index instead of one per row (a dependent sc1 read costs 1-3 us next
-// to the trunk pass; 16 rows one after the other made the fused GEMMs 35 us longer than GEMM + LayerNorm launch together).
-// Same arithmetic, same order per row as ln_tanh_row256.
-template <int R>
-__device__ __forceinline__ void ln_tanh_rows_live(const LnFwdArgs& a, int grp, int lrow0, int lrow_end, int lane) {
-  constexpr int D = 256;
-  const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.slabs);
-  const long gbase = (long)grp * a.S * a.slab_stride + lane * 4;
-  const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + (long)grp * a.pstride + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 ga = *reinterpret_cast<const float4*>(a.gamma + (long)grp * a.pstride + lane * 4);
-  const float4 be = *reinterpret_cast<const float4*>(a.beta + (long)grp * a.pstride + lane * 4);
-  float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.dot_out) dw = *reinterpret_cast<const float4*>(a.dot_w + (long)grp * a.dot_gstride + lane * 4);
-  f32x4 acc[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) acc[i] = (f32x4){b4.x, b4.y, b4.z, b4.w};
-  for (int s = 0; s < a.S; ++s) {
-    f32x4 x[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int lr = min(lrow0 + 4 * i, lrow_end - 1);   // (rows past the end re-read the last row; never stored)
-      x[i] = ld_sc1(rs, gbase + (long)s * a.slab_stride + (long)lr * D);
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i) acc[i] += x[i];
-  }
-  float s1[R], s2[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s1[i] += acc[i][j]; s2[i] += acc[i][j] * acc[i][j]; }
-  }
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-    for (int i = 0; i < R; ++i) { s1[i] += __shfl_xor(s1[i], off); s2[i] += __shfl_xor(s2[i], off); }
-  }
-  float d[R];
-  const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w}, dwv[4] = {dw.x, dw.y, dw.z, dw.w};
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int lr = lrow0 + 4 * i;
-    const float mean = s1[i] * (1.0f / D), mean2 = s2[i] * (1.0f / D);
-    const float var = fmaxf(mean2 - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + 1e-6f);
-    d[i] = 0.f;
-    f32x4 xh4, y4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xh = (acc[i][j] - mean) * rstd;
-      const float pre = xh * gam[j] + bet[j];
-      const float y = a.relu ? fmaxf(pre, 0.f) : tanhf(pre);
-      xh4[j] = xh; y4[j] = y;
-      d[i] += y * dwv[j];
-    }
-    if (lr < lrow_end) {
-      const long row = (long)grp * a.rows_per_group + lr;
-      *reinterpret_cast<f32x4u*>(a.y + (long)lr * a.ld_y + (long)grp * a.y_goff + lane * 4) = y4;
-      if (a.xhat) *reinterpret_cast<f32x4*>(a.xhat + row * D + lane * 4) = xh4;
-      if (a.rstd && lane == 0) a.rstd[row] = rstd;
-    }
-  }
-  if (a.dot_out) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-      for (int i = 0; i < R; ++i) d[i] += __shfl_xor(d[i], off);
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int lr = lrow0 + 4 * i;
-      if (lane == 0 && lr < lrow_end) a.dot_out[(long)grp * a.rows_per_group + lr] = d[i] + a.dot_b[(long)grp * a.dot_b_gstride];
-    }
-  }
-}
-
 // tanh-Gaussian head of rows [r0, r1) from the head GEMM's slabs (actor_critic_nets.py:179-272): one thread per (row, action)
 template <bool LIVE>
 __device__ __forceinline__ void policy_dist_rows(const PolicyDistArgs& v, int r0, int r1, int tid, int nthreads) {
@@ -363,9 +285,9 @@ __device__ __forceinline__ void policy_logp_rows(const PolicyDistArgs& v, int r0
 }
 
 // the epilogue proper; `lds` = the kernel's operand LDS (>= kEpiScratch floats + 1 int), idle after the K loop.
-// WITH_LN: the LayerNorm reducer keeps 8 rows of slabs in flight per wave (~140 VGPRs); the GEMM instantiations that never run
-// it (backward / weight-gradient launches) are compiled without it and keep their ~40-VGPR footprint.
-template <bool WITH_LN>
+// (A LayerNorm + tanh reducer -- the last arriver of a 64-row tile normalising its rows -- existed in round 4: bit-identical, and
+// slower in every schedule than the separate LayerNorm launch that spreads the rows over the chip; removed, numbers in
+// profiles/README.md.)
 __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& acc, float* C, int z, int batch, int m0, int n0,
                                               float* lds, int tid) {
   store_tile_sc1(C, g.ldc, m0, n0, acc, lds, tid);
@@ -387,12 +309,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& a
       if (n + 4 <= g.N) *reinterpret_cast<f32x4u*>(o) = sum;
       else for (int j = 0; j < g.N - n; ++j) o[j] = sum[j];
     }
-  } else if (g.epi == kEpiLn) {
-    if (!WITH_LN) __builtin_trap();   // (the host picks the instantiation: cannot happen)
-    if (!arrive_is_last(g.ctr + (long)batch * tiles_m + blockIdx.y, tiles_n * g.splitk, flag)) return;
-    const int r_end = min(m0 + kGBM, g.M);
-    if (WITH_LN)
-      for (int r = m0 + wave; r < r_end; r += 32) ln_tanh_rows_live<8>(g.ln, batch, r, r_end, lane);
   } else {   // kEpiPolicy
     if (!arrive_is_last(g.ctr + blockIdx.y, g.nbatch * g.splitk * tiles_n, flag)) return;
     const int r_end = min(m0 + kGBM, g.M);
@@ -411,7 +327,7 @@ struct GemmMulti {
   int n;
 };
 
-template <bool A_KFAST, bool B_KFAST, bool WITH_LN = false>
+template <bool A_KFAST, bool B_KFAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
   static_assert(2 * kGTile >= kEpiScratch + 4, "the epilogue's transpose scratch lives in the operand LDS");
   __shared__ __attribute__((aligned(16))) float ABf[2 * kGTile];
@@ -456,7 +372,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmMulti mm) {
       __syncthreads();
     }
   }
-  if (g.epi) { gemm_epilogue<WITH_LN>(g, acc, C, z, batch, m0, n0, As, tid); return; }
+  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, As, tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -683,7 +599,7 @@ struct XLoader {
 // (131 KB) conv workgroups instead of waiting for one of them to retire and taking its place.
 // GATHER: the SmallEncoder's implicit-GEMM operand (GemmDesc::gtab) is compiled in -- a separate instantiation, because a
 // run-time "gather or not" inside the chunk loop makes every loaded value a phi and hipcc then waits right behind each load
-template <bool A_KFAST, bool B_KFAST, int BK, bool WITH_LN = false, bool GATHER = false>
+template <bool A_KFAST, bool B_KFAST, int BK, bool GATHER = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
   constexpr int kPlane = kGBM * BK * 2;
   static_assert(6 * kPlane >= (kEpiScratch + 4) * 4, "the epilogue's transpose scratch lives in the operand LDS");
@@ -751,7 +667,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmMulti mm) {
       }
     }
   }
-  if (g.epi) { gemm_epilogue<WITH_LN>(g, acc, C, z, batch, m0, n0, reinterpret_cast<float*>(AB), tid); return; }
+  if (g.epi) { gemm_epilogue(g, acc, C, z, batch, m0, n0, reinterpret_cast<float*>(AB), tid); return; }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -831,29 +747,24 @@ int gemm_f32_multi(const GemmDesc* gs, int n, hipStream_t stream) {
   dim3 grid(gx, gy, z);
   // SERL_GEMM=f32: the exact fp32-MFMA kernel (v_mfma_f32_32x32x2_f32) instead of bf16x3 -- A/B timing and parity runs
   static const bool exact = []() { const char* e = getenv("SERL_GEMM"); return e && e[0] == 'f'; }();
-  bool with_ln = false, any_epi = false;
-  for (int i = 0; i < n; ++i) { with_ln = with_ln || gs[i].epi == kEpiLn; any_epi = any_epi || gs[i].epi != kEpiNone; }
+  bool any_epi = false;
+  for (int i = 0; i < n; ++i) any_epi = any_epi || gs[i].epi != kEpiNone;
   SERL_REQUIRE(!any_epi || vec, "epilogue GEMMs need a vector layout");
-  // (the forward layers -- the only LayerNorm epilogues -- are A k-contiguous, B n-contiguous)
-  SERL_REQUIRE(!with_ln || (a_k && !b_k), "LayerNorm epilogue on an unexpected operand layout");
   if (vec && (!exact || gather)) {   // BK = 16 (12 KB of LDS); BK = 32 (24 KB) was measured 30 us per step slower next to the trunk pass
     bool any_tab = false;
     for (int i = 0; i < n; ++i) any_tab = any_tab || gs[i].gtab != nullptr;
-    SERL_REQUIRE(!(any_tab && with_ln), "gather GEMM with a LayerNorm epilogue");
     for (int i = 0; i < n; ++i) SERL_REQUIRE(!any_tab || gs[i].gtab != nullptr, "a gather launch mixes gathered and plain operands");
     if (any_tab) {
-      if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16, false, true>), grid, dim3(256), 0, stream, mm);
-      else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, false, true>), grid, dim3(256), 0, stream, mm);
-      else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16, false, true>), grid, dim3(256), 0, stream, mm);
-      else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16, false, true>), grid, dim3(256), 0, stream, mm);
-    } else if (with_ln) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, true>), grid, dim3(256), 0, stream, mm);
-    else if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
+      if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16, true>), grid, dim3(256), 0, stream, mm);
+      else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16, true>), grid, dim3(256), 0, stream, mm);
+      else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16, true>), grid, dim3(256), 0, stream, mm);
+      else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16, true>), grid, dim3(256), 0, stream, mm);
+    } else if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, true, 16>), grid, dim3(256), 0, stream, mm);
     else if (a_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<true, false, 16>), grid, dim3(256), 0, stream, mm);
     else if (b_k) SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, true, 16>), grid, dim3(256), 0, stream, mm);
     else SERL_LAUNCH_CHAIN((gemm_bf16x3_kernel<false, false, 16>), grid, dim3(256), 0, stream, mm);
   } else if (vec) {
-    if (with_ln) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, false, true>), grid, dim3(256), 0, stream, mm);
-    else if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
+    if (a_k && b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, mm);
     else if (a_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, mm);
     else if (b_k) SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, mm);
     else SERL_LAUNCH_CHAIN((gemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, mm);

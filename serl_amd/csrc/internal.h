@@ -109,7 +109,7 @@ struct PolicyDistArgs {
 // small kernel that consumed its slabs is replaced by an arrival counter per output tile -- every workgroup stores its slab
 // tile write-through (sc1), drains, bumps the tile's counter, and the workgroup that draws the last ticket reads the slabs back
 // (sc1 loads) IN INDEX ORDER and finishes the layer.  Same summation order as the separate kernels: bit-identical results.
-enum { kEpiNone = 0, kEpiReduce = 1, kEpiLn = 2, kEpiPolicy = 3 };
+enum { kEpiNone = 0, kEpiReduce = 1, kEpiPolicy = 3 };
 struct GemmDesc {
   const float* A;
   const float* B;
@@ -134,11 +134,10 @@ struct GemmDesc {
   // kEpiReduce: out[zg][m][n] = sum of the `zred` consecutive slabs z = zg*zred .. (one counter per 64x64 output tile)
   int zred = 1;
   float* out = nullptr; long ld_out = 0, out_gstride = 0;
-  // kEpiLn: one counter per (batch, 64-row tile); the last of its tiles_n * splitk workgroups applies bias + LayerNorm + tanh
   // kEpiPolicy: one counter per 64-row tile; the last of its nbatch * splitk workgroups samples the tanh-Gaussian
-  union { LnFwdArgs ln; PolicyDistArgs pd; };
+  PolicyDistArgs pd;
   GemmDesc() : A(nullptr), B(nullptr), C(nullptr), M(0), N(0), K(0), sAm(0), sAk(0), sAb(0), sBk(0), sBn(0), sBb(0), ldc(0), sCz(0),
-               nbatch(0), splitk(0), ln{} {}
+               nbatch(0), splitk(0), pd{} {}
 };
 int gemm_f32(const GemmDesc& g, hipStream_t stream);
 

@@ -233,91 +233,9 @@ __global__ __launch_bounds__(1024) void small_reduce_chunks_kernel(const float* 
   }
 }
 
-// Weight gradient of a conv layer l >= 1 on the exact fp32 matrix pipe, operands straight from global memory (the scheme of
-// small_conv0_wgrad_kernel): [dkernel ; dbias] = col^T x dy with col the VIRTUAL im2col matrix of the layer's NHWC input
-// (col[row][i] = in[tab[row] + (i / gseg) * gpitch + i % gseg], column K = ones).  A workgroup owns a 64 x 64 block of the
-// [K + 1][cout] result (2 x 2 MFMA tiles per wave: two A and two B values per row pair feed four MFMAs) over one chunk of rows;
-// its four waves take interleaved row pairs and add their accumulators through LDS in wave order; chunks are added in order by
-// small_reduce_chunks_kernel.  (The bf16x3 GEMM spends ~100 VALU instructions on splitting both operands per 6 MFMAs and its
-// K here is the row count: 584 us for layer 1.)  MEASURED SLOWER than that GEMM (layer 1: +57 us, layer 2: +235 us, layer 3: +168 us,
-// profiles/r04_ab_small_wgrad.log): with 2 x 2 tiles each operand value is still fetched from L2 once per 2 MFMAs.  Opt-in
-// (SERL_SMALL_WGRAD_MFMA = last layer that uses it), results within the same tolerance of the oracle.
-__global__ __launch_bounds__(256) void small_wgrad_mfma_kernel(const float* in, const int* tab, const float* dy, float* part, long rows_cam,
-                                                              int K, int cout, int gseg, long gpitch, int chunks, int iblocks) {
-  __shared__ float red[3][4][32 * 32];   // waves 1..3 x (2 x 2 tiles)
-  const int cam = blockIdx.z, chunk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ib = blockIdx.x % iblocks, jb = blockIdx.x / iblocks;   // 64 patch columns x 64 output channels
-  const int li = lane & 31, kk = lane >> 5;
-  const long per = ((rows_cam + chunks - 1) / chunks + 7) & ~7L;
-  const long r0 = (long)chunk * per, r1 = min(rows_cam, r0 + per);
-  int cpos[2], ckind[2];   // per A tile: offset of patch column i inside the patch; 0 = data, 1 = ones column, 2 = beyond K
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int i = ib * 64 + t * 32 + li;
-    ckind[t] = i < K ? 0 : (i == K ? 1 : 2);
-    const int ic = min(i, K - 1);
-    cpos[t] = (int)((ic / gseg) * gpitch + ic % gseg);
-  }
-  const int j0 = jb * 64 + li;
-  const bool jok[2] = {j0 < cout, j0 + 32 < cout};
-  f32x16s acc[2][2];
-#pragma unroll
-  for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a_][b_][r] = 0.f;
-  const int* tc = tab + (long)cam * rows_cam;
-  const float* dyc = dy + (long)cam * rows_cam * cout;
-  for (long m = r0 + 2 * wave + kk; m - kk < r1; m += 32) {   // 4 row pairs per iteration: their loads are in flight together
-    float a[4][2], b[4][2];
-    int tv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) tv[u] = tc[min(m + 8 * u, rows_cam - 1)];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long mu = m + 8 * u;
-      const bool ok = mu < r1;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float v = in[(long)tv[u] + cpos[t]];
-        a[u][t] = !ok ? 0.f : (ckind[t] == 0 ? v : (ckind[t] == 1 ? 1.0f : 0.f));
-      }
-      const float* dr = dyc + min(mu, rows_cam - 1) * cout + j0;
-      b[u][0] = (ok && jok[0]) ? dr[0] : 0.f;
-      b[u][1] = (ok && jok[1]) ? dr[jok[1] ? 32 : 0] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-        for (int b_ = 0; b_ < 2; ++b_) acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][a_], b[u][b_], acc[a_][b_], 0, 0, 0);
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-      for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][a_ * 2 + b_][((r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + li] = acc[a_][b_][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* o = part + ((long)cam * chunks + chunk) * (long)(K + 1) * cout;
-#pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-      for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * kk, row = ib * 64 + a_ * 32 + rr, col = jb * 64 + b_ * 32 + li;
-          const int x = rr * 32 + li, q = a_ * 2 + b_;
-          const float v = ((acc[a_][b_][r] + red[0][q][x]) + red[1][q][x]) + red[2][q][x];
-          if (row <= K && col < cout) o[(long)row * cout + col] = v;
-        }
-  }
-}
+// (An exact-fp32-MFMA weight-gradient kernel for layers 1-3 -- operands straight from global memory, the scheme of
+// small_conv0_wgrad_kernel -- was measured slower than the bf16x3 GEMM below in round 4 (layer 1: +57 us, layer 2: +235 us,
+// layer 3: +168 us, profiles/r04_ab_small_wgrad.log) and removed in round 5.)
 
 // tab[m] = offset (floats) of the first element of im2col row m = (image, oy, ox) in the layer's NHWC input
 __global__ __launch_bounds__(256) void small_patch_table_kernel(int* tab, long rows, int hi, int wi, int ho, int wo, int cin) {
@@ -468,19 +386,6 @@ int small_backward(SmallWorkspace& ws, const float* P, long conv_off, long cam_s
       SERL_HIP(hipGetLastError());
       break;   // the pixels need no gradient
     }
-    static const int mfma_from = []() { const char* e = getenv("SERL_SMALL_WGRAD_MFMA"); return e ? atoi(e) : 0; }();   // layers 1..mfma_from; opt-in: measured slower
-    if (l <= mfma_from) {   // exact fp32 MFMA straight from the activations (no operand split); per-chunk partials added in order
-      const int Kp = 9 * cin;   // ones column = patch column Kp
-      int chunks = (int)std::min<long>(128, std::max<long>(1, rows_cam / 512));
-      while (chunks > 1 && (long)chunks * n_cam * (Kp + 1) * cout > ws.slabs_cap) chunks >>= 1;
-      const int iblocks = cdiv(Kp + 1, 64), jblocks = cdiv(cout, 64);
-      hipLaunchKernelGGL(small_wgrad_mfma_kernel, dim3(iblocks * jblocks, chunks, n_cam), dim3(256), 0, stream, ws.act[l - 1], ws.tab[l], dy,
-                         ws.slabs, rows_cam, Kp, cout, 3 * cin, (long)d.w[l] * cin, chunks, iblocks);
-      SERL_HIP(hipGetLastError());
-      hipLaunchKernelGGL(small_reduce_chunks_kernel, dim3(cdiv((Kp + 1) * cout, 64), n_cam), dim3(1024), 0, stream, ws.slabs, chunks,
-                         (Kp + 1) * cout, G + conv_off + small_conv_offset(l), cam_stride);
-      SERL_HIP(hipGetLastError());
-    } else
     {  // [dkernel ; dbias]_cam = col_cam^T x dy_cam, K-split over the rows, written into the gradient arena
       // (deeper splits -- 512 or 256 rows per workgroup instead of 2048 -- were measured neutral in round 4: 5.84 / 5.87 / 5.89 ms)
       int S = (int)std::min<long>(64, std::max<long>(1, rows_cam / 2048));

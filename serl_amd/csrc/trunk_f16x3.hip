@@ -1200,11 +1200,20 @@ struct ConvInitArgsB {
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
   int chunk;            // tiles per scheduling chunk (divides tiles_y * tiles_x)
   int* ticket;          // chunk ticket (zeroed per pass)
-  int stagger;          // s_sleep(127) periods the second workgroup of every CU waits before its first tile (see the kernel)
-  int ablate;           // TIMING EXPERIMENTS ONLY (SERL_CINIT_ABLATE, results are wrong): 1 no patch fill, 2 no MFMAs, 4 no pooling epilogue, 8 no pixel fetch
+  int ablate;           // TIMING EXPERIMENTS ONLY, compiled in with -DSERL_ABLATE (never in the shipped library; SERL_CINIT_ABLATE, results
+                        // are wrong): 1 no patch fill, 2 no MFMAs, 4 no pooling epilogue, 8 no pixel fetch
 };
 
 constexpr int kCbPatch = 37;     // input rows/cols per 16x16 output tile
+// phase ablation of conv_init for timing experiments: a compile-time `false` unless the library is built with -DSERL_ABLATE
+__device__ __forceinline__ bool c8_ablate(const ConvInitArgsB& a, int bit) {
+#ifdef SERL_ABLATE
+  return (a.ablate & bit) != 0;
+#else
+  (void)a; (void)bit;
+  return false;
+#endif
+}
 
 // POOL: relu(GN(.)) is monotone in the raw conv output with the sign of the channel's GroupNorm scale gamma (a frozen
 // parameter), so max_pool(relu(GN(x))) = relu(GN(extreme(x))) with extreme = max where gamma >= 0 and min where
@@ -1306,14 +1315,8 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   // workgroup that cannot become resident at once (the update chain's kernels own some wave slots when the two streams
   // overlap) starts its whole share late and the kernel takes up to twice as long (measured 259 us alone, 485 us
   // co-running); with tickets a late workgroup simply takes fewer chunks.
-  // ANTI-PHASE: the persistent workgroups all start together and every tile takes the same time, so the chip tends to move
-  // through a tile's phases in lockstep -- everybody fills patches, everybody runs MFMAs (HBM idle), everybody writes pooled
-  // outputs (matrix pipe idle).  The second workgroup of every CU (blocks gridDim.x / 2 ..) starts half a tile late, which puts
-  // its output phase under its partner's MFMA phase.  Same-call A/B: conv_init 306 -> 296 us alone, step -0.8 % (serial and
-  // pipelined); the phases' times mostly still add up (their cost is issue slots / latency inside a wave, not a shared unit).
-  // Neutral (and off by default) since the epilogue's stores no longer stall the next tile's loads.
-  if (a.stagger > 0 && (int)blockIdx.x >= (int)gridDim.x / 2)
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  // (An anti-phase start -- the second workgroup of every CU half a tile late -- was worth 3 % of this kernel until the epilogue's
+  // stores stopped stalling the next tile's loads; neutral since, removed in round 5.)
   __shared__ int s_next_chunk;
   const int nchunks = a.total_tiles / a.chunk;
   float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int t = tid + 256 * q;
-      if (t < kTasks && !(a.ablate & 1)) {
+      if (t < kTasks && !c8_ablate(a, 1)) {
         const int r = t / kGroups, g = t - r * kGroups;
         // bytes 0..11 = pixels 0..3 x (c0,c1,c2); patch column of pixel j = 4g - 1 + j (column -1 is not stored)
         const uint32_t d0 = pre[q][0], d1 = pre[q][1], d2 = pre[q][2];
@@ -1361,7 +1364,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     if (first_of_chunk) next_chunk = __builtin_amdgcn_readfirstlane(s_next_chunk);   // written before this tile's first barrier; scalar, so that
                                                                                       // everything derived from the tile index stays uniform
     // next tile's bytes (the first tile of the next chunk after the last one of this chunk), in flight under the MFMAs
-    if (!(a.ablate & 8)) SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
+    if (!c8_ablate(a, 8)) SERL_C8_FETCH(min(tile + 1 < t_end ? tile + 1 : next_chunk * a.chunk, a.total_tiles - 1));
     // POOL == 2: the neighbours' first column / first row (raw values written by this workgroup at earlier tiles), fetched HERE so
     // that their L2 round trip lies under the MFMAs.  Branch-free (a tile without that neighbour reads elsewhere and ignores the
     // values; `wave == 3` is a scalar branch): loads inside an exec-masked region get an `s_waitcnt vmcnt(0)` right behind them.
@@ -1407,7 +1410,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-    if (!(a.ablate & 2))
+    if (!c8_ablate(a, 2))
 #pragma unroll
     for (int ks = 0; ks < kC8K / 16; ++ks) {
       const int aoff = (ks >> 1) * kC8Pitch + (ks & 1) * 32;   // kernel row ky = ks/2, k-blocks 2(ks&1) + lh
@@ -1474,7 +1477,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
             q[tn] += v * v;
           }
         }
-    } else if (a.ablate & 4) {
+    } else if (c8_ablate(a, 4)) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1630,13 +1633,11 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   const int tpi = a.tiles_y * a.tiles_x;
   a.chunk = (pool_gamma && complete_pool) ? tpi : (tpi % 4 == 0 ? 4 : (tpi % 2 == 0 ? 2 : 1));
   a.ticket = ticket;
-  // (default off since the load / store reordering of round 4: 247.9 us with 2 periods, 246.4 us with none, same call)
-  static const int stagger = []() { const char* e = getenv("SERL_CINIT_STAGGER"); return e ? atoi(e) : 0; }();   // 2 x ~4 us = half a tile
-  a.stagger = stagger;
+#ifdef SERL_ABLATE
   { const char* e = getenv("SERL_CINIT_ABLATE"); a.ablate = e ? atoi(e) : 0; }
-  // 2 persistent workgroups per CU
-  static const int max_grid = []() { const char* e = getenv("SERL_CINIT_GRID"); return e ? atoi(e) : 512; }();   // (256 = one workgroup per CU: timing experiments)
-  const int grid = std::min(a.total_tiles / a.chunk, max_grid);
+#endif
+  // 2 persistent workgroups per CU (one per CU was measured 278 -> 377 us: issue-bound at two waves per SIMD)
+  const int grid = std::min(a.total_tiles / a.chunk, 512);
   ProfScope prof("conv_init", stream);
   if (pool_gamma) {  // fused pooling: `out` (the raw_init buffer) is carved into the three compact outputs
     SERL_REQUIRE(Ho % 16 == 0 && Wo % 16 == 0, "fused conv_init pooling needs full 16x16 tiles");
