@@ -341,14 +341,29 @@ def main():
     macs = dict(macs)
     for host, rid in rider.items():
         macs[host] = macs[host] + macs[rid]
+    # depth-first stage-0/1 schedule (SERL_TRUNK_CHUNK): a timed launch of those stages covers one CHUNK of the pass
+    try:
+        trunk_chunk = 0 if small else int(core.trunk_plan().get("chunk", 0))
+    except Exception:
+        trunk_chunk = 0
+
+    def parts_of(tag):
+        if tag == "conv_init":
+            return ci_parts
+        if trunk_chunk and (tag.startswith("conv_igemm/b0_") or tag.startswith("conv_igemm/b1_")):
+            return max(1, n_img // trunk_chunk)
+        return 1
     for tag, (ms, cnt) in sorted(prof.items()):
         ent = {"avg_us": 1e3 * ms / cnt, "timed_launches": cnt}
         if tag in rider:
             ent["includes"] = rider[tag]
         if tag in ("conv_init", "gn_relu_maxpool") and ci_parts > 1:
             ent["launches_per_pass"] = ci_parts
+        if parts_of(tag) > 1 and tag != "conv_init":
+            ent["launches_per_pass"] = parts_of(tag)
+            ent["pass_us"] = 1e3 * ms / cnt * parts_of(tag)
         if tag in macs:
-            fl = 2.0 * macs[tag] * n_img / (ci_parts if tag == "conv_init" else 1)
+            fl = 2.0 * macs[tag] * n_img / parts_of(tag)
             ent["tflops"] = fl / (ms / cnt * 1e-3) / 1e12
             if tag.startswith("conv_igemm"):
                 tot_flop += fl * cnt
@@ -382,7 +397,7 @@ def main():
     # executed-MFMA fraction per stage (b0: row-patch kernel, b1..b3: LDS-DMA kernel + 1x1 projection)
     frac_by_stage = {}
     for st in range(4):
-        fl = sum(2.0 * macs[t] * n_img * c for t, (m, c) in prof.items() if t.startswith(f"conv_igemm/b{st}_") and t in macs)
+        fl = sum(2.0 * macs[t] * n_img / parts_of(t) * c for t, (m, c) in prof.items() if t.startswith(f"conv_igemm/b{st}_") and t in macs)
         ms_ = sum(m for t, (m, c) in prof.items() if t.startswith(f"conv_igemm/b{st}_") and t in macs)
         if ms_ > 0:
             frac_by_stage[f"b{st}"] = round((3.0 if args.trunk == "f16x3" else 1.0) * fl / (ms_ * 1e-3) / 1e12 /

@@ -293,7 +293,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& g, const f32x16& a
   store_tile_sc1(C, g.ldc, m0, n0, acc, lds, tid);
   int* flag = reinterpret_cast<int*>(lds + kEpiScratch);
   const int tiles_m = (g.M + kGBM - 1) / kGBM, tiles_n = (g.N + kGBN - 1) / kGBN;
-  const int lane = tid & 63, wave = tid >> 6;
   if (g.epi == kEpiReduce) {
     const int zg = z / g.zred;
     if (!arrive_is_last(g.ctr + ((long)zg * tiles_m + blockIdx.y) * tiles_n + blockIdx.x, g.zred, flag)) return;

@@ -422,8 +422,16 @@ static int note_gather(serl_rb* rb, hipStream_t stream) {
   return SERL_OK;
 }
 // ... and a gather enqueued after an insert sees it: `stream` waits for the last insert's copies.  Caller holds rb->mu.
+// Once the last insert's event has COMPLETED the flag is cleared and later gathers carry no wait at all: until round 5 the flag
+// was never cleared, so every gather -- the first command of every trunk pass -- opened with a cross-stream wait on a
+// long-finished event (one of the suspects for the 75-90 us of idle time at the pass boundary, profiles/README.md).
 static int order_after_inserts(serl_rb* rb, hipStream_t stream) {
-  if (rb->insert_pending) SERL_HIP(hipStreamWaitEvent(stream, rb->last_insert, 0));
+  if (!rb->insert_pending) return SERL_OK;
+  const hipError_t q = hipEventQuery(rb->last_insert);
+  if (q == hipSuccess) { rb->insert_pending = false; return SERL_OK; }
+  if (q != hipErrorNotReady) SERL_HIP(q);
+  (void)hipGetLastError();   // (hipErrorNotReady is sticky in hipGetLastError)
+  SERL_HIP(hipStreamWaitEvent(stream, rb->last_insert, 0));
   return SERL_OK;
 }
 

@@ -2217,77 +2217,118 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
       SERL_HIP(hipGetLastError());
     }
   }
-  const float* x = ws.pool;  // split16
-  int cin = 64;
   static const char* kTags[kTrunkStages][3] = {{"conv_igemm/b0_conv0", "conv_igemm/b0_conv1", "conv_igemm/b0_proj"},
                                                 {"conv_igemm/b1_conv0", "conv_igemm/b1_conv1", "conv_igemm/b1_proj"},
                                                 {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
                                                 {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
-  for (int i = 0; i < kTrunkStages; ++i) {
-    if (i >= 1) { x = ws.blk[i - 1].out; cin = kStageFilters[i - 1]; }
-    if (i < stage_begin || i > stage_end) continue;
+  // One residual stage over the images [img0, img0 + nimg) of the pass.  `in_img` / `mid_img` / `out_img`: the image index at which
+  // this launch sequence addresses its input tensor, its block-internal tensors (norm0, rawp, raw0, raw1) and its output tensor --
+  // all equal to img0 for a whole-batch pass; the DEPTH-FIRST schedule below re-uses one chunk-sized window (index 0) for every
+  // tensor that is produced and consumed inside a chunk.  Statistics and arrival counters are always addressed at img0 (they are
+  // zeroed once per pass); a launch's tile tickets start at zero, so every chunk takes its own 8 ticket words (`tk`).
+  auto run_stage = [&](int i, int img0, int nimg, int in_img, int mid_img, int out_img, int tk) -> int {
+    const int cin = i == 0 ? 64 : kStageFilters[i - 1];
     const int f = kStageFilters[i], s = kStageStride[i];
     const int Hi = d.h[1 + i], Wi = d.w[1 + i], Ho = d.h[2 + i], Wo = d.w[2 + i], P = Ho * Wo;
     const int l0 = 1 + 3 * i, l1 = 2 + 3 * i, lp = 3 + 3 * i;
+    const size_t in_px = (size_t)Hi * Wi * cin, out_px = (size_t)P * f;   // floats per image (split8 = the fp32 footprint)
     const TrunkWeights::Block& bw = w.blk[i];
     const bool has_proj = bw.proj != nullptr;
+    auto st_of = [&](int layer) { return stats_of(layer) + (size_t)img0 * kGnGroups * 2; };
+    auto fz_of = [&](int layer, int mode) {
+      FuseArgs fz = fuse_of(layer, mode);
+      fz.sync += (size_t)img0 * kSyncPerImage;
+      fz.ticket += tk * 8;
+      return fz;
+    };
+    const GnRef gn_in = gn_ref_b(stats_of(0) + (size_t)img0 * kGnGroups * 2, w.gn_init_s, w.gn_init_b, d.h[0] * d.w[0], 64);
+    const float* x = (i == 0 ? ws.pool : ws.blk[i - 1].out) + (size_t)in_img * in_px;   // split16
+    float* const raw0 = ws.blk[i].raw0 + (size_t)mid_img * out_px;
+    float* const raw1 = ws.blk[i].raw1 + (size_t)mid_img * out_px;
+    float* const rawp = ws.blk[i].rawp ? ws.blk[i].rawp + (size_t)mid_img * out_px : nullptr;
+    float* const norm0 = ws.blk[i].norm0 + (size_t)mid_img * out_px;
+    float* const outp = ws.blk[i].out + (size_t)out_img * out_px;
     auto pw = [&](int which) { return PackedConvWeights{pk.blk[i][which].hi, pk.blk[i][which].lo, pk.blk[i][which].inv, pk.blk[i][which].slab, pk.blk[i][which].dma}; };
+    int rc;
     // GroupNorm + ReLU (+ residual) + split8 in the conv epilogue where the kernel for this shape supports it
     // (fz.mode comes back 0 otherwise and the elementwise pass below runs instead)
-    FuseArgs fz0 = fuse_of(l0, 1);
-    fz0.gn = gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f);
-    fz0.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].norm0);
+    FuseArgs fz0 = fz_of(l0, 1);
+    fz0.gn = gn_ref_b(st_of(l0), bw.gn0_s, bw.gn0_b, P, f);
+    fz0.out_split = reinterpret_cast<uint8_t*>(norm0);
     const bool raw_in = i == 0 && raw_b0;
-    const RawInput rin{ws.raw_init, gn_init};
-    // OPT-IN (SERL_PROJ_FUSE=1; built at the end of round 4 without GPU time left: NOT yet run on hardware): conv0's workgroups
-    // compute the block's projection tile too -- no projection launch (b1 / b2 / b3_proj: 76 + 46 + 31 us of a 2.5 ms step,
-    // latency-bound two-round launches), one more pass over tap (0, 0) of an input tile that conv0 fetches anyway
-    const char* pf_e = getenv("SERL_PROJ_FUSE");   // (read per pass: the probe / test flips it inside one process)
+    const RawInput rin{ws.raw_init + (size_t)in_img * in_px, gn_in};
+    // SERL_PROJ_FUSE=1 (opt-in): conv0's workgroups compute the block's projection tile too -- no projection launch, one more
+    // pass over tap (0, 0) of an input tile that conv0 fetches anyway (tests/test_agent_gpu.py::test_fused_projection)
+    const char* pf_e = getenv("SERL_PROJ_FUSE");   // (read per pass: the test flips it inside one process)
     const bool proj_fuse = pf_e && pf_e[0] == '1';
-    ProjFuse pf{pw(2), ws.blk[i].rawp, stats_of(lp), false};
-    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), ws.blk[i].raw0, stats_of(l0), N, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
+    ProjFuse pf{pw(2), rawp, st_of(lp), false};
+    if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), raw0, st_of(l0), nimg, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
                                 raw_in ? &rin : nullptr, &ws.plan.conv[i][0], ws.kslab, ws.kctr, has_proj && proj_fuse ? &pf : nullptr))) return rc;
     SERL_REQUIRE(!raw_in || fz0.mode, "block 0 was planned on the fused row-slab path");
     if (has_proj && pf.done) {
       ws.plan.conv[i][2] = ws.plan.conv[i][0];
       ws.plan.conv[i][2].kern = 'F'; ws.plan.conv[i][2].fused = 0;   // 'F': rode on conv0's launch
     } else if (has_proj)
-      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), ws.blk[i].rawp, stats_of(lp), N, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero, nullptr,
+      if ((rc = launch_conv_f16x3(kTags[i][2], x, pw(2), rawp, st_of(lp), nimg, Hi, Wi, cin, Ho, Wo, f, 1, s, stream, pk.zero, nullptr,
                                   nullptr, &ws.plan.conv[i][2], ws.kslab, ws.kctr))) return rc;
-    const long tot = (long)N * P * (f / 4);
+    const long tot = (long)nimg * P * (f / 4);
     if (!fz0.mode) {
       ProfScope prof("gn_relu_split", stream);
-      hipLaunchKernelGGL(gn_relu_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw0,
-                         gn_ref_b(stats_of(l0), bw.gn0_s, bw.gn0_b, P, f), reinterpret_cast<uint4*>(ws.blk[i].norm0), N, P, f);
+      hipLaunchKernelGGL(gn_relu_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, raw0,
+                         gn_ref_b(st_of(l0), bw.gn0_s, bw.gn0_b, P, f), reinterpret_cast<uint4*>(norm0), nimg, P, f);
       SERL_HIP(hipGetLastError());
     }
     const bool last = i == kTrunkStages - 1;
-    FuseArgs fz1 = fuse_of(l1, last ? 0 : (has_proj ? 3 : (raw_in ? 4 : 2)));
-    fz1.gn = gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f);
-    fz1.out_split = reinterpret_cast<uint8_t*>(ws.blk[i].out);
+    FuseArgs fz1 = fz_of(l1, last ? 0 : (has_proj ? 3 : (raw_in ? 4 : 2)));
+    fz1.gn = gn_ref_b(st_of(l1), bw.gn1_s, bw.gn1_b, P, f);
+    fz1.out_split = reinterpret_cast<uint8_t*>(outp);
     if (has_proj) {
-      fz1.res_raw = ws.blk[i].rawp;
-      fz1.res_gn = gn_ref_b(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f);
+      fz1.res_raw = rawp;
+      fz1.res_gn = gn_ref_b(st_of(lp), bw.gnp_s, bw.gnp_b, P, f);
     } else if (raw_in) {
-      fz1.res_raw = ws.raw_init;
-      fz1.res_gn = gn_init;
+      fz1.res_raw = rin.raw;
+      fz1.res_gn = gn_in;
     } else {
       fz1.res_split = reinterpret_cast<const uint8_t*>(x);
     }
-    if ((rc = launch_conv_f16x3(kTags[i][1], ws.blk[i].norm0, pw(1), ws.blk[i].raw1, stats_of(l1), N, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1,
+    if ((rc = launch_conv_f16x3(kTags[i][1], norm0, pw(1), raw1, st_of(l1), nimg, Ho, Wo, f, Ho, Wo, f, 3, 1, stream, pk.zero, &fz1,
                                 nullptr, &ws.plan.conv[i][1], ws.kslab, ws.kctr))) return rc;
     SERL_REQUIRE(!raw_in || fz1.mode, "block 0 was planned on the fused row-slab path");
     if (!fz1.mode) {
       ProfScope prof("block_out", stream);
-      hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, ws.blk[i].raw1,
-                         gn_ref_b(stats_of(l1), bw.gn1_s, bw.gn1_b, P, f),
-                         has_proj ? nullptr : reinterpret_cast<const uint4*>(x), has_proj ? ws.blk[i].rawp : nullptr,
-                         has_proj ? gn_ref_b(stats_of(lp), bw.gnp_s, bw.gnp_b, P, f) : GnRef{},
-                         last ? nullptr : reinterpret_cast<uint4*>(ws.blk[i].out), last ? feats_out : nullptr, N, P, f);
+      hipLaunchKernelGGL(block_out_split_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, raw1,
+                         gn_ref_b(st_of(l1), bw.gn1_s, bw.gn1_b, P, f),
+                         has_proj ? nullptr : reinterpret_cast<const uint4*>(x), has_proj ? rawp : nullptr,
+                         has_proj ? gn_ref_b(st_of(lp), bw.gnp_s, bw.gnp_b, P, f) : GnRef{},
+                         last ? nullptr : reinterpret_cast<uint4*>(outp), last ? feats_out + (size_t)out_img * out_px : nullptr, nimg, P, f);
       SERL_HIP(hipGetLastError());
     }
-    x = ws.blk[i].out;
-    cin = f;
+    return SERL_OK;
+  };
+  // DEPTH-FIRST over image chunks (SERL_TRUNK_CHUNK=<images>, stages 0 and 1 of a raw_b0 pass): stage 0 -> stage 1 of one chunk
+  // before the next chunk, every tensor produced and consumed inside a chunk living in ONE chunk-sized window that the next
+  // chunk overwrites -- at 256 images that window set is ~235 MB (norm0 / out of block 0: 67 MB each, norm0 / rawp of block 1:
+  // 33.5 MB each, plus the 67 MB slice of the raw pooled tensor a chunk reads twice), which the 256 MiB Infinity Cache can hold:
+  // the HBM-bound fused epilogues (residual read + split8 write, 114 of b0_conv1's 351 us) then move cache lines that never
+  // have to reach HBM.  Stage 1's output goes to its place in the whole-batch tensor; stages 2 and 3 run over the whole batch
+  // (their per-image tensors are small and their kernels lose efficiency at small M).
+  int chunk = 0;
+  { const char* e = getenv("SERL_TRUNK_CHUNK"); chunk = e ? atoi(e) : 0; }
+  const bool chunked = chunk > 0 && raw_b0 && N % chunk == 0 && N / chunk >= 2 && N / chunk <= kSyncTickets / 8 && chunk % 8 == 0 &&
+                       stage_begin <= 0 && stage_end >= 1 &&
+                       fused_can_wait(stream, P0 / 256 * (kStageFilters[0] / 64));
+  ws.plan.chunk = chunked ? chunk : 0;
+  for (int i = 0; i < kTrunkStages; ++i) {
+    if (i < stage_begin || i > stage_end) continue;
+    if (chunked && i == 0) {
+      for (int c = N / chunk - 1; c >= 0; --c) {   // (last images first: conv_init wrote them last)
+        if ((rc = run_stage(0, c * chunk, chunk, c * chunk, 0, 0, c))) return rc;
+        if ((rc = run_stage(1, c * chunk, chunk, 0, 0, c * chunk, c))) return rc;
+      }
+      continue;
+    }
+    if (chunked && i == 1) continue;
+    if ((rc = run_stage(i, 0, N, 0, 0, 0, 0))) return rc;
   }
   if (fuse_on && stage_end == kTrunkStages - 1) fused_pass_issued(stream);
   return SERL_OK;
