@@ -334,24 +334,16 @@ def main():
     ci_parts = 1
     if "conv_init_pool" in prof and "conv_init" in prof:
         ci_parts = max(1, int(round(prof["conv_init"][1] / max(prof["conv_init_pool"][1], 1))))
-    # SERL_PROJ_FUSE=1 (opt-in): a block's projection rides on its conv0 launch -- no b{i}_proj launch is timed, conv0's
+    # fused projection (default; SERL_PROJ_FUSE=0 switches it off): a block's projection rides on its conv0 launch -- no b{i}_proj launch is timed, conv0's
     # duration covers both, so conv0 is credited with both FLOP counts
     rider = {f"conv_igemm/b{i}_conv0": f"conv_igemm/b{i}_proj" for i in range(1, 4)
              if f"conv_igemm/b{i}_proj" in macs and f"conv_igemm/b{i}_proj" not in prof and f"conv_igemm/b{i}_conv0" in prof}
     macs = dict(macs)
     for host, rid in rider.items():
         macs[host] = macs[host] + macs[rid]
-    # depth-first stage-0/1 schedule (SERL_TRUNK_CHUNK): a timed launch of those stages covers one CHUNK of the pass
-    try:
-        trunk_chunk = 0 if small else int(core.trunk_plan().get("chunk", 0))
-    except Exception:
-        trunk_chunk = 0
-
     def parts_of(tag):
         if tag == "conv_init":
             return ci_parts
-        if trunk_chunk and (tag.startswith("conv_igemm/b0_") or tag.startswith("conv_igemm/b1_")):
-            return max(1, n_img // trunk_chunk)
         return 1
     for tag, (ms, cnt) in sorted(prof.items()):
         ent = {"avg_us": 1e3 * ms / cnt, "timed_launches": cnt}
@@ -407,9 +399,10 @@ def main():
         # 3x the algorithmic FLOPs, and that executed rate is what the fp16-MFMA roofline bounds
         executed = 3.0 * achieved
         roofline = {"bound": "mfma",
-                    "kernel": ("block convs of the frozen trunk, 11 launches per pass: conv3x3_rowslab_f16x3_kernel (both stage-0 convs and "
-                               "b1_conv1) + conv_dma_f16x3_kernel (every other 3x3 conv and the three 1x1 projections)" if Bl * len(KEYS) * 2 >= 1024 else
-                               "block convs of the frozen trunk, 11 launches per pass: conv3x3_rowslab_f16x3_kernel (stage 0, b1_conv1), "
+                    "kernel": (f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel (both stage-0 convs and "
+                               "b1_conv1) + conv_dma_f16x3_kernel (every other 3x3 conv; the three 1x1 projections ride on their block's conv0 launch "
+                               "unless SERL_PROJ_FUSE=0)" if Bl * len(KEYS) * 2 >= 1024 else
+                               f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel (stage 0, b1_conv1), "
                                "conv_dma_f16x3_kernel where at least 512 128-row tiles exist, conv_igemm_f16x3_kernel (64x64 tiles) otherwise") +
                               "; split-fp16 MFMA implicit GEMM, fp32 accumulate",
                     "achieved": round(executed, 3), "peak": PEAK_F16_MFMA, "unit": "TFLOP/s",

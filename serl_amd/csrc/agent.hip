@@ -1502,7 +1502,7 @@ int64_t serl_debug_chain_launches(void) { return (int64_t)g_chain_launches; }
 int serl_agent_trunk_plan(serl_agent* a, char* out, int cap) {
   SERL_REQUIRE(a && out && cap > 0, "bad argument");
   const TrunkPlan& p = a->tws.plan;
-  std::string s = "images=" + std::to_string(p.images) + " pool=" + std::to_string(p.pool) + " raw_b0=" + std::to_string(p.raw_b0) + " chunk=" + std::to_string(p.chunk);
+  std::string s = "images=" + std::to_string(p.images) + " pool=" + std::to_string(p.pool) + " raw_b0=" + std::to_string(p.raw_b0);
   static const char* kNames[3] = {"conv0", "conv1", "proj"};
   for (int i = 0; i < kTrunkStages; ++i)
     for (int k = 0; k < 3; ++k) {

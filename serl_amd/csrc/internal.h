@@ -26,7 +26,7 @@ struct TrunkDims {
 };
 TrunkDims trunk_dims(int H, int W);
 
-constexpr int kSyncPerImage = 8, kSyncTickets = 64;   // tickets: 8 per launch (one per XCD) x up to 8 image chunks of a depth-first pass
+constexpr int kSyncPerImage = 8, kSyncTickets = 16;   // tickets: 8 per launch (one per XCD)
 constexpr int kKsplitTiles = 1024;   // partial tiles (workgroups) a K-split conv launch may use: 16 MB of scratch
 // Which kernels the last split-fp16 pass selected (introspection for the parity tests: the shapes a data-parallel rank runs
 // choose other kernels than the full batch does).  kern: 'S' row-slab, 'D' LDS-DMA, 'R' register-staged implicit GEMM,
@@ -35,7 +35,6 @@ struct TrunkPlan {
   int images = 0;
   int pool = 0;      // 0: separate GroupNorm + max-pool pass, 1: pooled in conv_init + pool_finish, 2: completed in conv_init
   int raw_b0 = 0;    // block 0 reads conv_init's raw pooled tensor (RAWIN)
-  int chunk = 0;     // images per chunk of the depth-first stage-0/1 schedule (0: whole-batch launches)
   struct L { char kern = 0; int cfg = 0, pmode = 0, fused = 0, ksplit = 1; } conv[kTrunkStages][3];
 };
 struct TrunkWorkspace {

@@ -427,6 +427,8 @@ static int note_gather(serl_rb* rb, hipStream_t stream) {
 // long-finished event (one of the suspects for the 75-90 us of idle time at the pass boundary, profiles/README.md).
 static int order_after_inserts(serl_rb* rb, hipStream_t stream) {
   if (!rb->insert_pending) return SERL_OK;
+  static const bool old_wait = []() { const char* e = getenv("SERL_RB_OLD_WAIT"); return e && e[0] == '1'; }();   // TEMPORARY (A/B of round 5)
+  if (old_wait) { SERL_HIP(hipStreamWaitEvent(stream, rb->last_insert, 0)); return SERL_OK; }
   const hipError_t q = hipEventQuery(rb->last_insert);
   if (q == hipSuccess) { rb->insert_pending = false; return SERL_OK; }
   if (q != hipErrorNotReady) SERL_HIP(q);

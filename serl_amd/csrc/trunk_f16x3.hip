@@ -2222,10 +2222,9 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
                                                 {"conv_igemm/b2_conv0", "conv_igemm/b2_conv1", "conv_igemm/b2_proj"},
                                                 {"conv_igemm/b3_conv0", "conv_igemm/b3_conv1", "conv_igemm/b3_proj"}};
   // One residual stage over the images [img0, img0 + nimg) of the pass.  `in_img` / `mid_img` / `out_img`: the image index at which
-  // this launch sequence addresses its input tensor, its block-internal tensors (norm0, rawp, raw0, raw1) and its output tensor --
-  // all equal to img0 for a whole-batch pass; the DEPTH-FIRST schedule below re-uses one chunk-sized window (index 0) for every
-  // tensor that is produced and consumed inside a chunk.  Statistics and arrival counters are always addressed at img0 (they are
-  // zeroed once per pass); a launch's tile tickets start at zero, so every chunk takes its own 8 ticket words (`tk`).
+  // this launch sequence addresses its input tensor, its block-internal tensors (norm0, rawp, raw0, raw1) and its output tensor
+  // (all 0 and nimg = N for the whole-batch pass; a sub-batch schedule can window them).  Statistics and arrival counters are
+  // addressed at img0 (zeroed once per pass); a launch's tile tickets start at zero, so a sub-batch takes its own 8 ticket words (`tk`).
   auto run_stage = [&](int i, int img0, int nimg, int in_img, int mid_img, int out_img, int tk) -> int {
     const int cin = i == 0 ? 64 : kStageFilters[i - 1];
     const int f = kStageFilters[i], s = kStageStride[i];
@@ -2257,10 +2256,11 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     fz0.out_split = reinterpret_cast<uint8_t*>(norm0);
     const bool raw_in = i == 0 && raw_b0;
     const RawInput rin{ws.raw_init + (size_t)in_img * in_px, gn_in};
-    // SERL_PROJ_FUSE=1 (opt-in): conv0's workgroups compute the block's projection tile too -- no projection launch, one more
-    // pass over tap (0, 0) of an input tile that conv0 fetches anyway (tests/test_agent_gpu.py::test_fused_projection)
+    // FUSED PROJECTION (default; SERL_PROJ_FUSE=0 restores the separate launch): conv0's workgroups compute the block's projection
+    // tile too -- no projection launch, one more pass over tap (0, 0) of an input tile that conv0 fetches anyway.  Same-call A/B
+    // (profiles/r05_call1): pipelined step 2.557 -> 2.535 ms, serial 3.000 -> 2.970; tests/test_agent_gpu.py::test_fused_projection
     const char* pf_e = getenv("SERL_PROJ_FUSE");   // (read per pass: the test flips it inside one process)
-    const bool proj_fuse = pf_e && pf_e[0] == '1';
+    const bool proj_fuse = !(pf_e && pf_e[0] == '0');
     ProjFuse pf{pw(2), rawp, st_of(lp), false};
     if ((rc = launch_conv_f16x3(kTags[i][0], x, pw(0), raw0, st_of(l0), nimg, Hi, Wi, cin, Ho, Wo, f, 3, s, stream, pk.zero, &fz0,
                                 raw_in ? &rin : nullptr, &ws.plan.conv[i][0], ws.kslab, ws.kctr, has_proj && proj_fuse ? &pf : nullptr))) return rc;
@@ -2305,29 +2305,12 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
     }
     return SERL_OK;
   };
-  // DEPTH-FIRST over image chunks (SERL_TRUNK_CHUNK=<images>, stages 0 and 1 of a raw_b0 pass): stage 0 -> stage 1 of one chunk
-  // before the next chunk, every tensor produced and consumed inside a chunk living in ONE chunk-sized window that the next
-  // chunk overwrites -- at 256 images that window set is ~235 MB (norm0 / out of block 0: 67 MB each, norm0 / rawp of block 1:
-  // 33.5 MB each, plus the 67 MB slice of the raw pooled tensor a chunk reads twice), which the 256 MiB Infinity Cache can hold:
-  // the HBM-bound fused epilogues (residual read + split8 write, 114 of b0_conv1's 351 us) then move cache lines that never
-  // have to reach HBM.  Stage 1's output goes to its place in the whole-batch tensor; stages 2 and 3 run over the whole batch
-  // (their per-image tensors are small and their kernels lose efficiency at small M).
-  int chunk = 0;
-  { const char* e = getenv("SERL_TRUNK_CHUNK"); chunk = e ? atoi(e) : 0; }
-  const bool chunked = chunk > 0 && raw_b0 && N % chunk == 0 && N / chunk >= 2 && N / chunk <= kSyncTickets / 8 && chunk % 8 == 0 &&
-                       stage_begin <= 0 && stage_end >= 1 &&
-                       fused_can_wait(stream, P0 / 256 * (kStageFilters[0] / 64));
-  ws.plan.chunk = chunked ? chunk : 0;
+  // (A DEPTH-FIRST schedule -- stages 0 and 1 issued chunk by chunk over 128 / 256 / 512 images with every chunk-local tensor in one
+  // re-used window sized for the 256 MiB Infinity Cache -- was built and measured in round 5: correct, and SLOWER in every
+  // configuration (pipelined step 2.557 -> 2.638 / 2.739 / 3.030 ms at 512 / 256 / 128 images per chunk, serial 3.000 -> 3.109):
+  // the kernels lose more at small M than cache-resident tensors give back.  Removed; profiles/README.md, r05_call1.)
   for (int i = 0; i < kTrunkStages; ++i) {
     if (i < stage_begin || i > stage_end) continue;
-    if (chunked && i == 0) {
-      for (int c = N / chunk - 1; c >= 0; --c) {   // (last images first: conv_init wrote them last)
-        if ((rc = run_stage(0, c * chunk, chunk, c * chunk, 0, 0, c))) return rc;
-        if ((rc = run_stage(1, c * chunk, chunk, 0, 0, c * chunk, c))) return rc;
-      }
-      continue;
-    }
-    if (chunked && i == 1) continue;
     if ((rc = run_stage(i, 0, N, 0, 0, 0, 0))) return rc;
   }
   if (fuse_on && stage_end == kTrunkStages - 1) fused_pass_issued(stream);

@@ -53,7 +53,7 @@ def test_trunk_forward_with_the_opt_in_conv_k_split(gpu, ksplit, monkeypatch):
 
 @pytest.mark.parametrize("n", [1024, 128])
 def test_fused_projection(gpu, n, monkeypatch):
-    """SERL_PROJ_FUSE=1: a block's 1x1 stride-2 projection computed by conv0's workgroups (conv_dma_f16x3_kernel<.., PROJ = true>;
+    """Default since round 5 (SERL_PROJ_FUSE=0 = separate launch): a block's 1x1 stride-2 projection computed by conv0's workgroups (conv_dma_f16x3_kernel<.., PROJ = true>;
     resnet_v1.py:129-156 -- the projection's pixel is conv0's tap (0, 0)).  At 1024 images all three projections ride
     (plan 'F'); at 128 images (a rank's share) the stages that leave the LDS-DMA kernel keep their own launch.  Features within
     5e-6 of the fp64 oracle and within fp32 round-off of the pass with separate projection launches."""
@@ -75,31 +75,6 @@ def test_fused_projection(gpu, n, monkeypatch):
     ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
     err = AH.rel_err(fus[sel].cpu().numpy(), ref)
     print(f"fused projection n={n}: rel err vs fp64 = {err:.2e}")
-    assert err < 5e-6, err
-
-
-@pytest.mark.parametrize("chunk", [256, 512])
-def test_depth_first_chunks_of_stage_0_and_1(gpu, chunk, monkeypatch):
-    """SERL_TRUNK_CHUNK: stages 0 and 1 issued depth-first over image chunks, chunk-local tensors in one re-used window
-    (trunk_f16x3.hip; resnet_v1.py:260-269).  Same kernels on the same images: features equal the whole-batch pass up to the
-    order of the fp64 statistics atomics, and stay within 5e-6 of the fp64 oracle; the plan reports the chunk."""
-    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
-    n = 1024
-    st, core = AH.make_pair(cfg, B=n // 2, trunk_mode="f16x3")
-    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
-    monkeypatch.setenv("SERL_TRUNK_CHUNK", "0")
-    whole = core.trunk_forward(img).clone()
-    assert core.trunk_plan()["chunk"] == 0
-    monkeypatch.setenv("SERL_TRUNK_CHUNK", str(chunk))
-    for rep in range(3):       # (the window is re-used across chunks AND across passes)
-        got = core.trunk_forward(img).clone()
-        assert core.trunk_plan()["chunk"] == chunk, core.trunk_plan()
-        scale = float(whole.abs().max())
-        assert float((got - whole).abs().max()) / scale < 2e-6, rep
-    sel = list(range(4)) + list(range(chunk - 2, chunk + 2)) + list(range(n - 4, n))
-    ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
-    err = AH.rel_err(got[sel].cpu().numpy(), ref)
-    print(f"depth-first chunk {chunk}: rel err vs fp64 = {err:.2e}")
     assert err < 5e-6, err
 
 
