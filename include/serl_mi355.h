@@ -332,6 +332,57 @@ int serl_classifier_get(serl_classifier* c, const char* leaf, float* host_out, i
 /* dev_frames u8[n_cam][n][H][W][3] (device), n <= max_batch; dev_logits f32[n] (device) */
 int serl_classifier_logits(serl_classifier* c, const uint8_t* dev_frames, int n, float* dev_logits, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * JAX's PRNG (threefry2x32, non-partitionable; jax/_src/prng.py, jax/_src/random.py of jax 0.4.x) -- csrc/jaxrng.hip.
+ * The reference learner draws its crop offsets (vision/data_augmentations.py:7-36), REDQ indices (agents/continuous/sac.py:150-157),
+ * policy noise (sac.py:118-132,197-201,224-227) and Dropout masks from jax.random and advances `state.rng` as
+ * common/common.py:197-209, sac.py:287-289 and agents/continuous/drq.py:276-318 do.  These entry points reproduce that stream:
+ * keys, integers and the 32-bit draws behind every sample are bit-exact; normals follow XLA's float32 erf_inv polynomial.
+ * A key is uint32[2] (jax.random.PRNGKey(seed) = {seed >> 32, seed & 0xffffffff}).  The host functions need no device.
+ * --------------------------------------------------------------------------------------------- */
+int serl_jax_prngkey(uint64_t seed, uint32_t key_out[2]);                              /* jax.random.PRNGKey */
+int serl_jax_split(const uint32_t key[2], int num, uint32_t* keys_out /* [num][2] */); /* jax.random.split */
+int serl_jax_fold_in(const uint32_t key[2], uint32_t data, uint32_t key_out[2]);       /* jax.random.fold_in */
+int serl_jax_random_bits(const uint32_t key[2], int64_t n, uint32_t* out);             /* jax.random.bits(key, (n,)) */
+int serl_jax_randint(const uint32_t key[2], int64_t n, int32_t minval, int32_t maxval, int32_t* out); /* jax.random.randint */
+int serl_jax_normal_host(const uint32_t key[2], int64_t n, float* out);                /* jax.random.normal(key, (n,)) on the host */
+/* batched_random_crop's offsets (data_augmentations.py:22-36): keys = split(key, frames); (y, x)_i = randint(keys[i], (2,), 0,
+ * 2*padding + 1) -> yx_out int32[frames][2].  The SAME key serves every camera (drq.py:244-253). */
+int serl_jax_crop_offsets(const uint32_t key[2], int frames, int padding, int32_t* yx_out);
+/* Every key ONE learner call derives from state.rng, in the reference's order:
+ *   drq_aug != 0 (DrQAgent.update_critics / update_high_utd, drq.py:276-277,307-308): rng, k_obs, k_next = split(rng, 3)
+ *   then n_critic critic-only SACAgent.update calls and, if has_actor_temp, one actor + temperature update (sac.py:544-596); each:
+ *     _, r_actor, r_critic, r_temp = split(rng, 4)                                          (common.py:197-200, sorted loss names)
+ *     critic:  c, k_next_action = split(r_critic);  _, k_subsample = split(c)               (sac.py:137,151)
+ *     actor:   _, k_policy, k_sample, _ = split(r_actor, 4);  _, k_temp = split(r_temp)     (sac.py:197,222)
+ *     rng = split(rng)[0]                                                                   (sac.py:287-289)
+ * k_next_action / k_policy / k_temp are BOTH the Dropout rng of that policy forward and (k_next_action, k_temp) its sample seed
+ * (sac.py:122-128); k_sample seeds the policy-loss sample.  rng_out is state.rng after the call. */
+#define SERL_JAX_MAX_UTD 32
+typedef struct serl_jax_update_keys_t {
+  uint32_t rng_out[2];
+  uint32_t k_obs[2], k_next[2];
+  int32_t n_critic;
+  uint32_t k_next_action[SERL_JAX_MAX_UTD][2];
+  uint32_t k_subsample[SERL_JAX_MAX_UTD][2];
+  uint32_t k_policy[2], k_sample[2], k_temp[2];
+} serl_jax_update_keys_t;
+int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int has_actor_temp, serl_jax_update_keys_t* out);
+/* Device draws: job i writes elements [first, first + count) of the flat array a JAX call of `n_total` elements returns
+ * (a rank of a data-parallel job, or a minibatch window, fills its rows only):
+ *   SERL_JAX_NORMAL       f32  jax.random.normal(key, shape)             SERL_JAX_BERNOULLI_U8  u8  jax.random.bernoulli(key, p, shape)
+ *   SERL_JAX_BITS         u32  jax.random.bits(key, shape)
+ * One launch for up to 16 jobs on `stream`. */
+enum { SERL_JAX_NORMAL = 0, SERL_JAX_BERNOULLI_U8 = 1, SERL_JAX_BITS = 2 };
+typedef struct serl_jax_job {
+  uint32_t key[2];
+  int32_t kind;
+  float p;              /* bernoulli probability of a 1 */
+  int64_t n_total, first, count;
+  void* out;            /* device */
+} serl_jax_job;
+int serl_jax_fill(int device, const serl_jax_job* jobs, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,6 +201,10 @@ class Module:
         key = (name, self._path)
         c = self._scope.rng_counters.get(key, 0)
         self._scope.rng_counters[key] = c + 1
+        if jrandom._threefry_on():   # flax >= 0.8's own derivation (threefry.flax_fold_in_static): path names + call counter from 1
+            from jax import threefry as _tf
+            k = _tf.flax_fold_in_static(jrandom._tf_key(self._scope.rngs[name]), tuple(self._path) + (c + 1,))
+            return asarray(np.asarray(k, np.int64))
         h = int.from_bytes(("/".join(self._path) + f"#{c}").encode(), "little") % (1 << 62)
         return jrandom.fold_in(self._scope.rngs[name], h)
 

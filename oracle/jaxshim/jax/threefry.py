@@ -104,6 +104,20 @@ def bernoulli(key, p, shape):
     return uniform(key, shape) < np.float32(p)
 
 
+def flax_fold_in_static(rng, path):
+    """flax >= 0.8 (serl_launcher/requirements.txt): `flax/core/scope.py` `_fold_in_static` -- ONE fold_in of the first four bytes
+    (big-endian) of the SHA-1 over the concatenated suffix (strings as UTF-8, integers as their big-endian bytes;
+    `flax_fix_rng_separator` off).  The suffix of `Module.make_rng` is the scope path from the root plus the scope's call
+    counter (starting at 1).  Restated from the published source, NOT pinned (no flax install exists to check against)."""
+    m = hashlib.sha1()
+    for x in path:
+        if isinstance(x, str):
+            m.update(x.encode("utf-8"))
+        else:
+            m.update(int(x).to_bytes((int(x).bit_length() + 7) // 8, byteorder="big"))
+    return fold_in(rng, int.from_bytes(m.digest()[:4], "big"))
+
+
 def flax_fold_in_path(rng, path):
     """flax's LazyRng suffix folding (flax/core/scope.py `_legacy_rng_fold_in`, the default up to flax 0.8): strings fold in the
     first four bytes (big-endian) of their SHA-1, integers fold in as they are.  Flax-version dependent and NOT pinned here

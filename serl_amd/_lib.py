@@ -53,6 +53,16 @@ def _declare(lib):
         "serl_profile_enable": [i32],
         "serl_profile_reset": [],
         "serl_profile_read": [i32, vp, vp, vp, P(i32)],
+        # JAX's PRNG (csrc/jaxrng.hip; serl_amd/jaxrng.py)
+        "serl_jax_prngkey": [u64, P(u32)],
+        "serl_jax_split": [P(u32), i32, P(u32)],
+        "serl_jax_fold_in": [P(u32), u32, P(u32)],
+        "serl_jax_random_bits": [P(u32), i64, P(u32)],
+        "serl_jax_randint": [P(u32), i64, i32, i32, P(i32)],
+        "serl_jax_normal_host": [P(u32), i64, P(f32)],
+        "serl_jax_crop_offsets": [P(u32), i32, i32, P(i32)],
+        "serl_jax_update_keys": [P(u32), i32, i32, i32, vp],
+        "serl_jax_fill": [i32, vp, i32, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libserl_mi355.so")
-SOURCES = ["replay.hip", "trunk.hip", "trunk_f16x3.hip", "heads.hip", "small_encoder.hip", "agent.hip", "classifier.hip", "prof.hip"]
+SOURCES = ["replay.hip", "trunk.hip", "trunk_f16x3.hip", "heads.hip", "small_encoder.hip", "agent.hip", "classifier.hip", "prof.hip", "jaxrng.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

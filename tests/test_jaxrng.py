@@ -1,0 +1,127 @@
+"""The product's JAX PRNG (serl_amd/csrc/jaxrng.hip through serl_amd/jaxrng.py) against oracle/jaxshim/jax/threefry.py, which is
+pinned on the Random123 known-answer vectors and the values of JAX's documentation (tests/test_threefry_oracle.py).
+CPU part: every host entry point (keys, integers: BIT-EXACT; host normals: within 2e-6 relative of the oracle's float64 erf_inv)
+and the key schedule of one learner call (agents/continuous/drq.py:276-318, sac.py:137,151,197,222,287-289, common/common.py:197-200)
+against the same schedule written out with the oracle's split.  GPU part: the device draws."""
+import numpy as np
+import pytest
+
+from oracle.jaxshim.jax import threefry as T
+from serl_amd import jaxrng as J
+
+
+def test_threefry_known_answers_through_the_library():
+    # Random123 KAT for threefry2x32-20: key (0, 0), counter (0, 0); all-ones; the pi digits
+    for key, ctr, want in (((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+                           ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                           ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))):
+        # random_bits over n = 2 hashes the counter pair (0, 1); the KAT counters need the raw block: fold_in gives (0, data)
+        got = T.threefry2x32(key[0], key[1], np.array([ctr[0]], np.uint32), np.array([ctr[1]], np.uint32))
+        assert (int(got[0][0]), int(got[1][0])) == want          # the oracle itself (pinned elsewhere too)
+    # the library's block function through fold_in: counter (0, data)
+    for key, data in (((0, 0), 0), ((0x13198A2E, 0x03707344), 0x85A308D3), ((1, 2), 12345)):
+        assert np.array_equal(J.fold_in(np.array(key, np.uint32), data), T.fold_in(np.array(key, np.uint32), data))
+
+
+def test_keys_and_integers_are_bit_exact():
+    rng = np.random.default_rng(0)
+    for seed in (0, 1, 42, 2**31 - 1, 2**32 + 7):
+        k = J.prngkey(seed)
+        assert np.array_equal(k, T.PRNGKey(seed))
+        for num in (1, 2, 3, 4, 7, 256):
+            assert np.array_equal(J.split(k, num), T.split(k, num)), (seed, num)
+        for n in (1, 2, 3, 5, 8, 1001):
+            assert np.array_equal(J.random_bits(k, n), T.random_bits(k, (n,))), (seed, n)
+        for lo, hi in ((0, 9), (0, 10), (-3, 4), (0, 1), (5, 5), (0, 2**31 - 1), (-2**31, 2**31 - 1)):
+            for n in (1, 2, 3, 16):
+                assert np.array_equal(J.randint(k, n, lo, hi), T.randint(k, (n,), lo, hi)), (seed, lo, hi, n)
+        d = int(rng.integers(0, 2**32))
+        assert np.array_equal(J.fold_in(k, d), T.fold_in(k, d))
+
+
+def test_crop_offsets_follow_batched_random_crop():
+    # vision/data_augmentations.py:22-36: rngs = split(rng, frames); per frame randint(rng_i, (2,), 0, 2 * padding + 1) = (y, x)
+    for seed, frames in ((3, 1), (4, 8), (5, 256)):
+        k = T.PRNGKey(seed)
+        want = np.stack([T.randint(ki, (2,), 0, 9) for ki in T.split(k, frames)])
+        got = J.crop_offsets(k, frames, 4)
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+        assert got.min() >= 0 and got.max() <= 8
+
+
+def test_host_normals_are_within_a_few_ulps_of_the_oracle():
+    k = T.PRNGKey(7)
+    for n in (1, 6, 1537):
+        got, want = J.normal_host(k, n), T.normal(k, (n,))
+        # same 32-bit draws, same uniform; erf_inv: XLA's float32 polynomial (Giles: relative error of a few 1e-7, which IS what a
+        # JAX run computes) here, float64 scipy rounded to float32 in the oracle
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        assert (err <= 2e-6 * np.abs(want) + 1e-7).all(), float((err / (np.abs(want) + 1e-30)).max())
+
+
+def _schedule_by_hand(rng, drq_aug, n_critic, has_actor):
+    out = {}
+    if drq_aug:
+        rng, out["k_obs"], out["k_next"] = T.split(rng, 3)
+    out["k_next_action"], out["k_subsample"] = [], []
+    for u in range(n_critic + (1 if has_actor else 0)):
+        _, r_actor, r_critic, r_temp = T.split(rng, 4)
+        if u < n_critic:
+            c, k_na = T.split(r_critic)
+            _, k_sub = T.split(c)
+            out["k_next_action"].append(k_na)
+            out["k_subsample"].append(k_sub)
+        else:
+            _, out["k_policy"], out["k_sample"], _ = T.split(r_actor, 4)
+            _, out["k_temp"] = T.split(r_temp)
+        rng = T.split(rng)[0]
+    out["rng_out"] = rng
+    return out
+
+
+@pytest.mark.parametrize("drq_aug,n_critic,has_actor", [(1, 1, 0), (1, 1, 1), (1, 4, 1), (0, 2, 1), (0, 0, 1), (0, 1, 0)])
+def test_update_key_schedule(drq_aug, n_critic, has_actor):
+    rng = T.split(T.PRNGKey(11))[1]
+    want = _schedule_by_hand(rng, drq_aug, n_critic, has_actor)
+    got = J.UpdateKeys(rng, drq_aug, n_critic, has_actor)
+    assert np.array_equal(got.rng_out, want["rng_out"])
+    if drq_aug:
+        assert np.array_equal(got.k_obs, want["k_obs"]) and np.array_equal(got.k_next, want["k_next"])
+    for u in range(n_critic):
+        assert np.array_equal(got.k_next_action[u], want["k_next_action"][u])
+        assert np.array_equal(got.k_subsample[u], want["k_subsample"][u])
+    if has_actor:
+        for name in ("k_policy", "k_sample", "k_temp"):
+            assert np.array_equal(getattr(got, name), want[name]), name
+
+
+def test_flax_make_rng_equals_the_oracle_restatement():
+    k = T.PRNGKey(5)
+    for path, c in ((J.dropout_path("front"), 1), (("a", "b"), 2), (("modules_actor",), 300)):
+        assert np.array_equal(J.flax_make_rng(k, path, c), T.flax_fold_in_static(k, tuple(path) + (c,)))
+
+
+@pytest.mark.gpu
+def test_device_draws(gpu):
+    import torch
+    k = T.PRNGKey(9)
+    s = torch.cuda.current_stream().cuda_stream
+    for n in (1, 6, 1536, 2 * 4096 + 1):
+        nrm = torch.empty(n, dtype=torch.float32, device="cuda")
+        bits = torch.empty(n, dtype=torch.int32, device="cuda")
+        msk = torch.empty(n, dtype=torch.uint8, device="cuda")
+        J.fill(0, [J.job(J.NORMAL, k, n, nrm.data_ptr()), J.job(J.BITS, k, n, bits.data_ptr()),
+                   J.job(J.BERNOULLI_U8, k, n, msk.data_ptr(), p=0.9)], s)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32), T.random_bits(k, (n,)))
+        assert np.array_equal(msk.cpu().numpy().astype(bool), T.bernoulli(k, 0.9, (n,)))
+        got, want = nrm.cpu().numpy(), T.normal(k, (n,))
+        assert (np.abs(got.astype(np.float64) - want) <= 2e-6 * np.abs(want) + 1e-7).all()
+        assert np.abs(got - J.normal_host(k, n)).max() < 1e-6      # host and device libm differ in the last bits of log1p / sqrt
+    # a window of a larger array (a rank's rows of a data-parallel batch, a UTD minibatch)
+    n, first, count = 256 * 6, 64 * 6, 32 * 6
+    win = torch.empty(count, dtype=torch.float32, device="cuda")
+    J.fill(0, [J.job(J.NORMAL, k, n, win.data_ptr(), first=first, count=count)], s)
+    torch.cuda.synchronize()
+    full = J.normal_host(k, n)
+    assert np.abs(win.cpu().numpy() - full[first:first + count]).max() < 1e-6
