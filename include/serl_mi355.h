@@ -357,7 +357,9 @@ int serl_jax_crop_offsets(const uint32_t key[2], int frames, int padding, int32_
  *     actor:   _, k_policy, k_sample, _ = split(r_actor, 4);  _, k_temp = split(r_temp)     (sac.py:197,222)
  *     rng = split(rng)[0]                                                                   (sac.py:287-289)
  * k_next_action / k_policy / k_temp are BOTH the Dropout rng of that policy forward and (k_next_action, k_temp) its sample seed
- * (sac.py:122-128); k_sample seeds the policy-loss sample.  rng_out is state.rng after the call. */
+ * (sac.py:122-128); k_sample seeds the policy-loss sample.  rng_out is state.rng after the call.
+ * combined != 0 (SACAgent.update with all three networks, sac.py:243-299): ONE update whose critic, actor and temperature losses
+ * take their keys from the same 4-way split (n_critic = 1, has_actor_temp = 1). */
 #define SERL_JAX_MAX_UTD 32
 typedef struct serl_jax_update_keys_t {
   uint32_t rng_out[2];
@@ -367,7 +369,7 @@ typedef struct serl_jax_update_keys_t {
   uint32_t k_subsample[SERL_JAX_MAX_UTD][2];
   uint32_t k_policy[2], k_sample[2], k_temp[2];
 } serl_jax_update_keys_t;
-int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int has_actor_temp, serl_jax_update_keys_t* out);
+int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int has_actor_temp, int combined, serl_jax_update_keys_t* out);
 /* Device draws: job i writes elements [first, first + count) of the flat array a JAX call of `n_total` elements returns
  * (a rank of a data-parallel job, or a minibatch window, fills its rows only):
  *   SERL_JAX_NORMAL       f32  jax.random.normal(key, shape)             SERL_JAX_BERNOULLI_U8  u8  jax.random.bernoulli(key, p, shape)

@@ -88,6 +88,8 @@ def pack(res, param_seed, batch_seed):
     out = {"meta": np.array(json.dumps({"cfg": cfg_to_dict(cfg), "B": res["B"],
                                         "schedule": [[s[0]] + [list(x) if isinstance(x, (tuple, list)) else x for x in s[1:]] for s in res["schedule"]],
                                         "param_seed": param_seed, "batch_seed": batch_seed, "final_step": res["final"]["step"],
+                                        # which stream the stand-in jax.random drew from, state.rng before / after the schedule
+                                        "prng": res.get("prng", "philox"), "rng0": res.get("rng0"), "rng_final": res["final"].get("rng"),
                                         # shapes of the reference's agent.state.params / opt_states trees (flax state-dict form)
                                         "param_tree": _jsonable(res["final"]["param_tree"]),
                                         "opt_state_tree": _jsonable(res["final"]["opt_state_tree"])}))}

@@ -277,6 +277,7 @@ def run_reference(cfg: O.Config, B: int, schedule, param_seed=42, batch_seed=100
     params = jax.tree_map(lambda a: jnp.asarray(np.asarray(a)), params)
     agent = agent.replace(state=agent.state.replace(params=params, target_params=params))
 
+    rng0 = [int(v) & 0xFFFFFFFF for v in np.asarray(agent.state.rng).reshape(-1)]   # state.rng as the reference's factory left it
     steps = []
     for i, item in enumerate(schedule):
         kind = item[0]
@@ -332,7 +333,8 @@ def run_reference(cfg: O.Config, B: int, schedule, param_seed=42, batch_seed=100
         final["trunk_conv_init_target"] = np.asarray(tpe["conv_init"]["kernel"], np.float64).reshape(-1)
     final["param_tree"] = jax.tree_map(lambda a: tuple(np.shape(a)), st.params)
     final["opt_state_tree"] = jax.tree_map(lambda a: tuple(np.shape(a)), {k: _state_dict(v) for k, v in st.opt_states.items()})
-    return {"cfg": cfg, "B": B, "schedule": list(schedule), "steps": steps, "final": final}
+    final["rng"] = [int(v) & 0xFFFFFFFF for v in np.asarray(agent.state.rng).reshape(-1)]
+    return {"cfg": cfg, "B": B, "schedule": list(schedule), "steps": steps, "final": final, "rng0": rng0}
 
 
 def _state_dict(x):

@@ -61,7 +61,7 @@ def _declare(lib):
         "serl_jax_randint": [P(u32), i64, i32, i32, P(i32)],
         "serl_jax_normal_host": [P(u32), i64, P(f32)],
         "serl_jax_crop_offsets": [P(u32), i32, i32, P(i32)],
-        "serl_jax_update_keys": [P(u32), i32, i32, i32, vp],
+        "serl_jax_update_keys": [P(u32), i32, i32, i32, i32, vp],
         "serl_jax_fill": [i32, vp, i32, vp],
     }
     for name, args in sigs.items():

@@ -19,6 +19,7 @@ import torch
 from ..data.data_store import LazyBatch, gather_crop
 from ..utils import init as pinit
 from .. import _lib
+from .. import jaxrng as J
 from .batch import DeviceBatch
 from .core import APPLY_ACTOR_TEMP, APPLY_CRITIC, TX_NAMES, AgentCore
 from .flax_tree import export_tree
@@ -135,12 +136,24 @@ class TrainStateView:
 
 
 class DrQAgent:
+    _DRQ_AUG = True     # update_critics / update_high_utd open with `rng, obs_rng, next_obs_rng = split(rng, 3)` (drq.py:276-277,307-308)
+
     def __init__(self, core: AgentCore, image_keys, config: dict, seed: int):
         self.core = core
         self.image_keys = tuple(image_keys)
         self.config = config
         self._np_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 0xD1CE])))
-        self._rng_key = np.array([0, seed], np.uint32)
+        # RANDOMNESS.  "threefry" (default): the reference's own stream -- crop offsets, REDQ indices, policy noise and Dropout
+        # masks are drawn from jax.random's threefry2x32 with the reference's key schedule (serl_amd/jaxrng.py), and `state.rng`
+        # advances as common.py:197-209 / sac.py:287-289 / drq.py:276-318 do: a learner started from the same seed consumes the
+        # numbers a JAX learner consumes (integers bit-exact).  "hash": crop offsets from a numpy PCG64 stream, noise hashed on
+        # the device from cfg.seed inside the kernels that use it (no noise tensors; what the bench's DataParallelLearner runs).
+        self.rng_impl = "threefry"
+        # state.rng as create_drq / create leave it (drq.py:69-84, sac.py:355-372): rng = PRNGKey(seed); rng, init_rng = split(rng);
+        # rng, create_rng = split(rng); JaxRLTrainState.create(rng=create_rng)
+        self._rng_key = J.split(J.split(J.prngkey(seed))[0])[1]
+        self.last_draws = {}     # what the last update call drew from its keys (crop offsets, REDQ indices): parity tests read it
+        self._noise_bufs = {}
         self._batch: Optional[DeviceBatch] = None
         self._update_serial = 0
         self.state = TrainStateView(self)
@@ -149,6 +162,7 @@ class DrQAgent:
         self.prefetch = True
         self._sched = None
         self._slot_batches = [None, None, None]   # one device batch per pipeline slot (TorchPipelineSchedule.slots)
+        self._slot_crops = [None, None, None]     # the crop offsets drawn for the batch in each slot
         self._prefetched = None   # (key of the lazy batch, slot)
 
     # ------------------------------------------------------------------ construction
@@ -241,12 +255,74 @@ class DrQAgent:
             self._batch = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
         return self._batch
 
-    def _draw_crops(self, B):
-        # data_augmentation_fn (drq.py:244-253): one (dy,dx) in [0,8] per frame, the SAME for every camera;
-        # obs and next_obs use independent draws (drq.py:279-281).  Host stream, not jax threefry.
-        co = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
-        cn = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
-        return co, cn
+    def _draw_crops(self, B, rng=None):
+        """data_augmentation_fn (drq.py:244-253): one (dy, dx) in [0, 8] per frame, the SAME for every camera; obs and next_obs
+        use independent keys (drq.py:279-281).  `rng`: state.rng at the entry of the call that consumes the batch (None: the
+        current one) -- rng, obs_rng, next_obs_rng = split(rng, 3); offsets = batched_random_crop's (data_augmentations.py:22-36)."""
+        if self.rng_impl != "threefry":
+            co = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
+            cn = self._np_rng.integers(0, 9, size=(B, 2)).astype(np.int32)
+            return co, cn
+        k = J.split(self._rng_key if rng is None else rng, 3)
+        return J.crop_offsets(k[1], B, 4), J.crop_offsets(k[2], B, 4)
+
+    # ------------------------------------------------------------------ the reference's random stream for one call
+    def _call_keys(self, n_critic, has_actor_temp, drq_aug=None, combined=False):
+        """Keys of the learner call about to run, derived from state.rng (None when the device-hashed stream is selected)."""
+        if self.rng_impl != "threefry":
+            return None
+        return J.UpdateKeys(self._rng_key, self._DRQ_AUG if drq_aug is None else drq_aug, n_critic, has_actor_temp, combined)
+
+    def _finish_call(self, keys):
+        if keys is not None:
+            self._rng_key = keys.rng_out.copy()
+
+    def _jax_noise(self, keys, B, want_critic=True, want_actor=True):
+        """The noise tensors of one call, filled on the device from the call's keys (ONE launch): for critic update i over the
+        minibatch rows [i*mb, (i+1)*mb) the next-action sample and the policy encoder's Dropout masks of sac.py:118-132, the
+        REDQ subsample (host integers, sac.py:150-157); for the actor + temperature update the samples / masks of sac.py:197-201 and
+        :224-227.  Shapes are the reference's ((mb, A) normals, one (mb, 4096) mask per camera from that camera's Dropout key)."""
+        c = self.core.cfg
+        dev, A = self.core.device, c.act_dim
+        n_cam = c.n_cam if c.encoder_type == 0 else 0          # (the SmallEncoder path has no Dropout: pooling "avg")
+        D = 512 * c.sle_features
+        nb = self._noise_bufs.get(B)
+        if nb is None:
+            nb = {k: torch.empty((B, A), dtype=torch.float32, device=dev) for k in ("eps_next", "eps_pi", "eps_temp")}
+            if n_cam:
+                nb.update({k: torch.empty((n_cam, B, D), dtype=torch.uint8, device=dev) for k in ("mask_next", "mask_obs_pi", "mask_next_temp")})
+            self._noise_bufs = {B: nb}
+        keep = 1.0 - float(c.dropout)
+        jobs, noise = [], {}
+
+        def masks(name, key, row0, rows):
+            for ci, cam in enumerate(self.image_keys[:n_cam]):
+                jobs.append(J.job(J.BERNOULLI_U8, J.flax_make_rng(key, J.dropout_path(cam), 1), rows * D,
+                                  nb[name].data_ptr() + (ci * B + row0) * D, p=keep))
+            if n_cam:
+                noise[name] = nb[name]
+
+        if want_critic and keys.n_critic:
+            mb = B // keys.n_critic
+            m = int(c.critic_subsample_size)
+            redq = np.zeros((keys.n_critic, max(m, 1)), np.int32)
+            for i in range(keys.n_critic):
+                jobs.append(J.job(J.NORMAL, keys.k_next_action[i], mb * A, nb["eps_next"].data_ptr() + i * mb * A * 4))
+                masks("mask_next", keys.k_next_action[i], i * mb, mb)
+                if m > 0:
+                    redq[i] = J.randint(keys.k_subsample[i], m, 0, c.ensemble)
+            noise["eps_next"] = nb["eps_next"]
+            if m > 0:
+                noise["redq_idx"] = redq
+                self.last_draws["redq_idx"] = redq.copy()
+        if want_actor and keys.has_actor_temp:
+            jobs.append(J.job(J.NORMAL, keys.k_sample, B * A, nb["eps_pi"].data_ptr()))
+            masks("mask_obs_pi", keys.k_policy, 0, B)
+            jobs.append(J.job(J.NORMAL, keys.k_temp, B * A, nb["eps_temp"].data_ptr()))
+            masks("mask_next_temp", keys.k_temp, 0, B)
+            noise["eps_pi"], noise["eps_temp"] = nb["eps_pi"], nb["eps_temp"]
+        J.fill(c.device, jobs, self.core._stream())
+        return noise
 
     def prepare(self, batch, crops=None) -> DeviceBatch:
         """sample-gather [+ concat_batches] + _unpack + random-shift crop -> DeviceBatch."""
@@ -256,6 +332,7 @@ class DrQAgent:
             B = batch.batch_size
             out = self._device_batch(B)
             co, cn = crops if crops is not None else self._draw_crops(B)
+            self.last_draws["crop_obs"], self.last_draws["crop_next"] = co, cn
             gather_crop(batch.parts, co, cn, out)
             return out
         # reference-format dict of device tensors (packed or unpacked frames)
@@ -264,6 +341,7 @@ class DrQAgent:
         B = int(batch["rewards"].shape[0])
         out = self._device_batch(B)
         co, cn = crops if crops is not None else self._draw_crops(B)
+        self.last_draws["crop_obs"], self.last_draws["crop_next"] = co, cn
         keep, ptrs = [], (C.c_void_p * len(self.image_keys))()
         for i, k in enumerate(self.image_keys):
             if k in nobs:  # unpacked: re-pack [B,2,H,W,C] (train_utils._unpack inverse)
@@ -303,21 +381,24 @@ class DrQAgent:
             self._slot_batches[slot] = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
         return self._slot_batches[slot]
 
-    def _produce(self, batch: LazyBatch, slot, db):
+    def _produce(self, batch: LazyBatch, slot, db, rng=None):
         """gather + crop and the frozen trunk on the side stream.  (Round 2 gathered on the caller's stream and made the side
         stream wait for it: a dependency that crosses streams costs 60-100 us on this stack, at every pass.  An actor-side
         insert that overwrites a slot waits ON THE COPY STREAM for the gathers in flight, never on the host.)"""
         sch = self._sched
-        co, cn = self._draw_crops(db.batch)
+        co, cn = self._draw_crops(db.batch, rng)      # rng: state.rng at the entry of the call that will consume this batch
+        self._slot_crops[slot] = (co, cn)
         sch.wait_consumed(slot)     # host side: the update that used this slot ended two passes ago
         with sch.side():
             gather_crop(batch.parts, co, cn, db)
             self.core.encode_slot(db, slot)
         sch.produced(slot)
 
-    def _acquire(self, batch: LazyBatch):
+    def _acquire(self, batch: LazyBatch, next_rng=None):
         """-> (slot, DeviceBatch) with the frozen-trunk features of `batch` ready in `slot` (prefetched during the
-        previous update, or encoded now), and starts the same work for the iterator's next batch on the side stream."""
+        previous update, or encoded now), and starts the same work for the iterator's next batch on the side stream.
+        `next_rng`: state.rng after the call in progress = at the entry of the call that consumes the next batch (the key
+        schedule is pure host arithmetic, so the next batch's crop keys are known before this update has run)."""
         from ..parallel import TorchPipelineSchedule
         if self._sched is None:
             self._sched = TorchPipelineSchedule(self.core.device, prioritise_update=False)
@@ -336,11 +417,12 @@ class DrQAgent:
             db = self._slot_batch(slot, B)
             self._produce(batch, slot, db)
             sch.wait_produced(slot)
+        self.last_draws["crop_obs"], self.last_draws["crop_next"] = self._slot_crops[slot]
         self._prefetched = None
         nxt = batch.peek_next() if batch.peek_next is not None else None
         if nxt is not None and nxt.batch_size == B:
             s2 = (slot + 1) % sch.slots
-            self._produce(nxt, s2, self._slot_batch(s2, B))
+            self._produce(nxt, s2, self._slot_batch(s2, B), next_rng)
             # (the parts are kept alive with the key: a freed index array's address could otherwise be reused by a
             # later sample and false-match)
             self._prefetched = (self._lazy_key(nxt), s2, list(nxt.parts))
@@ -357,9 +439,12 @@ class DrQAgent:
 
     # ------------------------------------------------------------------ updates
     def update_critics(self, batch, *, pmap_axis: Optional[str] = None, noise=None, crops=None):
-        """drq.py:296-328."""
+        """drq.py:296-328.  `noise` / `crops` inject explicit draws (parity tests); None = drawn from state.rng."""
+        keys = self._call_keys(1, False)
         if self._can_prefetch(batch, crops):
-            slot, db = self._acquire(batch)
+            slot, db = self._acquire(batch, None if keys is None else keys.rng_out)
+            if noise is None and keys is not None:
+                noise = self._jax_noise(keys, db.batch)
             self.core.begin_update()
             self.core.critic_grads(0, db.batch, db.batch, noise)
             self.core.apply(APPLY_CRITIC)
@@ -367,16 +452,22 @@ class DrQAgent:
         else:
             db = self.prepare(batch, crops)
             self._sync_side_stream()
+            if noise is None and keys is not None:
+                noise = self._jax_noise(keys, db.batch)
             self.core.update_critics(db, noise)
+        self._finish_call(keys)
         self._update_serial += 1
         return self, PendingInfo(self, "critics", self._update_serial)
 
     def update_high_utd(self, batch, *, utd_ratio: int, pmap_axis: Optional[str] = None, noise=None, crops=None):
         """drq.py:255-294 -> sac.py:544-596."""
+        keys = self._call_keys(utd_ratio, True)
         if self._can_prefetch(batch, crops):
             B = batch.batch_size
             assert B % utd_ratio == 0, f"Batch size {B} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
-            slot, db = self._acquire(batch)
+            slot, db = self._acquire(batch, None if keys is None else keys.rng_out)
+            if noise is None and keys is not None:
+                noise = self._jax_noise(keys, B)
             mb = B // utd_ratio
             self.core.begin_update()
             for i in range(utd_ratio):
@@ -390,7 +481,10 @@ class DrQAgent:
             assert db.batch % utd_ratio == 0, \
                 f"Batch size {db.batch} must be divisible by UTD ratio {utd_ratio}"  # sac.py:561-563
             self._sync_side_stream()
+            if noise is None and keys is not None:
+                noise = self._jax_noise(keys, db.batch)
             self.core.update_high_utd(db, utd_ratio, noise)
+        self._finish_call(keys)
         self._update_serial += 1
         return self, PendingInfo(self, "high_utd", self._update_serial)
 
@@ -408,7 +502,14 @@ class DrQAgent:
             n = batch.batch_size if isinstance(batch, LazyBatch) else int(batch["rewards"].shape[0])
             db = self.prepare(batch, crops=(np.full((n, 2), 4, np.int32),) * 2)
         self._sync_side_stream()
+        # SACAgent.update (sac.py:243-299): no augmentation split; every selected loss takes its key from ONE 4-way split
+        nets = set(networks_to_update)
+        crit, act = "critic" in nets, bool(nets & {"actor", "temperature"})
+        keys = self._call_keys(1 if crit else 0, act, drq_aug=False, combined=crit and act)
+        if noise is None and keys is not None:
+            noise = self._jax_noise(keys, db.batch, want_critic=crit, want_actor=act)
         self.core.update(db, tuple(networks_to_update), noise)
+        self._finish_call(keys)
         self._update_serial += 1
         return self, PendingInfo(self, frozenset(networks_to_update), self._update_serial)
 
@@ -425,10 +526,17 @@ class DrQAgent:
         self._sync_side_stream()
         f = torch.from_numpy(frames).to(self.core.device)
         s = torch.from_numpy(st.reshape(n, -1)).to(self.core.device)
-        eps = None
-        if not argmax:
-            assert seed is not None, "Must specify rng when sampling"
-            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(np.asarray(seed).reshape(-1).tolist())))
-            eps = torch.from_numpy(g.standard_normal((n, c.act_dim)).astype(np.float32)).to(self.core.device)
+        eps = None if argmax else self._action_noise(seed, n)
         a = self.core.sample_actions(f, s, eps).cpu().numpy()
         return a if batched else a[0]
+
+    def _action_noise(self, seed, n):
+        """dist.sample(seed=seed) of sac.py:316-320: distrax draws jax.random.normal(seed, (1,) + batch + (A,))."""
+        assert seed is not None, "Must specify rng when sampling"
+        c = self.core.cfg
+        eps = torch.empty((n, c.act_dim), dtype=torch.float32, device=self.core.device)
+        if self.rng_impl == "threefry" and J.is_key(seed):
+            J.fill(c.device, [J.job(J.NORMAL, seed, n * c.act_dim, eps.data_ptr())], self.core._stream())
+            return eps
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(np.asarray(seed).reshape(-1).tolist())))
+        return torch.from_numpy(g.standard_normal((n, c.act_dim)).astype(np.float32)).to(self.core.device)

@@ -21,6 +21,8 @@ from .drq import DrQAgent
 
 
 class SACAgent(DrQAgent):
+    _DRQ_AUG = False    # SACAgent.update_high_utd (sac.py:544-596) has no augmentation split
+
     @classmethod
     def create_states(cls, rng, observations, actions, critic_network_kwargs: dict = None,
                       critic_ensemble_size: int = 2, critic_subsample_size: Optional[int] = None,
@@ -95,10 +97,6 @@ class SACAgent(DrQAgent):
         batched = st.ndim == 2
         n = st.shape[0] if batched else 1
         s = torch.from_numpy(st.reshape(n, -1)).to(self.core.device)
-        eps = None
-        if not argmax:
-            assert seed is not None, "Must specify rng when sampling"
-            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(np.asarray(seed).reshape(-1).tolist())))
-            eps = torch.from_numpy(g.standard_normal((n, c.act_dim)).astype(np.float32)).to(self.core.device)
+        eps = None if argmax else self._action_noise(seed, n)
         a = self.core.sample_actions(None, s, eps).cpu().numpy()
         return a if batched else a[0]

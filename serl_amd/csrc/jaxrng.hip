@@ -181,8 +181,9 @@ int serl_jax_crop_offsets(const uint32_t key[2], int frames, int padding, int32_
   return SERL_OK;
 }
 
-int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int has_actor_temp, serl_jax_update_keys_t* out) {
+int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int has_actor_temp, int combined, serl_jax_update_keys_t* out) {
   SERL_REQUIRE(rng && out && n_critic >= 0 && n_critic <= SERL_JAX_MAX_UTD && (n_critic > 0 || has_actor_temp), "bad argument");
+  SERL_REQUIRE(!combined || (n_critic == 1 && has_actor_temp), "a combined update is one critic + actor + temperature step");
   uint32_t r[2] = {rng[0], rng[1]};
   *out = serl_jax_update_keys_t{};
   if (drq_aug) {   // drq.py:276-277 / :307-308: rng, obs_rng, next_obs_rng = split(rng, 3); state.rng = rng
@@ -192,7 +193,7 @@ int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int h
     out->k_obs[0] = k[2]; out->k_obs[1] = k[3];
     out->k_next[0] = k[4]; out->k_next[1] = k[5];
   }
-  const int n_updates = n_critic + (has_actor_temp ? 1 : 0);
+  const int n_updates = combined ? 1 : n_critic + (has_actor_temp ? 1 : 0);
   for (int u = 0; u < n_updates; ++u) {
     // common.py:197-200: new_rng, *rngs = split(state.rng, 4) with the loss dict's leaves in sorted key order
     // (actor, critic, temperature); sac.py:287-289: afterwards state.rng = split(state.rng)[0] of the ENTRY rng
@@ -206,7 +207,8 @@ int serl_jax_update_keys(const uint32_t rng[2], int drq_aug, int n_critic, int h
       uint32_t s[4];
       serl::split_host(c, 2, s);                  // sac.py:151: rng, subsample_key = split(rng)
       out->k_subsample[u][0] = s[2]; out->k_subsample[u][1] = s[3];
-    } else {
+    }
+    if (combined || u >= n_critic) {
       uint32_t p[8];
       serl::split_host(r_actor, 4, p);            // sac.py:197: rng, policy_rng, sample_rng, critic_rng = split(rng, 4)
       out->k_policy[0] = p[2]; out->k_policy[1] = p[3];

@@ -502,7 +502,14 @@ static int stage_params(serl_rb* rb, const void* const* srcs, const size_t* size
     }
   }
   uint8_t* d = rb->stage_dev + (size_t)s * rb->stage_slot_bytes;
-  SERL_HIP(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, stream));
+  static const bool zero_copy = []() { const char* e = getenv("SERL_STAGE_ZEROCOPY"); return e && e[0] == '1'; }();   // TEMPORARY (A/B, round 5)
+  if (zero_copy) {   // the kernel reads the (coherent, pinned) host slot itself: no copy command on the stream
+    void* dp = nullptr;
+    SERL_HIP(hipHostGetDevicePointer(&dp, h, 0));
+    d = static_cast<uint8_t*>(dp);
+  } else {
+    SERL_HIP(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, stream));
+  }
   *dev_out = d;
   rb->stage_used[s] = true;
   return s;

@@ -100,11 +100,11 @@ def crop_offsets(key, frames: int, padding: int = 4) -> np.ndarray:
 class UpdateKeys:
     """Every key one learner call derives from state.rng (serl_jax_update_keys; order documented in the header)."""
 
-    def __init__(self, rng, drq_aug: bool, n_critic: int, has_actor_temp: bool):
+    def __init__(self, rng, drq_aug: bool, n_critic: int, has_actor_temp: bool, combined: bool = False):
         if n_critic > MAX_UTD:
             raise ValueError(f"utd_ratio {n_critic} exceeds SERL_JAX_MAX_UTD = {MAX_UTD}")
         k, s = _key(rng), _UpdateKeys()
-        _lib.check(_lib.lib().serl_jax_update_keys(_kp(k), int(bool(drq_aug)), int(n_critic), int(bool(has_actor_temp)), C.byref(s)))
+        _lib.check(_lib.lib().serl_jax_update_keys(_kp(k), int(bool(drq_aug)), int(n_critic), int(bool(has_actor_temp)), int(bool(combined)), C.byref(s)))
         a = lambda f: np.array(list(f), np.uint32)
         self.rng_in, self.rng_out = k.copy(), a(s.rng_out)
         self.k_obs, self.k_next = a(s.k_obs), a(s.k_next)

@@ -55,6 +55,17 @@ CASES = {
                                [("critics",), ("high_utd", 2), ("update", ("actor", "critic", "temperature"))]),
     "sac_state_subsample3": (O.Config(image_keys=(), S=10, A=4, discount=0.99, subsample=3, backup_entropy=True), 8,
                              [("high_utd", 2), ("update", ("critic",)), ("high_utd", 1)]),
+    # ---- the reference's OWN random stream (case names ending in _threefry run under SERL_JAXSHIM_PRNG=threefry: the stand-in
+    # jax.random then draws what jax.random draws, oracle/jaxshim/jax/threefry.py).  tests/test_golden_update_gpu.py runs the HIP
+    # agent on these FROM THE SEED ONLY -- nothing injected -- and compares the integers it drew (crop offsets, REDQ indices,
+    # Dropout masks) bit for bit, its normals to 2e-6, and the final state at the usual 1e-4.
+    "drq_64_threefry": (O.Config(image_keys=("front", "wrist"), H=64, W=64, S=5, A=3), 8,
+                        [("critics",), ("high_utd", 2), ("critics",), ("high_utd", 1)]),
+    "drq_update_threefry": (O.Config(image_keys=("front",), H=64, W=64, S=5, A=3), 6,
+                            [("update", ("actor", "critic", "temperature")), ("critics",), ("update", ("critic",)),
+                             ("update", ("actor", "temperature"))]),
+    "sac_state_threefry": (O.Config(image_keys=(), S=10, A=4, discount=0.99, warmup=2000, temp_warmup=0), 8,
+                           [("high_utd", 2), ("update", ("actor", "critic", "temperature")), ("high_utd", 1)]),
 }
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]
 
@@ -64,7 +75,12 @@ def main():
     for name, (cfg, B, sched) in CASES.items():
         if ONLY and name not in ONLY:
             continue
+        if name.endswith("_threefry"):
+            os.environ["SERL_JAXSHIM_PRNG"] = "threefry"
+        else:
+            os.environ.pop("SERL_JAXSHIM_PRNG", None)
         res = RR.run_reference(cfg, B, sched, PARAM_SEED, BATCH_SEED)
+        res["prng"] = os.environ.pop("SERL_JAXSHIM_PRNG", "philox")
         rec = G.pack(res, PARAM_SEED, BATCH_SEED)
         path = os.path.join(out_dir, f"update_{name}.npz")
         np.savez_compressed(path, **rec)

@@ -59,19 +59,19 @@ def test_host_normals_are_within_a_few_ulps_of_the_oracle():
         assert (err <= 2e-6 * np.abs(want) + 1e-7).all(), float((err / (np.abs(want) + 1e-30)).max())
 
 
-def _schedule_by_hand(rng, drq_aug, n_critic, has_actor):
+def _schedule_by_hand(rng, drq_aug, n_critic, has_actor, combined=False):
     out = {}
     if drq_aug:
         rng, out["k_obs"], out["k_next"] = T.split(rng, 3)
     out["k_next_action"], out["k_subsample"] = [], []
-    for u in range(n_critic + (1 if has_actor else 0)):
+    for u in range(1 if combined else n_critic + (1 if has_actor else 0)):
         _, r_actor, r_critic, r_temp = T.split(rng, 4)
         if u < n_critic:
             c, k_na = T.split(r_critic)
             _, k_sub = T.split(c)
             out["k_next_action"].append(k_na)
             out["k_subsample"].append(k_sub)
-        else:
+        if combined or u >= n_critic:
             _, out["k_policy"], out["k_sample"], _ = T.split(r_actor, 4)
             _, out["k_temp"] = T.split(r_temp)
         rng = T.split(rng)[0]
@@ -79,11 +79,12 @@ def _schedule_by_hand(rng, drq_aug, n_critic, has_actor):
     return out
 
 
-@pytest.mark.parametrize("drq_aug,n_critic,has_actor", [(1, 1, 0), (1, 1, 1), (1, 4, 1), (0, 2, 1), (0, 0, 1), (0, 1, 0)])
-def test_update_key_schedule(drq_aug, n_critic, has_actor):
+@pytest.mark.parametrize("drq_aug,n_critic,has_actor,combined", [(1, 1, 0, 0), (1, 1, 1, 0), (1, 4, 1, 0), (0, 2, 1, 0), (0, 0, 1, 0),
+                                                                  (0, 1, 0, 0), (0, 1, 1, 1)])
+def test_update_key_schedule(drq_aug, n_critic, has_actor, combined):
     rng = T.split(T.PRNGKey(11))[1]
-    want = _schedule_by_hand(rng, drq_aug, n_critic, has_actor)
-    got = J.UpdateKeys(rng, drq_aug, n_critic, has_actor)
+    want = _schedule_by_hand(rng, drq_aug, n_critic, has_actor, combined)
+    got = J.UpdateKeys(rng, drq_aug, n_critic, has_actor, combined)
     assert np.array_equal(got.rng_out, want["rng_out"])
     if drq_aug:
         assert np.array_equal(got.k_obs, want["k_obs"]) and np.array_equal(got.k_next, want["k_next"])
