@@ -2,7 +2,7 @@
 # Round 5, GPU call 3: the JAX-stream tests (device draws; HIP agent from the seed only vs the threefry goldens), the API-level DrQ tests,
 # A/B of zero-copy parameter staging (does the H2D copy command cause the pass-boundary gap?) with a per-queue timeline.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call3; rm -rf $O; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests/test_jaxrng.py tests/test_golden_update_gpu.py tests/test_drq_agent_gpu.py tests/test_sac_state_gpu.py -m gpu -x -q --durations=8 > $O/pytest.log 2>&1
+timeout 600 python -m pytest tests/test_jaxrng.py tests/test_golden_update_gpu.py tests/test_drq_agent_gpu.py tests/test_sac_state_gpu.py -m gpu -q --durations=8 > $O/pytest.log 2>&1
 echo "rc=$?" >> $O/pytest.log; tail -30 $O/pytest.log
 NB="--no-cpu-baseline --no-verify --steps 110 --repeats 3"
 run() {

@@ -424,11 +424,10 @@ static int note_gather(serl_rb* rb, hipStream_t stream) {
 // ... and a gather enqueued after an insert sees it: `stream` waits for the last insert's copies.  Caller holds rb->mu.
 // Once the last insert's event has COMPLETED the flag is cleared and later gathers carry no wait at all: until round 5 the flag
 // was never cleared, so every gather -- the first command of every trunk pass -- opened with a cross-stream wait on a
-// long-finished event (one of the suspects for the 75-90 us of idle time at the pass boundary, profiles/README.md).
+// long-finished event (same-call A/B: pipelined 2.4497 / 2.4696 -> 2.4431 / 2.4544 ms, serial unchanged; NOT the cause of the
+// 80-110 us of idle time at the pass boundary, profiles/README.md).
 static int order_after_inserts(serl_rb* rb, hipStream_t stream) {
   if (!rb->insert_pending) return SERL_OK;
-  static const bool old_wait = []() { const char* e = getenv("SERL_RB_OLD_WAIT"); return e && e[0] == '1'; }();   // TEMPORARY (A/B of round 5)
-  if (old_wait) { SERL_HIP(hipStreamWaitEvent(stream, rb->last_insert, 0)); return SERL_OK; }
   const hipError_t q = hipEventQuery(rb->last_insert);
   if (q == hipSuccess) { rb->insert_pending = false; return SERL_OK; }
   if (q != hipErrorNotReady) SERL_HIP(q);
@@ -502,14 +501,9 @@ static int stage_params(serl_rb* rb, const void* const* srcs, const size_t* size
     }
   }
   uint8_t* d = rb->stage_dev + (size_t)s * rb->stage_slot_bytes;
-  static const bool zero_copy = []() { const char* e = getenv("SERL_STAGE_ZEROCOPY"); return e && e[0] == '1'; }();   // TEMPORARY (A/B, round 5)
-  if (zero_copy) {   // the kernel reads the (coherent, pinned) host slot itself: no copy command on the stream
-    void* dp = nullptr;
-    SERL_HIP(hipHostGetDevicePointer(&dp, h, 0));
-    d = static_cast<uint8_t*>(dp);
-  } else {
-    SERL_HIP(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, stream));
-  }
+  // (round 5: letting the gather kernel read the pinned host slot itself -- no copy command on the stream -- left the step
+  //  unchanged, 2.5225 / 2.5198 -> 2.5221 / 2.5239 ms: the idle time in front of a pass is not the copy's, profiles/README.md)
+  SERL_HIP(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, stream));
   *dev_out = d;
   rb->stage_used[s] = true;
   return s;

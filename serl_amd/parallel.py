@@ -92,6 +92,8 @@ class TorchPipelineSchedule:
         # not starved by the (throughput-bound) trunk kernels of the next batch
         self.side_stream = torch.cuda.Stream(device=device, priority=-1 if prioritise_trunk else 0)
         self.main_stream = torch.cuda.Stream(device=device, priority=-1) if prioritise_update else None
+        # (round 5: events created with hipEventDisableSystemFence -- these and every event of the library -- left the step and the
+        #  idle time at the pass boundary unchanged: 2.4702 / 2.4698 -> 2.4790 / 2.4534 ms, profiles/README.md)
         self.ev_prod = [torch.cuda.Event() for _ in range(self.slots)]
         self.ev_cons = [None] * self.slots
 

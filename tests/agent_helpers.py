@@ -30,11 +30,25 @@ def make_pair(cfg: O.Config, B, dtype=torch.float64, seed=42, agent_seed=0, trun
     return st, core
 
 
-def synth_batch(cfg: O.Config, B, seed=0):
+_FRAMES = {}
+
+
+def synth_batch(cfg: O.Config, B, seed=0, frames_seed=None):
+    """frames_seed: take the (obs, next) frames from that seed instead of `seed` -- full-shape tests share ONE frame set so that the
+    fp64 oracle's frozen-trunk pass over it (O.features, memoised) is paid once per session; everything else follows `seed`."""
     rng = np.random.default_rng(seed)
+    if frames_seed is not None:
+        fk = (cfg.image_keys, B, cfg.H, cfg.W, frames_seed)
+        if fk not in _FRAMES:
+            fr = np.random.default_rng(frames_seed)
+            _FRAMES[fk] = ({k: fr.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys},
+                           {k: fr.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys})
+        for k in cfg.image_keys:       # (keep `rng` where it would be without the shared frames: scalar fields unchanged)
+            rng.integers(0, 256, (1,), dtype=np.uint8)
+        obs, nxt = _FRAMES[fk]
     return {
-        "obs": {k: rng.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys},
-        "next": {k: rng.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys},
+        "obs": {k: v.copy() for k, v in obs.items()} if frames_seed is not None else {k: rng.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys},
+        "next": {k: v.copy() for k, v in nxt.items()} if frames_seed is not None else {k: rng.integers(0, 256, (B, cfg.H, cfg.W, 3), dtype=np.uint8) for k in cfg.image_keys},
         "state": rng.standard_normal((B, cfg.S)).astype(np.float32),
         "next_state": rng.standard_normal((B, cfg.S)).astype(np.float32),
         "action": rng.uniform(-1, 1, (B, cfg.A)).astype(np.float32),

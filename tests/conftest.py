@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
+    config.addinivalue_line("markers", "slow: long variant of a test that has a short form in the default run (SERL_SLOW=1 runs it)")
 
 
 def _has_gpu():
@@ -20,6 +21,11 @@ def _has_gpu():
 def pytest_collection_modifyitems(config, items):
     """A plain `pytest tests` on a CPU box skips the gpu-marked tests instead of erroring.  The GPU runner
     (`-m gpu`, or SERL_REQUIRE_GPU=1) stays strict: selecting GPU tests without a GPU is a failure there."""
+    if os.environ.get("SERL_SLOW") != "1":
+        skip_slow = pytest.mark.skip(reason="long variant (SERL_SLOW=1 runs it); its short form is part of this run")
+        for it in items:
+            if "slow" in it.keywords:
+                it.add_marker(skip_slow)
     if _has_gpu():
         return
     strict = os.environ.get("SERL_REQUIRE_GPU") == "1" or "gpu" in (config.getoption("-m") or "").replace("not gpu", "")

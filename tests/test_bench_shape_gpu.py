@@ -46,11 +46,13 @@ def _assert_grads(worst, worst_el, what):
     print(f"{what}: worst leaf {max(worst.values()):.2e}, worst element (>1e-3 of max) {max(worst_el.values()):.2e}")
 
 
-@pytest.mark.parametrize("keys,A", [(KEYS, 6), (("wrist_1", "wrist_2"), 7)])   # C2 (headline) and C4/C5-style keys
+# C2 (headline) in every run; C4/C5-style keys and A = 7 at the full shape is the long variant (their small-shape form is
+# tests/test_agent_gpu.py::test_baseline_config_shapes_match_oracle)
+@pytest.mark.parametrize("keys,A", [(KEYS, 6), pytest.param(("wrist_1", "wrist_2"), 7, marks=pytest.mark.slow)])
 def test_update_critics_at_bench_shape(gpu, keys, A):
     cfg = _cfg(keys, A)
     st, core = AH.make_pair(cfg, B)
-    b = AH.synth_batch(cfg, B, seed=21)
+    b = AH.synth_batch(cfg, B, seed=21, frames_seed=70 if keys == KEYS else None)
     noise = O.make_noise(cfg, B, seed=22)
     torch.set_num_threads(max(1, torch.get_num_threads()))
     info, aux = O.update_critics(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64))
@@ -76,7 +78,7 @@ def test_update_critics_at_bench_shape(gpu, keys, A):
 def test_update_high_utd_at_bench_shape(gpu):
     cfg = _cfg()
     st, core = AH.make_pair(cfg, B)
-    b = AH.synth_batch(cfg, B, seed=23)
+    b = AH.synth_batch(cfg, B, seed=23, frames_seed=71)
     noise = O.make_noise(cfg, B, seed=24, utd_ratio=1)
     info, aux = O.update_high_utd(st, AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64), 1)
     db = AH.batch_to_device(cfg, b)

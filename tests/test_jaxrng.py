@@ -1,6 +1,6 @@
 """The product's JAX PRNG (serl_amd/csrc/jaxrng.hip through serl_amd/jaxrng.py) against oracle/jaxshim/jax/threefry.py, which is
 pinned on the Random123 known-answer vectors and the values of JAX's documentation (tests/test_threefry_oracle.py).
-CPU part: every host entry point (keys, integers: BIT-EXACT; host normals: within 2e-6 relative of the oracle's float64 erf_inv)
+CPU part: every host entry point (keys, integers: BIT-EXACT; host normals: within 1e-5 relative of the oracle's float64 erf_inv)
 and the key schedule of one learner call (agents/continuous/drq.py:276-318, sac.py:137,151,197,222,287-289, common/common.py:197-200)
 against the same schedule written out with the oracle's split.  GPU part: the device draws."""
 import numpy as np
@@ -53,10 +53,11 @@ def test_host_normals_are_within_a_few_ulps_of_the_oracle():
     k = T.PRNGKey(7)
     for n in (1, 6, 1537):
         got, want = J.normal_host(k, n), T.normal(k, (n,))
-        # same 32-bit draws, same uniform; erf_inv: XLA's float32 polynomial (Giles: relative error of a few 1e-7, which IS what a
-        # JAX run computes) here, float64 scipy rounded to float32 in the oracle
+        # same 32-bit draws, same uniform; erf_inv: XLA's float32 formula here (Giles' polynomial on w = -log1p(-u*u) evaluated in
+        # float32: a few 1e-7 in the centre, up to 6e-6 for |x| > 3 where 1 - u*u cancels -- which IS what a JAX run computes),
+        # float64 scipy rounded to float32 in the oracle
         err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-        assert (err <= 2e-6 * np.abs(want) + 1e-7).all(), float((err / (np.abs(want) + 1e-30)).max())
+        assert (err <= 1e-5 * np.abs(want) + 2e-7).all(), float((err / (np.abs(want) + 1e-30)).max())
 
 
 def _schedule_by_hand(rng, drq_aug, n_critic, has_actor, combined=False):
@@ -117,7 +118,7 @@ def test_device_draws(gpu):
         assert np.array_equal(bits.cpu().numpy().view(np.uint32), T.random_bits(k, (n,)))
         assert np.array_equal(msk.cpu().numpy().astype(bool), T.bernoulli(k, 0.9, (n,)))
         got, want = nrm.cpu().numpy(), T.normal(k, (n,))
-        assert (np.abs(got.astype(np.float64) - want) <= 2e-6 * np.abs(want) + 1e-7).all()
+        assert (np.abs(got.astype(np.float64) - want) <= 1e-5 * np.abs(want) + 2e-7).all()
         assert np.abs(got - J.normal_host(k, n)).max() < 1e-6      # host and device libm differ in the last bits of log1p / sqrt
     # a window of a larger array (a rank's rows of a data-parallel batch, a UTD minibatch)
     n, first, count = 256 * 6, 64 * 6, 32 * 6

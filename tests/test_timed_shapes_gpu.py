@@ -58,7 +58,7 @@ def _oracle_pair():
         cfg = _cfg()
         trunk, theta = O.init_params(cfg, 42)
         st = O.TrainState(cfg, trunk, theta, torch.float64)
-        b = AH.synth_batch(cfg, B, seed=61)
+        b = AH.synth_batch(cfg, B, seed=61, frames_seed=70)
         noise = O.make_noise(cfg, B, seed=62, utd_ratio=1)
         tb, tn = AH.batch_to_torch(b, torch.float64), O.noise_to_torch(noise, torch.float64)
         fo, fn = O.features(st, tb["obs"]), O.features(st, tb["next"])
@@ -163,7 +163,7 @@ def test_car8_iteration_at_bench_shape(gpu):
     the HIP side runs the whole path (trunk + update) on every step."""
     cfg = _cfg()
     st, core = AH.make_pair(cfg, B)
-    frames = [AH.synth_batch(cfg, B, seed=70 + i) for i in range(2)]
+    frames = [AH.synth_batch(cfg, B, seed=70 + i, frames_seed=70 + i) for i in range(2)]
     feats = []
     for f in frames:
         tb = AH.batch_to_torch(f, torch.float64)

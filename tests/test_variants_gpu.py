@@ -12,10 +12,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_exact_fp32_gemm_passes_the_bench_shape_parity_test(gpu):
+def _child(test_file, k, n):
     env = dict(os.environ, SERL_GEMM="f32")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_bench_shape_gpu.py", "-q", "-x", "-m", "gpu", "-k",
-                        "update_high_utd_at_bench_shape"],
+    r = subprocess.run([sys.executable, "-m", "pytest", test_file, "-q", "-x", "-m", "gpu", "-k", k],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "1 passed" in r.stdout, r.stdout[-500:]
+    assert f"{n} passed" in r.stdout, r.stdout[-500:]
+
+
+def test_exact_fp32_gemm_passes_the_update_parity_tests(gpu):
+    """critic + actor / temperature updates at B = 40 and 16, 64x64 (a few seconds; the bench-shape form below is the long one)"""
+    _child("tests/test_agent_gpu.py", "test_update_high_utd_matches_oracle and f16x3", 2)
+
+
+@pytest.mark.slow
+def test_exact_fp32_gemm_passes_the_bench_shape_parity_test(gpu):
+    _child("tests/test_bench_shape_gpu.py", "update_high_utd_at_bench_shape", 1)
