@@ -117,6 +117,10 @@ def main():
                          "one all-reduce per update on the update stream itself (off)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="go through torch.distributed.run (one rank per GPU, RCCL group) even with --gpus 1")
+    ap.add_argument("--noise", choices=["threefry", "hash"], default="threefry",
+                    help="policy noise / Dropout masks: jax.random's threefry stream with the reference's key schedule, filled on the "
+                         "device per update (default), or hashed inside the consuming kernels (no noise tensors).  Crop offsets and "
+                         "REDQ indices are the reference's threefry integers either way")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE rank's share (B/world samples, no collective) of a world-size-N job")
     args = ap.parse_args()
@@ -233,7 +237,8 @@ def main():
             dist.all_reduce(t)
 
     learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
-                                  all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on")
+                                  all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on",
+                                  image_keys=KEYS, device_noise=args.noise)
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
     if os.environ.get("SERL_BENCH_DIAG") == "noproduced" and hasattr(sched, "ev_prod"):
@@ -456,6 +461,8 @@ def main():
                    "critic_actor_ratio": car, "utd_ratio": 1,
                    "buffers": [{"capacity": c_, "fill": f_, "seed": s_, "samples_per_batch": n_} for c_, f_, s_, n_ in bufspec],
                    "replay_capacity": bufspec[0][0], "replay_fill": bufspec[0][1], "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": car,
+                   "random_stream": ("jax.random threefry2x32 with the reference's key schedule: crop offsets, REDQ indices"
+                                     + (", policy noise, Dropout masks" if learner.device_noise == "threefry" else "; policy noise / Dropout masks hashed on the device")),
                    "encoder": args.encoder, "trunk_passes_per_grad_step": 0 if small else 2, "trunk_arithmetic": "f32" if small else args.trunk,
                    "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
         "roofline": roofline,

@@ -132,7 +132,12 @@ class DataParallelLearner:
 
     def __init__(self, core, gather, buffers: List[object], batch_sizes: List[int], rank: int = 0,
                  world: int = 1, all_reduce=None, seed: int = 0, ensemble: int = 10, schedule=None,
-                 overlap_reduce: bool = False):
+                 overlap_reduce: bool = False, image_keys=None, device_noise: str = "hash"):
+        """seed: the reference's `make_drq_agent(seed, ...)` -- state.rng starts where DrQAgent.create_drq leaves it and advances
+        with the reference's key schedule (serl_amd/jaxrng.py); crop offsets and REDQ indices of every step are the integers a JAX
+        learner with that seed draws.  device_noise = "threefry": policy noise and Dropout masks are jax.random's too (this rank's
+        rows of the global (B, A) normals / (B, 4096) masks, filled by one launch per update; needs image_keys) -- "hash": hashed
+        inside the kernels that consume them from cfg.seed (no noise tensors)."""
         self.core, self.gather, self.buffers, self.batch_sizes = core, gather, buffers, batch_sizes
         self.rank, self.world = rank, world
         self.B = sum(batch_sizes)
@@ -141,9 +146,16 @@ class DataParallelLearner:
         self.all_reduce = all_reduce
         self.ensemble = ensemble
         self.sched = schedule or SerialSchedule()
-        # host noise shared by all ranks (same seed): crop offsets and REDQ subsample indices
-        self._crop_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 1])))
-        self._redq_rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 2])))
+        # the reference's random stream, identical on all ranks (same seed): state.rng as create_drq leaves it (drq.py:69-84)
+        from . import jaxrng as J
+        self._J = J
+        self._rng = J.split(J.split(J.prngkey(seed))[0])[1]
+        self._keys = None            # keys of the call in progress
+        self.image_keys = tuple(image_keys) if image_keys is not None else None
+        assert device_noise in ("hash", "threefry")
+        self.device_noise = device_noise if (self.image_keys is not None and hasattr(core, "cfg")) else "hash"
+        self._nbuf = None
+        self.last_draws = {}
         self._gv = {}
         self._pending = None   # slot of the prefetched (sampled + gathered + encoded) batch
         self.force_reduce = False   # diagnostic: issue the collectives even with one rank
@@ -174,9 +186,10 @@ class DataParallelLearner:
         if self.world > 1 or self.force_reduce:
             self.all_reduce(self._view(which))
 
-    def _produce(self):
+    def _produce(self, rng):
         """Sample one global batch (identical index/crop streams on all ranks), materialise this rank's
-        slice and run the frozen trunk on it -- on the side stream when pipelining."""
+        slice and run the frozen trunk on it -- on the side stream when pipelining.  `rng`: state.rng at the entry of the call
+        that will consume this batch (rng, obs_rng, next_obs_rng = split(rng, 3), drq.py:276-277,307-308)."""
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.sched.slots
         # replicated stores (serl_amd/data/replicated.py): every rank applies the same actor transitions here, i.e. at
@@ -185,8 +198,9 @@ class DataParallelLearner:
             if hasattr(buf, "step_barrier"):
                 buf.step_barrier()
         parts = [(b, b.sample_indices(n)) for b, n in zip(self.buffers, self.batch_sizes)]
-        co = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
-        cn = self._crop_rng.integers(0, 9, size=(self.B, 2)).astype(np.int32)
+        k3 = self._J.split(rng, 3)
+        co, cn = self._J.crop_offsets(k3[1], self.B, 4), self._J.crop_offsets(k3[2], self.B, 4)
+        self.last_draws["crops"] = (co, cn)
         local, (lo, hi) = shard_parts(parts, self.rank, self.world)
         self.sched.wait_consumed(slot)
         split = getattr(self.sched, "update_after_stage", None)
@@ -202,18 +216,56 @@ class DataParallelLearner:
         return slot
 
     def _acquire(self):
-        slot = self._pending if self._pending is not None else self._produce()
+        slot = self._pending if self._pending is not None else self._produce(self._keys.rng_in)
         self._pending = None
         if self.sched.slots > 1:
-            self._pending = self._produce()      # batch i+1 overlaps the update of batch i
+            self._pending = self._produce(self._keys.rng_out)      # batch i+1 overlaps the update of batch i; its call starts at rng_out
             if getattr(self.sched, "update_after_stage", None) is not None:
                 self.sched.wait_mid(self._pending)
         self.sched.wait_produced(slot)
         self.core.select_slot(slot)
         return slot
 
+    def _noise(self, critic: bool):
+        """this rank's rows of the call's jax.random draws (device_noise = "threefry"), REDQ indices always"""
+        J, keys = self._J, self._keys
+        noise = {}
+        if critic:
+            noise["redq_idx"] = J.randint(keys.k_subsample[0], 2, 0, self.ensemble).reshape(1, 2)
+            self.last_draws["redq_idx"] = noise["redq_idx"]
+        if self.device_noise != "threefry":
+            return noise if critic else None
+        import torch
+        c = self.core.cfg
+        A, D, Bl, B, lo = c.act_dim, 512 * c.sle_features, self.Bl, self.B, self.rank * self.Bl
+        n_cam = c.n_cam if c.encoder_type == 0 else 0
+        if self._nbuf is None:
+            dev = self.core.device
+            self._nbuf = {k: torch.empty((Bl, A), dtype=torch.float32, device=dev) for k in ("eps_next", "eps_pi", "eps_temp")}
+            if n_cam:
+                self._nbuf.update({k: torch.empty((n_cam, Bl, D), dtype=torch.uint8, device=dev)
+                                   for k in ("mask_next", "mask_obs_pi", "mask_next_temp")})
+        nb, jobs, keep = self._nbuf, [], 1.0 - float(c.dropout)
+
+        def draws(eps_name, eps_key, mask_name, mask_key):
+            jobs.append(J.job(J.NORMAL, eps_key, B * A, nb[eps_name].data_ptr(), first=lo * A, count=Bl * A))
+            noise[eps_name] = nb[eps_name]
+            for ci, cam in enumerate(self.image_keys[:n_cam]):
+                jobs.append(J.job(J.BERNOULLI_U8, J.flax_make_rng(mask_key, J.dropout_path(cam), 1), B * D,
+                                  nb[mask_name].data_ptr() + ci * Bl * D, first=lo * D, count=Bl * D, p=keep))
+            if n_cam:
+                noise[mask_name] = nb[mask_name]
+
+        if critic:
+            draws("eps_next", keys.k_next_action[0], "mask_next", keys.k_next_action[0])
+        else:
+            draws("eps_pi", keys.k_sample, "mask_obs_pi", keys.k_policy)
+            draws("eps_temp", keys.k_temp, "mask_next_temp", keys.k_temp)
+        J.fill(c.device, jobs, self.core._stream())
+        return noise
+
     def _critic(self):
-        noise = {"redq_idx": self._redq_rng.integers(0, self.ensemble, size=(1, 2)).astype(np.int32)}
+        noise = self._noise(True)
         self.core.begin_update()
         if self._overlap and (self.world > 1 or self.force_reduce):
             self._critic_overlapped(noise)
@@ -243,20 +295,24 @@ class DataParallelLearner:
 
     def update_critics(self):
         """DrQAgent.update_critics over the global batch (one grad-step)."""
+        self._keys = self._J.UpdateKeys(self._rng, True, 1, False)
         with self.sched.main():
             slot = self._acquire()
             self._critic()
             self.sched.consumed(slot)
+        self._rng = self._keys.rng_out
 
     def update_high_utd(self):
         """DrQAgent.update_high_utd(utd_ratio=1): critic step, then actor+temperature on the same batch."""
+        self._keys = self._J.UpdateKeys(self._rng, True, 1, True)
         with self.sched.main():
             slot = self._acquire()
             self._critic()
-            self.core.actor_grads(self.B, None)
+            self.core.actor_grads(self.B, self._noise(False))
             self._reduce(APPLY_ACTOR_TEMP)
             self.core.apply(APPLY_ACTOR_TEMP)
             self.sched.consumed(slot)
+        self._rng = self._keys.rng_out
 
     def iteration(self, critic_actor_ratio: int = 1):
         """One learner-loop iteration (examples/async_drq_sim/async_drq_sim.py:266-292)."""
