@@ -117,6 +117,13 @@ def main():
                          "one all-reduce per update on the update stream itself (off)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="go through torch.distributed.run (one rank per GPU, RCCL group) even with --gpus 1")
+    ap.add_argument("--parallel", choices=["dp", "farm"], default="dp",
+                    help="how --gpus N > 1 spreads the learner: dp = batch-sharded data parallelism with gradient all-reduce (default); "
+                         "farm = step-pipelined trunk farm (serl_amd/parallel.py TrunkFarmLearner: rank 0 updates on the full batch, "
+                         "ranks 1..N-1 run the frozen trunk of every (N-1)-th batch and send the features point to point)")
+    ap.add_argument("--farm-role", choices=["updater", "worker"], default=None,
+                    help="single-GPU measurement of ONE piece of the trunk farm: worker = gather + augment + trunk of every batch, no "
+                         "update; updater = the update chain with nothing co-running, features arriving by a device-to-device copy")
     ap.add_argument("--noise", choices=["threefry", "hash"], default="threefry",
                     help="policy noise / Dropout masks: jax.random's threefry stream with the reference's key schedule, filled on the "
                          "device per update (default), or hashed inside the consuming kernels (no noise tensors).  Crop offsets and "
@@ -164,8 +171,9 @@ def main():
     if args.fill is not None:
         bufspec[0][1] = args.fill
     B = sum(b[3] for b in bufspec)
-    assert B % world == 0
-    Bl = B // world
+    farm = args.parallel == "farm" and world > 1 or args.farm_role is not None
+    assert farm or B % world == 0
+    Bl = B if farm else B // world                     # a trunk farm keeps the FULL batch on every rank
     emu = args.emulate_world
     if emu:
         assert world == 1
@@ -236,9 +244,37 @@ def main():
         else:
             dist.all_reduce(t)
 
-    learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
-                                  all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on",
-                                  image_keys=KEYS, device_noise=args.noise)
+    if farm:
+        from serl_amd.parallel import TrunkFarmLearner
+
+        class _Copied:      # emulated transfer: a device-to-device copy of one batch's features on a third stream
+            def __init__(self):
+                self.stream, self.ev, self.src = torch.cuda.Stream(device=local_rank), torch.cuda.Event(), None
+
+            def __call__(self, t, peer, tag):
+                if self.src is None:
+                    self.src = torch.randn_like(t) * 0.1
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    t.copy_(self.src, non_blocking=True)
+                    self.ev.record(self.stream)
+                return self
+
+            def wait(self):
+                torch.cuda.current_stream().wait_event(self.ev)
+
+        if args.farm_role is not None:
+            assert world == 1
+            send, recv = None, (_Copied() if args.farm_role == "updater" else None)
+        else:
+            send = lambda t, dst, tag: dist.isend(t, dst)       # noqa: E731  (RCCL point to point; tags are not used by the backend)
+            recv = lambda t, src, tag: dist.irecv(t, src)       # noqa: E731
+        learner = TrunkFarmLearner(core, gather, rbs, [b[3] for b in bufspec], rank, world, send=send, recv=recv, seed=7,
+                                   schedule=sched, image_keys=KEYS, device_noise=args.noise, role=args.farm_role)
+    else:
+        learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
+                                      all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on",
+                                      image_keys=KEYS, device_noise=args.noise)
 
     learner.force_reduce = args.force_collective or launched   # a launched 1-rank job still runs the RCCL path
     if os.environ.get("SERL_BENCH_DIAG") == "noproduced" and hasattr(sched, "ev_prod"):
@@ -320,7 +356,8 @@ def main():
         host_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     info = core.read_info()
-    assert all(np.isfinite(v) for v in info.values()), info
+    if not (farm and learner.role == "worker"):
+        assert all(np.isfinite(v) for v in info.values()), info
     if world > 1:   # max over ranks, per repetition
         t = torch.tensor(dts, device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -328,7 +365,7 @@ def main():
     dt = float(np.median(dts))
     grad_steps = args.steps * car
     value = grad_steps / dt
-    verify = None if (args.no_verify or args.no_pipeline or args.trunk != "f16x3" or small) else verify_features(learner, core, dbs, car)
+    verify = None if (args.no_verify or args.no_pipeline or args.trunk != "f16x3" or small or farm) else verify_features(learner, core, dbs, car)
 
     # ---- roofline of the dominant kernel family (implicit-GEMM convs of the frozen trunk)
     macs = conv_macs_per_image()
@@ -460,7 +497,9 @@ def main():
                    "per_gpu_batch": Bl, "cameras": len(KEYS), "image_keys": list(KEYS), "image": [H, W, 3], "state_dim": S, "act_dim": A,
                    "critic_actor_ratio": car, "utd_ratio": 1,
                    "buffers": [{"capacity": c_, "fill": f_, "seed": s_, "samples_per_batch": n_} for c_, f_, s_, n_ in bufspec],
-                   "replay_capacity": bufspec[0][0], "replay_fill": bufspec[0][1], "parallelism": f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else ""), "grad_steps_per_step": car,
+                   "replay_capacity": bufspec[0][0], "replay_fill": bufspec[0][1], "parallelism": (f"trunk farm, {args.farm_role} role measured alone on one GPU" if args.farm_role else
+                                                                                                      f"trunk farm: 1 updater + {world - 1} trunk workers, features point to point" if farm else
+                                                                                                      f"dp{world}" + (f" (emulating 1 rank of dp{emu}, no collective)" if emu else "")), "grad_steps_per_step": car,
                    "random_stream": ("jax.random threefry2x32 with the reference's key schedule: crop offsets, REDQ indices"
                                      + (", policy noise, Dropout masks" if learner.device_noise == "threefry" else "; policy noise / Dropout masks hashed on the device")),
                    "encoder": args.encoder, "trunk_passes_per_grad_step": 0 if small else 2, "trunk_arithmetic": "f32" if small else args.trunk,
@@ -487,7 +526,8 @@ def main():
                     + "and one of [scalars | actor grads] per actor update; HIP events on the stream the collective is enqueued on, every 4th call"}
     if verify is not None:
         out["verify"] = verify
-    diag = os.environ.get("SERL_BENCH_DIAG") or ("hostprof" if os.environ.get("SERL_BENCH_HOSTPROF") == "1" else "")
+    diag = os.environ.get("SERL_BENCH_DIAG") or ("hostprof" if os.environ.get("SERL_BENCH_HOSTPROF") == "1" else "") or (
+        f"farm-role-{args.farm_role}" if args.farm_role else "")
     if diag:
         # a diagnostic run is never a bench line: no `metric` / `value` / `unit` (SERL_BENCH_DIAG=noproduced runs updates that did
         # not wait for their features -- its numbers time a wrong computation)

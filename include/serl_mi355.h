@@ -255,6 +255,13 @@ int serl_agent_encode_slot(serl_agent* a, const serl_batch* batch, int slot, voi
  * the update of the previous batch only once this pass has left its first stages. */
 int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slot, int stage_begin, int stage_end, void* stream);
 int serl_agent_select_slot(serl_agent* a, int slot);
+/* Features computed ELSEWHERE.  The trunk is frozen and its output is cut off by a stop_gradient (vision/resnet_v1.py:286), so
+ * the features of a batch depend on its pixels only -- another GPU can run that pass ("trunk farm": serl_amd/parallel.py
+ * TrunkFarmLearner).  serl_agent_slot_features gives the slot's feature buffer f32[2][n_cam][batch][h*w][512] (what encode_slot
+ * writes; a producer sends from it, the updating rank receives into it); serl_agent_bind_slot attaches a batch (states, actions,
+ * rewards, masks -- and its frames, which the update does not read) to a slot WITHOUT running the trunk. */
+int serl_agent_slot_features(serl_agent* a, int slot, float** dev_out, int64_t* count_out);
+int serl_agent_bind_slot(serl_agent* a, const serl_batch* batch, int slot);
 int serl_agent_critic_grads(serl_agent* a, int offset, int count, int global_count,
                             const serl_noise* noise, int redq_row, void* stream);
 /* The same critic phase with its gradients published in two BUCKETS so the caller can all-reduce the first while the

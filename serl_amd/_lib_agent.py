@@ -61,6 +61,8 @@ def declare(lib):
         "serl_agent_encode_slot": [vp, P(SerlBatch), i32, vp],
         "serl_agent_encode_slot_range": [vp, P(SerlBatch), i32, i32, i32, vp],
         "serl_agent_select_slot": [vp, i32],
+        "serl_agent_slot_features": [vp, i32, P(vp), P(i64)],
+        "serl_agent_bind_slot": [vp, P(SerlBatch), i32],
         "serl_agent_critic_grads": [vp, i32, i32, i32, P(SerlNoise), i32, vp],
         "serl_agent_critic_grads_bucketed": [vp, i32, i32, i32, P(SerlNoise), i32, vp, vp],
         "serl_agent_grad_bucket": [vp, i32, P(vp), P(i64)],

@@ -170,6 +170,16 @@ class AgentCore:
     def select_slot(self, slot):
         _lib.check(self.L.serl_agent_select_slot(self._h, slot))
 
+    def bind_slot(self, batch, slot):
+        """attach a batch to a pipeline slot without running the trunk (its features arrive from another GPU: slot_features)"""
+        _lib.check(self.L.serl_agent_bind_slot(self._h, C.byref(batch.cstruct), slot))
+
+    def slot_features(self, slot) -> torch.Tensor:
+        """zero-copy view of the slot's frozen-trunk features, f32[2 * n_cam * batch * h*w * 512]"""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.L.serl_agent_slot_features(self._h, slot, C.byref(p), C.byref(n)))
+        return _wrap_device_f32(p.value, int(n.value), self.device)
+
     def critic_grads(self, offset, count, global_count, noise=None, redq_row=0):
         _lib.check(self.L.serl_agent_critic_grads(self._h, offset, count, global_count, self._noise(noise),
                                                   redq_row, self._stream()))

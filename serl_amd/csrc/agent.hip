@@ -1116,6 +1116,26 @@ int serl_agent_encode_slot_range(serl_agent* a, const serl_batch* batch, int slo
   return SERL_OK;
 }
 
+int serl_agent_slot_features(serl_agent* a, int slot, float** dev_out, int64_t* count_out) {
+  SERL_REQUIRE(a && dev_out && count_out, "NULL argument");
+  SERL_REQUIRE(slot >= 0 && slot < serl_agent::kSlots, "slot must be 0..%d", serl_agent::kSlots - 1);
+  SERL_REQUIRE(!a->state_only && !a->small, "this agent has no frozen-trunk features");
+  *dev_out = a->feats_slot[slot];
+  *count_out = 2LL * a->cfg.n_cam * a->cfg.batch * a->HW * 512;
+  return SERL_OK;
+}
+
+int serl_agent_bind_slot(serl_agent* a, const serl_batch* batch, int slot) {
+  SERL_REQUIRE(a, "NULL agent");
+  SERL_REQUIRE(slot >= 0 && slot < serl_agent::kSlots, "slot must be 0..%d", serl_agent::kSlots - 1);
+  int rc = check_batch(a, batch);
+  if (rc) return rc;
+  SERL_REQUIRE(batch->batch == a->cfg.batch, "externally computed features cover a full-size batch");
+  a->cur_slot[slot] = *batch;
+  a->slot_valid[slot] = true;
+  return SERL_OK;
+}
+
 int serl_agent_select_slot(serl_agent* a, int slot) {
   SERL_REQUIRE(a, "NULL agent");
   SERL_REQUIRE(slot >= 0 && slot < serl_agent::kSlots && a->slot_valid[slot], "slot %d holds no encoded batch", slot);

@@ -319,3 +319,102 @@ class DataParallelLearner:
         for _ in range(critic_actor_ratio - 1):
             self.update_critics()
         self.update_high_utd()
+
+
+class TrunkFarmLearner(DataParallelLearner):
+    """The second way to spread the learner over P GPUs: a STEP-PIPELINED TRUNK FARM.
+
+    The ResNet trunk is frozen and cut off by a stop_gradient (vision/resnet_v1.py:286), so the features of a batch depend on its
+    pixels only -- not on the parameters being trained, not on any other batch.  Rank 0 (the updater) is the only rank that holds
+    live parameters: it runs every update (sac.py:243-299) on the FULL batch and never runs the trunk.  Ranks 1 .. P-1 (trunk
+    workers) hold the replay replica and the frozen trunk: worker w gathers, augments and encodes every (P-1)-th batch at full
+    batch size -- the efficient 1024-image kernels, not the 1/P-size kernels of batch-sharded data parallelism -- and ships the
+    features (33.5 MB at B = 256, two cameras) to rank 0 point to point.  No gradient all-reduce exists: per step one P2P
+    transfer, off the updater's critical path.  Every rank draws the identical index / key streams (same seed, replicated
+    buffers), so the updater's results are BIT-IDENTICAL to the single-GPU learner's, whatever P.
+
+    Rate = min(update chain alone on rank 0, (P - 1) x one trunk pass): the chain bounds it from P = 4 on.
+
+    send(tensor, dst, tag) / recv(tensor, src, tag) -> handle with .wait() (or None): torch.distributed isend / irecv on RCCL, a
+    host-staged gloo pair in the single-GPU test.  role: "updater" / "worker" override the rank's role for single-GPU emulation
+    (bench.py --farm-role: the pieces of the projection are measured one at a time)."""
+
+    def __init__(self, core, gather, buffers, batch_sizes, rank=0, world=2, send=None, recv=None, seed=0, ensemble=10,
+                 schedule=None, image_keys=None, device_noise="hash", role=None, n_workers=None):
+        super().__init__(core, gather, buffers, batch_sizes, 0, 1, all_reduce=None, seed=seed, ensemble=ensemble,
+                         schedule=schedule, image_keys=image_keys, device_noise=device_noise)
+        assert world >= 2 or role is not None, "a trunk farm needs an updater and at least one worker"
+        self.farm_rank, self.farm_world = rank, world
+        self.role = role or ("updater" if rank == 0 else "worker")
+        self.n_workers = n_workers if n_workers is not None else max(world - 1, 1)
+        self.send, self.recv = send, recv
+        if self.role == "updater" and hasattr(core, "set_chain_budget"):
+            core.set_chain_budget(0)     # nothing co-runs with the update chain on this rank: the default (deeper) K-splits
+        self._t = 0                  # global batch counter (identical on every rank)
+        self._recv_pending = {}      # slot -> handle
+
+    def owner(self, t):
+        return 1 + (t % self.n_workers)
+
+    # every rank walks the same sequence of batches; what it does with batch t depends on its role
+    def _produce(self, rng):
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self.sched.slots
+        t = self._t
+        self._t += 1
+        for buf in self.buffers:
+            if hasattr(buf, "step_barrier"):
+                buf.step_barrier()
+        parts = [(b, b.sample_indices(n)) for b, n in zip(self.buffers, self.batch_sizes)]     # (keeps every rank's index stream in step)
+        k3 = self._J.split(rng, 3)
+        if self.role == "worker" and self.owner(t) != self.farm_rank and self.farm_world > 1:
+            return slot                                                       # another worker's batch
+        co, cn = self._J.crop_offsets(k3[1], self.B, 4), self._J.crop_offsets(k3[2], self.B, 4)
+        self.last_draws["crops"] = (co, cn)
+        self.sched.wait_consumed(slot)
+        with self.sched.side():
+            db = self.gather(parts, co, cn, slot)
+            if self.role == "worker":
+                self.core.encode_slot(db, slot)
+                if self.send is not None:
+                    h = self.send(self.core.slot_features(slot), 0, t)
+                    if h is not None:
+                        self._recv_pending[slot] = h                            # (completion of the send frees the slot)
+            else:
+                self.core.bind_slot(db, slot)
+                if self.recv is not None:
+                    self._recv_pending[slot] = self.recv(self.core.slot_features(slot), self.owner(t), t)
+        self.sched.produced(slot)
+        return slot
+
+    def _wait_transfer(self, slot):
+        h = self._recv_pending.pop(slot, None)
+        if h is not None:
+            h.wait()
+
+    def _acquire(self):
+        slot = super()._acquire()
+        if self.role == "updater":
+            self._wait_transfer(slot)
+        return slot
+
+    def _worker_step(self, has_actor):
+        """a worker's share of one learner call: the key bookkeeping of the call and, if it owns the batch, its pass"""
+        self._keys = self._J.UpdateKeys(self._rng, True, 1, has_actor)
+        slot = self._pending if self._pending is not None else self._produce(self._keys.rng_in)
+        self._pending = None
+        if self.sched.slots > 1:
+            self._pending = self._produce(self._keys.rng_out)
+        self._wait_transfer(slot)          # the send of this slot's features (if it was ours) has completed
+        self.sched.consumed(slot)
+        self._rng = self._keys.rng_out
+
+    def update_critics(self):
+        if self.role == "worker":
+            return self._worker_step(False)
+        return super().update_critics()
+
+    def update_high_utd(self):
+        if self.role == "worker":
+            return self._worker_step(True)
+        return super().update_high_utd()

@@ -32,7 +32,8 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from serl_amd.agents.batch import DeviceBatch
     from serl_amd.data.data_store import MemoryEfficientReplayBufferDataStore, gather_crop
-    from serl_amd.parallel import DataParallelLearner, SerialSchedule
+    from serl_amd.parallel import DataParallelLearner, SerialSchedule, TrunkFarmLearner
+    farm = os.environ.get("SERL_TEST_PARALLEL", "dp") == "farm" and world > 1
     from serl_amd.utils.launcher import make_drq_agent
     from serl_amd.utils.synthetic import transition_stream
     from serl_amd.data.replicated import ReplicatedDataStore
@@ -44,7 +45,7 @@ def main():
             rb.insert(tr)
     rb.flush()                              # collective: the initial fill is in every replica
     assert len(rb) > 150
-    Bl = B // world
+    Bl = B if farm else B // world          # a trunk farm keeps the full batch on every rank
     obs = {"front": np.zeros((1, H, W, 3), np.uint8), "wrist": np.zeros((1, H, W, 3), np.uint8), "state": np.zeros((1, S), np.float32)}
     agent = make_drq_agent(3, obs, np.zeros((A,), np.float32), image_keys=KEYS, encoder_type="resnet-pretrained", batch_size=Bl)
     core = agent.core
@@ -59,8 +60,20 @@ def main():
         dist.all_reduce(h)
         t.copy_(h)
 
-    learner = DataParallelLearner(core, gather, [rb], [B], rank, world, all_reduce=all_reduce, seed=7, schedule=SerialSchedule(),
-                                  overlap_reduce=os.environ.get("SERL_TEST_OVERLAP", "1") == "1")   # (the opt-in bucketed path stays covered)
+    def send(t, dst, tag):                  # features of one batch, worker -> updater (gloo on the host copy)
+        torch.cuda.synchronize()
+        dist.send(t.cpu(), dst)
+
+    def recv(t, src, tag):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(h, src)
+        t.copy_(h)
+
+    if farm:
+        learner = TrunkFarmLearner(core, gather, [rb], [B], rank, world, send=send, recv=recv, seed=7, schedule=SerialSchedule())
+    else:
+        learner = DataParallelLearner(core, gather, [rb], [B], rank, world, all_reduce=all_reduce, seed=7, schedule=SerialSchedule(),
+                                      overlap_reduce=os.environ.get("SERL_TEST_OVERLAP", "1") == "1")   # (the opt-in bucketed path stays covered)
     drawn = []
     orig = rb.replica.sample_indices
     rb.replica.sample_indices = lambda n: (drawn.append(orig(n)) or drawn[-1])

@@ -145,3 +145,68 @@ def test_learner_declares_its_shard():
         core = FakeCore()
         DataParallelLearner(core, lambda parts, co, cn, slot: None, [Buf()], [16], rank, world, all_reduce=lambda t: None)
         assert getattr(core, "shard", None) == ((rank * 4, 16) if world > 1 else None)
+
+
+# ---- trunk farm (serl_amd/parallel.py TrunkFarmLearner): rank 0 updates, ranks 1.. encode every (P-1)-th batch ------------------
+class FarmCore(FakeCore):
+    """"features" of a batch = a tensor derived from the gathered sample ids; the update reads ONLY the received features"""
+
+    def __init__(self, dim=7, B=24):
+        super().__init__(dim)
+        self.feat = {s: torch.zeros(B, dtype=torch.float64) for s in range(3)}
+        self.encoded = 0
+
+    def encode_slot(self, batch, slot):
+        self.slots[slot] = batch
+        self.feat[slot].copy_(torch.tensor(batch["ids"].astype(np.float64) * 3.0 + 1.0))
+        self.encoded += 1
+
+    def bind_slot(self, batch, slot):
+        self.slots[slot] = {k: v for k, v in batch.items() if k != "ids"}          # the updater never sees pixels
+        self.feat[slot].fill_(float("nan"))                                         # must be overwritten by the transfer
+
+    def slot_features(self, slot):
+        return self.feat[slot]
+
+    def select_slot(self, slot):
+        self.batch = dict(self.slots[slot], ids=((self.feat[slot] - 1.0) / 3.0).numpy().copy())
+
+
+def _run_farm(rank, world, port, out):
+    from serl_amd.parallel import TrunkFarmLearner
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bufs = [FakeBuffer(500, 0), FakeBuffer(60, 1)]
+    core = FarmCore()
+
+    def send(t, dst, tag):
+        dist.send(t, dst)
+
+    def recv(t, src, tag):
+        dist.recv(t, src)
+
+    lr = TrunkFarmLearner(core, _tagged_gather(bufs), bufs, [12, 12], rank, world, send=send, recv=recv, seed=3)
+    for _ in range(4):
+        lr.iteration(critic_actor_ratio=3)
+    out[rank] = (core.params.numpy().copy(), core.encoded, [x.numpy().copy() for x in core.log])
+    dist.destroy_process_group()
+
+
+def test_trunk_farm_world3_equals_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_farm, args=(3, port, out), nprocs=3, join=True)
+    bufs = [FakeBuffer(500, 0), FakeBuffer(60, 1)]
+    core = FakeCore()
+    lr = DataParallelLearner(core, _tagged_gather(bufs), bufs, [12, 12], 0, 1, seed=3)
+    for _ in range(4):
+        lr.iteration(critic_actor_ratio=3)
+    p0, enc0, log0 = out[0]
+    assert enc0 == 0 and np.array_equal(p0, core.params.numpy()), "the updater must reproduce the single process bit for bit"
+    assert len(log0) == len(core.log) and all(np.array_equal(a, b.numpy()) for a, b in zip(log0, core.log))
+    # 12 batches, two workers: six passes each, no parameters ever applied
+    assert out[1][1] == 6 and out[2][1] == 6 and not out[1][2] and not out[2][2]
+    assert not np.any(out[1][0]) and not np.any(out[2][0])
