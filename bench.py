@@ -117,10 +117,12 @@ def main():
                          "one all-reduce per update on the update stream itself (off)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="go through torch.distributed.run (one rank per GPU, RCCL group) even with --gpus 1")
-    ap.add_argument("--parallel", choices=["dp", "farm"], default="dp",
-                    help="how --gpus N > 1 spreads the learner: dp = batch-sharded data parallelism with gradient all-reduce (default); "
+    ap.add_argument("--parallel", choices=["auto", "dp", "farm"], default="auto",
+                    help="how --gpus N > 1 spreads the learner: dp = batch-sharded data parallelism with gradient all-reduce; "
                          "farm = step-pipelined trunk farm (serl_amd/parallel.py TrunkFarmLearner: rank 0 updates on the full batch, "
-                         "ranks 1..N-1 run the frozen trunk of every (N-1)-th batch and send the features point to point)")
+                         "ranks 1..N-1 run the frozen trunk of every (N-1)-th batch and send the features point to point); "
+                         "auto (default) = dp up to 2 GPUs, farm from 4 (the single-GPU measurements of the two designs' pieces, "
+                         "DESIGN.md section 5: 1.75x / 2.71x / 3.63x before collective time vs 1.12x / 3.33x / 3.33x at 2 / 4 / 8 GPUs)")
     ap.add_argument("--farm-role", choices=["updater", "worker"], default=None,
                     help="single-GPU measurement of ONE piece of the trunk farm: worker = gather + augment + trunk of every batch, no "
                          "update; updater = the update chain with nothing co-running, features arriving by a device-to-device copy")
@@ -171,7 +173,7 @@ def main():
     if args.fill is not None:
         bufspec[0][1] = args.fill
     B = sum(b[3] for b in bufspec)
-    farm = args.parallel == "farm" and world > 1 or args.farm_role is not None
+    farm = (args.parallel == "farm" and world > 1) or (args.parallel == "auto" and world >= 3) or args.farm_role is not None
     assert farm or B % world == 0
     Bl = B if farm else B // world                     # a trunk farm keeps the FULL batch on every rank
     emu = args.emulate_world

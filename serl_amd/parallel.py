@@ -356,6 +356,9 @@ class TrunkFarmLearner(DataParallelLearner):
     def owner(self, t):
         return 1 + (t % self.n_workers)
 
+    def _reduce(self, which):
+        pass        # one rank holds the parameters and sees the whole batch: there is no gradient to reduce
+
     # every rank walks the same sequence of batches; what it does with batch t depends on its role
     def _produce(self, rng):
         slot = self._next_slot
@@ -375,6 +378,7 @@ class TrunkFarmLearner(DataParallelLearner):
         with self.sched.side():
             db = self.gather(parts, co, cn, slot)
             if self.role == "worker":
+                self._wait_transfer(slot)      # (this stream: the previous send out of this slot's feature buffer has completed)
                 self.core.encode_slot(db, slot)
                 if self.send is not None:
                     h = self.send(self.core.slot_features(slot), 0, t)
