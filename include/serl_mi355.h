@@ -219,6 +219,18 @@ typedef struct serl_noise {
   const uint8_t* mask_obs_pi;
   const float* eps_temp;          /* temperature loss sample at next_obs (sac.py:224-227) */
   const uint8_t* mask_next_temp;
+  /* Round 5 -- jax.random KEYS instead of tensors (HOST pointers to uint32 words; NULL = none).  Where the tensor above is NULL
+   * and its key is given, the draws are jax.random's for that key (serl_jax_* below: bits exact, normals through XLA's float32
+   * erf_inv), produced INSIDE the kernels that consume them -- no noise tensor exists, no extra launch.  Array shapes are the
+   * reference's: normal(key, (global minibatch rows, act_dim)), bernoulli(key_cam, 1 - dropout, (global minibatch rows, 4096));
+   * a rank of a data-parallel job draws its rows of them (serl_agent_set_shard).  key_*_next are indexed by the minibatch of a
+   * high-UTD update (redq_row): [utd][2] and [utd][n_cam][2]; the others are [2] and [n_cam][2]. */
+  const uint32_t* key_eps_next;
+  const uint32_t* key_mask_next;
+  const uint32_t* key_eps_pi;
+  const uint32_t* key_mask_obs_pi;
+  const uint32_t* key_eps_temp;
+  const uint32_t* key_mask_next_temp;
 } serl_noise;
 
 /* sac.py:185-189,215-219,234,291-297 */

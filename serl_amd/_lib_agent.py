@@ -32,6 +32,9 @@ class SerlNoise(C.Structure):
         ("eps_next", C.c_void_p), ("mask_next", C.c_void_p), ("redq_idx", C.c_void_p),
         ("eps_pi", C.c_void_p), ("mask_obs_pi", C.c_void_p),
         ("eps_temp", C.c_void_p), ("mask_next_temp", C.c_void_p),
+        # jax.random keys (host uint32 words) instead of tensors: serl_mi355.h "Round 5"
+        ("key_eps_next", C.c_void_p), ("key_mask_next", C.c_void_p), ("key_eps_pi", C.c_void_p), ("key_mask_obs_pi", C.c_void_p),
+        ("key_eps_temp", C.c_void_p), ("key_mask_next_temp", C.c_void_p),
     ]
 
 

@@ -104,7 +104,8 @@ class AgentCore:
 
     # ---- updates ---------------------------------------------------------------------------
     def _noise(self, noise: Optional[dict]):
-        """noise: dict of torch device tensors (eps_*, mask_*) and np.int32 redq_idx, or None."""
+        """noise: dict of torch device tensors (eps_*, mask_*), np.int32 redq_idx and / or jax.random keys (key_eps_* uint32[..., 2],
+        key_mask_* uint32[..., n_cam, 2]: draws made inside the consuming kernels where the tensor is absent), or None."""
         if noise is None:
             self._keep = None
             return None
@@ -124,9 +125,19 @@ class AgentCore:
             redq = np.ascontiguousarray(redq, dtype=np.int32)
             keep.append(redq)
             rp = redq.ctypes.data
+        def key(name):      # jax.random keys of draws whose tensor is absent (host uint32 words, kept alive with the struct)
+            k = noise.get(name)
+            if k is None:
+                return None
+            k = np.ascontiguousarray(k, dtype=np.uint32)
+            keep.append(k)
+            return k.ctypes.data
+
         n = SerlNoise(dev("eps_next", torch.float32), dev("mask_next", torch.uint8), rp,
                       dev("eps_pi", torch.float32), dev("mask_obs_pi", torch.uint8),
-                      dev("eps_temp", torch.float32), dev("mask_next_temp", torch.uint8))
+                      dev("eps_temp", torch.float32), dev("mask_next_temp", torch.uint8),
+                      key("key_eps_next"), key("key_mask_next"), key("key_eps_pi"), key("key_mask_obs_pi"),
+                      key("key_eps_temp"), key("key_mask_next_temp"))
         self._keep = (keep, n)
         return C.byref(n)
 

@@ -149,6 +149,10 @@ class DrQAgent:
         # numbers a JAX learner consumes (integers bit-exact).  "hash": crop offsets from a numpy PCG64 stream, noise hashed on
         # the device from cfg.seed inside the kernels that use it (no noise tensors; what the bench's DataParallelLearner runs).
         self.rng_impl = "threefry"
+        # how the threefry draws reach the kernels: "keys" = the kernels draw them in place from the call's keys (no noise tensors,
+        # no extra launch); "tensors" = one serl_jax_fill launch per call materialises them (bit-identical results:
+        # tests/test_drq_agent_gpu.py; the tensors can then be inspected -- agent._noise_bufs)
+        self.noise_form = "keys"
         # state.rng as create_drq / create leave it (drq.py:69-84, sac.py:355-372): rng = PRNGKey(seed); rng, init_rng = split(rng);
         # rng, create_rng = split(rng); JaxRLTrainState.create(rng=create_rng)
         self._rng_key = J.split(J.split(J.prngkey(seed))[0])[1]
@@ -266,6 +270,25 @@ class DrQAgent:
         k = J.split(self._rng_key if rng is None else rng, 3)
         return J.crop_offsets(k[1], B, 4), J.crop_offsets(k[2], B, 4)
 
+    def _jax_keys(self, keys, n_cam, want_critic, want_actor):
+        """serl_noise with KEYS only: every draw happens inside the kernel that consumes it (heads.hip: Dropout mask in the
+        SpatialLearnedEmbeddings kernel, normals in the policy-head epilogue); REDQ indices are host integers."""
+        c, noise = self.core.cfg, {}
+        cam_keys = lambda k: np.stack([J.flax_make_rng(k, J.dropout_path(cam), 1) for cam in self.image_keys[:n_cam]])  # noqa: E731
+        if want_critic and keys.n_critic:
+            m = int(c.critic_subsample_size)
+            noise["key_eps_next"] = np.stack(keys.k_next_action)
+            if n_cam:
+                noise["key_mask_next"] = np.stack([cam_keys(k) for k in keys.k_next_action])
+            if m > 0:
+                noise["redq_idx"] = np.stack([J.randint(k, m, 0, c.ensemble) for k in keys.k_subsample]).astype(np.int32)
+                self.last_draws["redq_idx"] = noise["redq_idx"].copy()
+        if want_actor and keys.has_actor_temp:
+            noise["key_eps_pi"], noise["key_eps_temp"] = keys.k_sample, keys.k_temp
+            if n_cam:
+                noise["key_mask_obs_pi"], noise["key_mask_next_temp"] = cam_keys(keys.k_policy), cam_keys(keys.k_temp)
+        return noise
+
     # ------------------------------------------------------------------ the reference's random stream for one call
     def _call_keys(self, n_critic, has_actor_temp, drq_aug=None, combined=False):
         """Keys of the learner call about to run, derived from state.rng (None when the device-hashed stream is selected)."""
@@ -286,6 +309,8 @@ class DrQAgent:
         dev, A = self.core.device, c.act_dim
         n_cam = c.n_cam if c.encoder_type == 0 else 0          # (the SmallEncoder path has no Dropout: pooling "avg")
         D = 512 * c.sle_features
+        if self.noise_form == "keys":
+            return self._jax_keys(keys, n_cam, want_critic, want_actor)
         nb = self._noise_bufs.get(B)
         if nb is None:
             nb = {k: torch.empty((B, A), dtype=torch.float32, device=dev) for k in ("eps_next", "eps_pi", "eps_temp")}

@@ -408,8 +408,9 @@ struct EncJob {
   EncBuf* e;
   const float* act_src;  // optional rider: copy [cnt][A] actions (ld A) to act_dst (ld XA)
   float* act_dst;
-  int gen_mask = 0;            // fused chain, mask == nullptr: hash the Dropout keep-mask inside the SLE kernel from mask_seed
-  uint64_t mask_seed = 0;
+  int gen_mask = 0;            // fused chain, mask == nullptr: 1 = hash the Dropout keep-mask inside the SLE kernel from mask_seed,
+  uint64_t mask_seed = 0;      // 2 = jax.random.bernoulli(tf_key[camera], keep, (tf_rows, D)) rows tf_row0.. (serl_noise key_mask_*)
+  const uint32_t* tf_key = nullptr; long tf_rows = 0, tf_row0 = 0;
 };
 int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
@@ -467,6 +468,10 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
     for (int i = 0; i < n; ++i) {
       sv[i].gen = jobs[i].gen_mask; sv[i].seed = jobs[i].mask_seed;
       sv[i].row_offset = a->shard_off + off; sv[i].rows_global = a->shard_global ? a->shard_global : Bfull;
+      if (jobs[i].gen_mask == 2) {
+        for (int k = 0; k < c.n_cam; ++k) { sv[i].tf_key[k][0] = jobs[i].tf_key[2 * k]; sv[i].tf_key[k][1] = jobs[i].tf_key[2 * k + 1]; }
+        sv[i].tf_rows = jobs[i].tf_rows; sv[i].tf_row0 = jobs[i].tf_row0;
+      }
     }
   }
   if (a->small) {   // trainable conv stack + average pool per (parameter vector, observation side); no dropout (pool "avg")
@@ -545,6 +550,7 @@ struct PolJob {
   float* alpha_out;  // optional rider: alpha = softplus(lagrange) of P (lagrange.py:49-50)
   // fused chain, eps == nullptr: the draws are hashed inside the head kernel from (eps_seed, global row) and kept in eps_out
   float* eps_out = nullptr; uint64_t eps_seed = 0; long eps_row0 = 0;
+  const uint32_t* tf_key = nullptr; long tf_rows = 0, tf_row0 = 0;   // jax.random.normal(tf_key, (tf_rows, A)) rows tf_row0.. (serl_noise key_eps_*)
 };
 int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStream_t st) {
   const serl_agent_cfg& c = a->cfg;
@@ -586,6 +592,8 @@ int policy_fwd_multi(serl_agent* a, const PolJob* jobs, int n, int cnt, hipStrea
       g.pd = pv[i];
       g.pd.sum_logp = nullptr;
       g.pd.eps_out = j.eps_out; g.pd.seed = j.eps_seed; g.pd.row_offset = j.eps_row0;
+      g.pd.tf = j.tf_key ? 1 : 0;
+      if (j.tf_key) { g.pd.tf_key[0] = j.tf_key[0]; g.pd.tf_key[1] = j.tf_key[1]; g.pd.tf_rows = j.tf_rows; g.pd.tf_row0 = j.tf_row0; }
       g.pd.B = cnt; g.pd.A = A; g.pd.std_min = c.std_min; g.pd.std_max = c.std_max;
       g.pd.slab_ld = g.ldc; g.pd.slab_stride = g.sCz;
       SERL_REQUIRE(j.eps || j.eps_out, "policy noise: neither draws nor a buffer for hashed ones");
@@ -881,20 +889,66 @@ void fetch_noise(serl_agent* a, NoiseBatch& nb, const float* given_eps, const ui
   }
 }
 
+// rows of the GLOBAL (mini)batch in front of this rank's `cnt` rows (serl_agent_set_shard: this rank owns rows shard_off.. of a
+// global batch of shard_global; a minibatch of a high-UTD update is sharded the same way)
+static long tf_row0_of(const serl_agent* a, int cnt) {
+  return a->shard_global ? (a->shard_off * (long)cnt) / std::max<long>(a->cur.batch, 1) : 0;
+}
+
+// One-launch-per-operation chain (SERL_CHAIN_FUSE=0) with jax.random KEYS instead of tensors: the draws are materialised in the
+// agent's noise buffers by serl_jax_fill (rows [off, off + cnt) of the buffers = rows tf_row0.. of the global arrays) and then
+// taken as given tensors.  *eps / *mask are replaced only where the caller gave a key and no tensor.
+int jax_noise_tensors(serl_agent* a, const uint32_t* key_eps, const uint32_t* key_mask, int slot, int off, int cnt, long global_count,
+                      hipStream_t st, const float** eps, const uint8_t** mask) {
+  const serl_agent_cfg& c = a->cfg;
+  serl_jax_job jobs[1 + SERL_MAX_CAMS];
+  int n = 0;
+  const long row0 = tf_row0_of(a, cnt);
+  if (key_eps && !*eps) {
+    serl_jax_job& j = jobs[n++];
+    j = serl_jax_job{};
+    j.key[0] = key_eps[0]; j.key[1] = key_eps[1]; j.kind = SERL_JAX_NORMAL;
+    j.n_total = global_count * c.act_dim; j.first = row0 * c.act_dim; j.count = (long)cnt * c.act_dim;
+    j.out = a->eps_buf[slot] + (long)off * c.act_dim;
+    *eps = a->eps_buf[slot];
+  }
+  if (key_mask && !*mask && !a->state_only && !a->small) {
+    for (int k = 0; k < c.n_cam; ++k) {
+      serl_jax_job& j = jobs[n++];
+      j = serl_jax_job{};
+      j.key[0] = key_mask[2 * k]; j.key[1] = key_mask[2 * k + 1]; j.kind = SERL_JAX_BERNOULLI_U8; j.p = 1.0f - c.dropout;
+      j.n_total = global_count * a->D; j.first = row0 * a->D; j.count = (long)cnt * a->D;
+      j.out = a->mask_buf[slot] + ((long)k * a->cur.batch + off) * a->D;
+    }
+    *mask = a->mask_buf[slot];
+  }
+  return n ? serl_jax_fill(c.device, jobs, n, (void*)st) : SERL_OK;
+}
+
 // Fused chain: nothing is generated ahead of time.  Missing normal draws are hashed inside the policy-head epilogue (same
 // stream as gen_noise: seed and global-row indexing unchanged) and kept in eps_buf[slot]; a missing Dropout mask is hashed
 // inside the SLE kernel.  The seeds advance exactly as fetch_noise advances them.
-struct FusedNoise { const float* eps; float* eps_out; uint64_t eps_seed; const uint8_t* mask; int gen_mask; uint64_t mask_seed; };
-FusedNoise fetch_noise_fused(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot) {
+// key_eps / key_mask (serl_noise key_*, host words; nullptr = none): jax.random keys of the draws -- used where the tensor is absent.
+struct FusedNoise {
+  const float* eps; float* eps_out; uint64_t eps_seed; const uint8_t* mask; int gen_mask; uint64_t mask_seed;
+  const uint32_t* tf_eps; const uint32_t* tf_mask;
+};
+FusedNoise fetch_noise_fused(serl_agent* a, const float* given_eps, const uint8_t* given_mask, int slot,
+                             const uint32_t* key_eps = nullptr, const uint32_t* key_mask = nullptr) {
   const serl_agent_cfg& c = a->cfg;
   FusedNoise f{};
   f.eps = given_eps;
   f.eps_out = a->eps_buf[slot];
-  if (!given_eps) f.eps_seed = c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr));
+  if (!given_eps) {
+    if (key_eps) f.tf_eps = key_eps;
+    else f.eps_seed = c.seed ^ (0xA5A5ull + 7919ull * (++a->noise_ctr));
+  }
   if (given_mask || a->state_only || a->small) f.mask = a->small ? nullptr : given_mask;
+  else if (key_mask) { f.gen_mask = 2; f.tf_mask = key_mask; }
   else { f.gen_mask = 1; f.mask_seed = c.seed ^ (0x5A5Aull + 104729ull * (++a->noise_ctr)); }
   return f;
 }
+
 
 // learning rate of optimizer `tx` at `count` (optimizers.py:14-30): warm-up -> constant, or warm-up -> cosine decay
 float lr_at(const serl_agent_cfg& c, int64_t count, int tx) {
@@ -1210,15 +1264,20 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   a->pg_defer = true;
   const int A = c.act_dim;
   if (a->fuse) {
-    const FusedNoise fz = fetch_noise_fused(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0);
+    const FusedNoise fz = fetch_noise_fused(a, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0,
+                                            noise && noise->key_eps_next ? noise->key_eps_next + 2 * redq_row : nullptr,
+                                            noise && noise->key_mask_next ? noise->key_mask_next + 2 * c.n_cam * redq_row : nullptr);
+    const long tf_row0 = tf_row0_of(a, cnt);
     EncJob ej[3] = {{a->theta, 1, fz.mask, &a->encP, nullptr, nullptr},
                     {a->theta_t, 1, nullptr, &a->encT, nullptr, nullptr},
                     {a->theta, 0, nullptr, &a->encO, a->cur.action + (long)off * A, a->crit.x + a->E}};
     ej[0].gen_mask = fz.gen_mask; ej[0].mask_seed = fz.mask_seed;
+    ej[0].tf_key = fz.tf_mask; ej[0].tf_rows = global_count; ej[0].tf_row0 = tf_row0;
     RC(encode_multi(a, ej, 3, off, cnt, st));
     PolJob pj{a->theta, &a->pol, a->encP.enc, a->encP.ld, fz.eps ? fz.eps + (long)off * A : nullptr, a->critT.x + a->E, a->XA, nullptr,
               c.backup_entropy ? a->aux + X_ALPHA : nullptr};
     pj.eps_out = fz.eps_out + (long)off * A; pj.eps_seed = fz.eps_seed; pj.eps_row0 = a->shard_off + off;
+    pj.tf_key = fz.tf_eps; pj.tf_rows = global_count; pj.tf_row0 = tf_row0;
     RC(policy_fwd_multi(a, &pj, 1, cnt, st));
     const CritJob cj[2] = {{a->theta_t, &a->critT}, {a->theta, &a->crit}};
     RC(critic_fwd_multi(a, cj, 2, cnt, st));
@@ -1239,7 +1298,12 @@ int serl_agent_critic_grads_bucketed(serl_agent* a, int off, int cnt, int global
   }
   const float* eps; const uint8_t* mask;
   NoiseBatch nb;
-  fetch_noise(a, nb, noise ? noise->eps_next : nullptr, noise ? noise->mask_next : nullptr, 0, a->cur.batch, &eps, &mask);
+  const float* g_eps = noise ? noise->eps_next : nullptr;
+  const uint8_t* g_mask = noise ? noise->mask_next : nullptr;
+  RC(jax_noise_tensors(a, noise && noise->key_eps_next ? noise->key_eps_next + 2 * redq_row : nullptr,
+                       noise && noise->key_mask_next ? noise->key_mask_next + 2 * c.n_cam * redq_row : nullptr, 0, off, cnt, global_count,
+                       st, &g_eps, &g_mask));
+  fetch_noise(a, nb, g_eps, g_mask, 0, a->cur.batch, &eps, &mask);
   RC(nb.flush(st));
   // the three encoder passes of the critic loss in one set of launches: online policy input at next_obs
   // (dropout), target-critic input at next_obs (target_params, train=False), online-critic input at obs
@@ -1285,18 +1349,25 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
   const float* eps_pi; const uint8_t* mask_pi; const float* eps_t; const uint8_t* mask_t;
   hipStream_t s0 = st;
   if (a->fuse) {
-    const FusedNoise fp = fetch_noise_fused(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1);
-    const FusedNoise ft = fetch_noise_fused(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2);
+    const FusedNoise fp = fetch_noise_fused(a, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1,
+                                            noise ? noise->key_eps_pi : nullptr, noise ? noise->key_mask_obs_pi : nullptr);
+    const FusedNoise ft = fetch_noise_fused(a, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2,
+                                            noise ? noise->key_eps_temp : nullptr, noise ? noise->key_mask_next_temp : nullptr);
+    const long tf_row0 = tf_row0_of(a, cnt);
     EncJob ej[3] = {{a->theta, 1, ft.mask, &a->encT, nullptr, nullptr},
                     {a->theta, 0, nullptr, &a->encO, nullptr, nullptr},
                     {a->theta, 0, fp.mask, &a->encP, nullptr, nullptr}};
     ej[0].gen_mask = ft.gen_mask; ej[0].mask_seed = ft.mask_seed;
     ej[2].gen_mask = fp.gen_mask; ej[2].mask_seed = fp.mask_seed;
+    ej[0].tf_key = ft.tf_mask; ej[0].tf_rows = global_count; ej[0].tf_row0 = tf_row0;
+    ej[2].tf_key = fp.tf_mask; ej[2].tf_rows = global_count; ej[2].tf_row0 = tf_row0;
     RC(encode_multi(a, ej, 3, 0, cnt, s0));
     PolJob pj[2] = {{a->theta, &a->polT, a->encT.enc, a->encT.ld, ft.eps, a->act_tmp, A, a->SC + S_LOGP_NEXT, a->aux + X_ALPHA},
                     {a->theta, &a->pol, a->encP.enc, a->encP.ld, fp.eps, a->crit.x + a->E, a->XA, a->SC + S_LOGP, nullptr}};
     pj[0].eps_out = ft.eps_out; pj[0].eps_seed = ft.eps_seed; pj[0].eps_row0 = a->shard_off;
     pj[1].eps_out = fp.eps_out; pj[1].eps_seed = fp.eps_seed; pj[1].eps_row0 = a->shard_off;
+    pj[0].tf_key = ft.tf_eps; pj[0].tf_rows = global_count; pj[0].tf_row0 = tf_row0;
+    pj[1].tf_key = fp.tf_eps; pj[1].tf_rows = global_count; pj[1].tf_row0 = tf_row0;
     RC(policy_fwd_multi(a, pj, 2, cnt, s0));
     eps_pi = fp.eps ? fp.eps : fp.eps_out;   // (the backward reads the draws the head epilogue used)
     const CritJob cj{a->theta, &a->crit};
@@ -1330,8 +1401,14 @@ int serl_agent_actor_grads(serl_agent* a, int global_count, const serl_noise* no
     return SERL_OK;
   }
   NoiseBatch nb;
-  fetch_noise(a, nb, noise ? noise->eps_pi : nullptr, noise ? noise->mask_obs_pi : nullptr, 1, cnt, &eps_pi, &mask_pi);
-  fetch_noise(a, nb, noise ? noise->eps_temp : nullptr, noise ? noise->mask_next_temp : nullptr, 2, cnt, &eps_t, &mask_t);
+  const float* g_eps_pi = noise ? noise->eps_pi : nullptr; const uint8_t* g_mask_pi = noise ? noise->mask_obs_pi : nullptr;
+  const float* g_eps_t = noise ? noise->eps_temp : nullptr; const uint8_t* g_mask_t = noise ? noise->mask_next_temp : nullptr;
+  RC(jax_noise_tensors(a, noise ? noise->key_eps_pi : nullptr, noise ? noise->key_mask_obs_pi : nullptr, 1, 0, cnt, global_count, st,
+                       &g_eps_pi, &g_mask_pi));
+  RC(jax_noise_tensors(a, noise ? noise->key_eps_temp : nullptr, noise ? noise->key_mask_next_temp : nullptr, 2, 0, cnt, global_count, st,
+                       &g_eps_t, &g_mask_t));
+  fetch_noise(a, nb, g_eps_pi, g_mask_pi, 1, cnt, &eps_pi, &mask_pi);
+  fetch_noise(a, nb, g_eps_t, g_mask_t, 2, cnt, &eps_t, &mask_t);
   RC(nb.flush(st));
   // encoder passes of the actor step in one set of launches: temperature loss input (next_obs, dropout;
   // sac.py:223-234), critic-side encoding of obs (train=False), policy input at obs (dropout; sac.py:193-221)

@@ -61,7 +61,9 @@ int colsum3(const float* dg, const float* xhat, const float* dpre, int groups, i
 struct SleFwdArgs {
   const float* x; const float* K; const uint8_t* mask; float* f;
   // sle_proprio_fwd only: mask == nullptr && gen -> Dropout keep-mask hashed from (seed, camera, GLOBAL row, channel)
+  // gen == 2: jax.random.bernoulli(tf_key[camera], keep, (tf_rows, channels * 8))[tf_row0 + row][...] instead of the hash (jaxrng.h)
   int gen; uint64_t seed; long row_offset, rows_global;
+  uint32_t tf_key[4][2]; long tf_rows, tf_row0;
 };
 // SpatialLearnedEmbeddings channel-blocked (a workgroup = 256 channels x 8 samples: the kernel K is read once per workgroup,
 // not once per sample) + inline Dropout mask + the proprio branch as extra workgroups of the same launch (pv == nullptr: none)

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "heads.h"
+#include "jaxrng.h"
 #include "prof.h"
 
 namespace serl {
@@ -259,7 +260,12 @@ __device__ __forceinline__ void policy_dist_rows(const PolicyDistArgs& v, int r0
     }
     float ep;
     if (v.eps) ep = v.eps[(long)b * A + j];
-    else { ep = hash_normal(v.seed, (uint64_t)(v.row_offset + b) * (uint64_t)A + (uint64_t)j); v.eps_out[(long)b * A + j] = ep; }
+    else {
+      ep = v.tf ? normal_from_bits(random_bits_at(v.tf_key[0], v.tf_key[1], (uint64_t)v.tf_rows * (uint64_t)A,
+                                                 (uint64_t)(v.tf_row0 + b) * (uint64_t)A + (uint64_t)j))
+                : hash_normal(v.seed, (uint64_t)(v.row_offset + b) * (uint64_t)A + (uint64_t)j);
+      v.eps_out[(long)b * A + j] = ep;
+    }
     v.pre[(long)b * A + j] = mean;
     v.pre[((long)B + b) * A + j] = ls;
     const float sd = fminf(fmaxf(expf(ls), v.std_min), v.std_max);
@@ -1230,7 +1236,7 @@ __device__ __forceinline__ void proprio_row(const ProprioArgs& a, int S, int row
 // in flight (96 workgroups of 8 samples each took 64 us next to the trunk pass at 32 samples)
 template <int kSleNb>
 __global__ __launch_bounds__(256) void sle_proprio_fwd_kernel(Multi<SleFwdArgs> mv, Multi<ProprioArgs> pv, int has_proprio,
-                                                              float keep_scale, unsigned keep_thr, int N, int HW, int Cc,
+                                                              float keep_scale, unsigned keep_thr, float keep_p, int N, int HW, int Cc,
                                                               long xs, long ks, long ms, long fs, int S, int nb_sle) {
   if ((int)blockIdx.x >= nb_sle) {
     if (!has_proprio || blockIdx.y != 0) return;
@@ -1285,6 +1291,13 @@ __global__ __launch_bounds__(256) void sle_proprio_fwd_kernel(Multi<SleFwdArgs> 
       const uint8_t* m = mask + (long)s * Cc * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[s][j] = m[j] ? acc[s][j] * keep_scale : 0.f;
+    } else if (v.gen == 2) {   // jax.random.bernoulli(key of this camera, keep, (rows, Cc * 8)): element (row, c * 8 + j)
+      const uint32_t k0 = v.tf_key[blockIdx.y][0], k1 = v.tf_key[blockIdx.y][1];
+      const uint64_t rowlen = (uint64_t)Cc * 8ull, total = (uint64_t)v.tf_rows * rowlen;
+      const uint64_t e0 = (uint64_t)(v.tf_row0 + n0 + s) * rowlen + (uint64_t)c * 8ull;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[s][j] = bits_to_unit(random_bits_at(k0, k1, total, e0 + (uint64_t)j)) < keep_p ? acc[s][j] * keep_scale : 0.f;
     } else if (v.gen) {
       const uint64_t ctr = (((uint64_t)blockIdx.y * (uint64_t)v.rows_global + (uint64_t)(v.row_offset + n0 + s)) * (uint64_t)Cc + (uint64_t)c) * 3ull;
       const uint64_t h0 = mix64(v.seed ^ mix64(ctr)), h1 = mix64(v.seed ^ mix64(ctr + 1)), h2 = mix64(v.seed ^ mix64(ctr + 2));
@@ -1312,10 +1325,10 @@ int sle_proprio_fwd_multi(const SleFwdArgs* vs, const ProprioArgs* ps, int n, fl
   const int nb_sle = cdiv(Cc, 256) * cdiv(N, nb), nb_prop = ps ? cdiv(N, 4) : 0;
   if (nb == 2)
     SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel<2>, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
-                      1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
+                      1.0f / keep, (unsigned)(keep * 16777216.0f), keep, N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
   else
     SERL_LAUNCH_CHAIN(sle_proprio_fwd_kernel<8>, dim3(nb_sle + nb_prop, groups, n), dim3(256), 0, stream, mv, pv, ps ? 1 : 0,
-                      1.0f / keep, (unsigned)(keep * 16777216.0f), N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
+                      1.0f / keep, (unsigned)(keep * 16777216.0f), keep, N, HW, Cc, x_gs, k_gs, mask_gs, f_gs, state_dim, nb_sle);
   SERL_HIP(hipGetLastError());
   return SERL_OK;
 }

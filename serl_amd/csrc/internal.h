@@ -103,6 +103,8 @@ struct PolicyDistArgs {
   // fused form only (GemmDesc::epi == kEpiPolicy): eps == nullptr -> N(0,1) draws hashed from (seed, global row, j), kept in eps_out
   float* eps_out; uint64_t seed; long row_offset;
   int B, A; float std_min, std_max; long slab_ld, slab_stride;
+  // tf != 0 (and eps == nullptr): the draws are jax.random.normal(tf_key, (tf_rows, A))[tf_row0 + b][j] instead of the hash (jaxrng.h)
+  int tf; uint32_t tf_key[2]; long tf_rows, tf_row0;
 };
 
 // Epilogues of the update chain's GEMMs ("last-arriver" fusion, heads.hip): a launch boundary between a K-split GEMM and the

@@ -155,6 +155,7 @@ class DataParallelLearner:
         assert device_noise in ("hash", "threefry")
         self.device_noise = device_noise if (self.image_keys is not None and hasattr(core, "cfg")) else "hash"
         self._nbuf = None
+        self.noise_form = "keys"     # "keys": drawn inside the consuming kernels; "tensors": one serl_jax_fill launch per update
         self.last_draws = {}
         self._gv = {}
         self._pending = None   # slot of the prefetched (sampled + gathered + encoded) batch
@@ -235,6 +236,19 @@ class DataParallelLearner:
             self.last_draws["redq_idx"] = noise["redq_idx"]
         if self.device_noise != "threefry":
             return noise if critic else None
+        if self.noise_form == "keys":      # the kernels draw this rank's rows of the global arrays themselves (serl_agent_set_shard)
+            c = self.core.cfg
+            n_cam = c.n_cam if c.encoder_type == 0 else 0
+            cam = lambda k: np.stack([J.flax_make_rng(k, J.dropout_path(x), 1) for x in self.image_keys[:n_cam]])  # noqa: E731
+            if critic:
+                noise["key_eps_next"] = keys.k_next_action[0]
+                if n_cam:
+                    noise["key_mask_next"] = cam(keys.k_next_action[0])
+            else:
+                noise["key_eps_pi"], noise["key_eps_temp"] = keys.k_sample, keys.k_temp
+                if n_cam:
+                    noise["key_mask_obs_pi"], noise["key_mask_next_temp"] = cam(keys.k_policy), cam(keys.k_temp)
+            return noise
         import torch
         c = self.core.cfg
         A, D, Bl, B, lo = c.act_dim, 512 * c.sle_features, self.Bl, self.B, self.rank * self.Bl

@@ -255,3 +255,46 @@ def test_zero_learning_rate_is_honoured(gpu):
     assert np.array_equal(agent.core.get("params", "temp/lagrange"), lam0)
     assert not np.array_equal(agent.core.get("params", "actor/w2"), w0)
     assert float(agent.state.opt_states["temperature"]["hyperparams"]["learning_rate"]) == 0.0
+
+
+@pytest.mark.parametrize("chain_fuse", ["1", "0"])
+def test_draws_inside_the_kernels_equal_the_materialised_draws(gpu, monkeypatch, chain_fuse):
+    """The reference's random stream reaches the kernels as KEYS by default (serl_noise key_*: Dropout masks drawn in the
+    SpatialLearnedEmbeddings kernel, normals in the policy-head epilogue -- csrc/heads.hip through csrc/jaxrng.h) or, with
+    agent.noise_form = "tensors", as tensors filled by one serl_jax_fill launch (bit-exact against the oracle's jax.random in
+    tests/test_jaxrng.py).  Same keys, same elements of the same arrays: parameters and info must agree TO THE BIT, for minibatch
+    windows of a UTD = 2 update too, on the fused chain and on the one-launch-per-operation chain (which materialises key draws
+    itself: agent.hip jax_noise_tensors)."""
+    import numpy as np
+    import torch
+    from serl_amd.utils.launcher import make_drq_agent
+    monkeypatch.setenv("SERL_CHAIN_FUSE", chain_fuse)
+    keys_, H, S, A, B = ("front", "wrist"), 64, 5, 3, 8
+    obs0 = {k: np.zeros((1, H, H, 3), np.uint8) for k in keys_}
+    obs0["state"] = np.zeros((1, S), np.float32)
+    rng = np.random.default_rng(0)
+
+    def batch():
+        t = lambda a: torch.tensor(a, device="cuda")  # noqa: E731
+        obs = {k: t(rng.integers(0, 256, (B, 2, H, H, 3), dtype=np.uint8)) for k in keys_}
+        obs["state"] = t(rng.standard_normal((B, 1, S)).astype(np.float32))
+        return {"observations": obs, "next_observations": {"state": t(rng.standard_normal((B, 1, S)).astype(np.float32))},
+                "actions": t(rng.uniform(-1, 1, (B, A)).astype(np.float32)), "rewards": t((rng.random(B) < 0.3).astype(np.float32)),
+                "masks": t((rng.random(B) < 0.9).astype(np.float32))}
+
+    batches = [batch() for _ in range(3)]
+    out = []
+    for form in ("keys", "tensors"):
+        agent = make_drq_agent(5, obs0, np.zeros((A,), np.float32), image_keys=keys_, encoder_type="resnet-pretrained", batch_size=B)
+        agent.noise_form = form
+        infos = []
+        agent, info = agent.update_critics(batches[0]); infos.append(dict(info["critic"]))
+        agent, info = agent.update_high_utd(batches[1], utd_ratio=2); infos.append({**info["critic"], **info["actor"], **info["temperature"]})
+        agent, info = agent.update(batches[2]); infos.append({**info["critic"], **info["actor"], **info["temperature"]})
+        torch.cuda.synchronize()
+        out.append((infos, {k: agent.core.get("params", k) for k in ("critic/w1", "actor/w2", "enc/0/dense/kernel", "enc/1/sle", "temp/lagrange")},
+                    [int(v) for v in agent.state.rng]))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert out[0][2] == out[1][2]
+    for k in out[0][1]:
+        assert np.array_equal(out[0][1][k].view(np.uint32), out[1][1][k].view(np.uint32)), k
