@@ -272,7 +272,7 @@ def main():
             send = lambda t, dst, tag: dist.isend(t, dst)       # noqa: E731  (RCCL point to point; tags are not used by the backend)
             recv = lambda t, src, tag: dist.irecv(t, src)       # noqa: E731
         learner = TrunkFarmLearner(core, gather, rbs, [b[3] for b in bufspec], rank, world, send=send, recv=recv, seed=7,
-                                   schedule=sched, image_keys=KEYS, device_noise=args.noise, role=args.farm_role)
+                                   schedule=sched, image_keys=KEYS, device_noise=args.noise, role=args.farm_role, chain_budget=1024)
     else:
         learner = DataParallelLearner(core, gather, rbs, [b[3] for b in bufspec], rank, emu if emu else world,
                                       all_reduce=all_reduce, seed=7, schedule=sched, overlap_reduce=args.overlap_reduce == "on",

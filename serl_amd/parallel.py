@@ -354,7 +354,7 @@ class TrunkFarmLearner(DataParallelLearner):
     (bench.py --farm-role: the pieces of the projection are measured one at a time)."""
 
     def __init__(self, core, gather, buffers, batch_sizes, rank=0, world=2, send=None, recv=None, seed=0, ensemble=10,
-                 schedule=None, image_keys=None, device_noise="hash", role=None, n_workers=None):
+                 schedule=None, image_keys=None, device_noise="hash", role=None, n_workers=None, chain_budget=None):
         super().__init__(core, gather, buffers, batch_sizes, 0, 1, all_reduce=None, seed=seed, ensemble=ensemble,
                          schedule=schedule, image_keys=image_keys, device_noise=device_noise)
         assert world >= 2 or role is not None, "a trunk farm needs an updater and at least one worker"
@@ -363,9 +363,11 @@ class TrunkFarmLearner(DataParallelLearner):
         self.n_workers = n_workers if n_workers is not None else max(world - 1, 1)
         self.send, self.recv = send, recv
         if self.role == "updater" and hasattr(core, "set_chain_budget"):
-            # nothing co-runs with the update chain on this rank: deeper K-splits pay (same call, updater alone:
-            # 512 -> 0.7406, 1024 -> 0.7054, 2048 -> 0.7099, 4096 -> 0.7236 ms per step; profiles/r05_scaling_pieces.txt)
-            core.set_chain_budget(1024)
+            # chain_budget: K-split budget of the update chain's GEMMs on the updater (None = the library default, 512: results
+            # bit-identical to a single-GPU learner that runs with the same budget -- the K-split depth fixes the fp32 summation
+            # order).  Nothing co-runs with the chain on this rank, so deeper splits pay: same call, updater alone, 512 -> 0.7406,
+            # 1024 -> 0.7054, 2048 -> 0.7099, 4096 -> 0.7236 ms per step (profiles/r05_scaling_pieces.txt); bench.py passes 1024.
+            core.set_chain_budget(0 if chain_budget is None else int(chain_budget))
         self._t = 0                  # global batch counter (identical on every rank)
         self._recv_pending = {}      # slot -> handle
 

@@ -133,6 +133,11 @@ def test_fused_chain_hand_off_survives_2000_steps_under_load(gpu):
         for core in (fused, plain, loader):
             core.encode_slot(batches[0], 0)
             core.select_slot(0)
+        # an agent's trunk workspace is not re-entrant: `loader` runs its next passes on side[0], which is not ordered behind the
+        # default stream -- without this wait its first pass there could overlap the encode_slot above (two passes of ONE agent
+        # sharing statistics, arrival counters and tile tickets: an intermittent device trap in the first process of a fresh box,
+        # round 5)
+        torch.cuda.synchronize()
         for it in range(n_steps):
             k = it % 3
             # load: the third agent's whole update (trunk + chain) on one stream, a bare trunk pass on another
