@@ -412,7 +412,7 @@ def main():
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     # HBM bytes per launch of the family from the PMC counters.  NOT measured by this process: rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE passes (scripts/collect_evidence.sh, serial schedule, possibly another box) leave them in profiles/pmc_traffic.json;
-    # `traffic_source` says so in the line.  The rocprof-derived fraction (profiles/r04_frac_from_stats.txt) rides along the same way.
+    # `traffic_source` says so in the line.  The rocprof-derived fraction (profiles/r05_frac_from_stats.txt) rides along the same way.
     traffic, traffic_source, frac_rocprof = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -423,10 +423,10 @@ def main():
             traffic = None
     try:
         import re as _re
-        txt = open(os.path.join(ROOT, "profiles", "r04_frac_from_stats.txt")).read()
+        txt = open(os.path.join(ROOT, "profiles", "r05_frac_from_stats.txt")).read()
         vals = [float(m) for m in _re.findall(r"frac ([0-9.]+)", txt)]     # line 1: pipelined schedule, line 2: serial
         frac_rocprof = dict(zip(("pipelined", "serial"), vals))
-        frac_rocprof["source"] = "profiles/r04_frac_from_stats.txt (rocprofv3 --kernel-trace --stats CSVs, scripts/frac_from_stats.py), not this run"
+        frac_rocprof["source"] = "profiles/r05_frac_from_stats.txt (rocprofv3 --kernel-trace --stats CSVs, scripts/frac_from_stats.py), not this run"
     except Exception:
         frac_rocprof = None
     n_launch = max(1, sum(c for t, (m, c) in prof.items() if t.startswith("conv_igemm")))

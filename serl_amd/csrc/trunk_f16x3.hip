@@ -78,7 +78,7 @@ struct ConvArgsB {
   int stagger;
 };
 
-// LDS-DMA kernel, OPT-IN (SERL_PROJ_FUSE=1): the block's 1x1 stride-2 projection computed by the SAME workgroup in front of its
+// LDS-DMA kernel, default since round 5 (SERL_PROJ_FUSE=0 switches it off): the block's 1x1 stride-2 projection computed by the SAME workgroup in front of its
 // 3x3 stride-2 conv0 tile (same input, same output tile: the projection's pixel is conv0's tap (0, 0)).  A separate kernel
 // parameter behind the existing ones, and a separate instantiation (PROJ): the kernels without it keep their code and their
 // argument offsets.
