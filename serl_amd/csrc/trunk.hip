@@ -554,7 +554,7 @@ static void conv_dims(int i, int which, int& K, int& Cout) {
 static bool slab_copy(int i, int which) { return which != 2 && kStageFilters[i] <= 128 && (which == 1 || kStageStride[i] == 1); }
 
 // layers the LDS-DMA kernel may take (at least 128 output channels, K a multiple of 32)
-static bool dma_copy(int i, int which) { (void)which; return kStageFilters[i] >= 128; }
+static bool dma_copy(int i, int which) { return kStageFilters[i] >= 128 || (i == 0 && which <= 1); }   // (+ block 0: the row-slab kernels' LDS-DMA weight / operand staging)
 
 size_t trunk_packed_bytes() {
   size_t off = 0;

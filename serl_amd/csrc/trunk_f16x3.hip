@@ -988,7 +988,10 @@ constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (6
 // the hi / lo' split are applied while a slab is staged (a.in_gn: per-channel scale / shift of this tile's image, held in
 // LDS) -- the elementwise pass that would materialise the split8 tensor (read 268 MB + write 268 MB per trunk pass) is gone.
 // A thread then stages one (pixel, k-half) = 8 channels per slab part: two 16-byte fp32 loads in, one hi and one lo' unit out.
-template <bool RAWIN>
+// WDMA (round 5): the WEIGHTS of a sub-chunk arrive by LDS-DMA in the LDS-DMA kernels' piece order (4 KB per tap, swizzled
+// [cout][64 B]: see conv3x3_slabdma_f16x3_kernel) one sub-chunk ahead -- three of a thread's five staging loads, their registers
+// and their ds_write_b128 disappear; the activations keep the register path (RAWIN applies GroupNorm + ReLU + split on the way).
+template <bool RAWIN, bool WDMA = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
@@ -1060,8 +1063,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 #define SERL_RS_LOAD_A(RA, PART, CG)                                                               \
   _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                   \
     RA[j] = *reinterpret_cast<const u32x4*>(a.in + rbase[PART][j] + ((CG) << 4));
-#define SERL_RS_LOAD_B(RB, BG, BKY)                                                                \
+#define SERL_RS_DMA_B(BG, BKY, BBUF)                                                               \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(wdsrc + ((size_t)(((BKY) * 3 + kx) * c16n + (BG)) << 12)), \
+                                     (lds_void_t*)(smB + (BBUF) * B_BYTES + kx * 4096 + (tid >> 6) * 1024), 16, 0, 0);
+#define SERL_RS_LOAD_B(RB, BG, BKY)                                                                \
+  if (!WDMA) _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                      \
     RB[kx] = wslab ? *reinterpret_cast<const u32x4*>(wslab + ((size_t)(((BG) * 3 + (BKY)) * 3 + kx) << 11)) \
                    : *reinterpret_cast<const u32x4*>(wrow + ((BKY) * 3 + kx) * a.Cin + ((BG) << 4));
 #define SERL_RS_STORE_A(RA, PART, ABUF, CGN)                                                       \
@@ -1094,7 +1101,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
       *reinterpret_cast<u32x4*>(smA + (ABUF) * A_BYTES + (u_ & 3) * A_REGION + (u_ >> 2) * 16) = v; \
   }
 #define SERL_RS_STORE_B(RB, BBUF)                                                                  \
-  _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                 \
+  if (!WDMA) _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                      \
     *reinterpret_cast<u32x4*>(smB + (BBUF) * B_BYTES + kx * B_TAP + b_plane * B_PLANE + b_half * B_HALF + b_cout * 16) = RB[kx];
 // what is fetched while sub-chunk (CG, KY) computes: the weights of the NEXT sub-chunk and part KY of the NEXT slab (the
 // last slab re-fetches itself: harmless, keeps the loop uniform) -- and where it goes when that sub-chunk is done
@@ -1103,6 +1110,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
     const int ncg_ = (KY) == 2 ? (CG) + 1 : (CG), nky_ = (KY) == 2 ? 0 : (KY) + 1;                 \
     const int ncgc_ = min(ncg_, c16n - 1), sn_ = min((CG) + 1, c16n - 1);                          \
     SERL_RS_LOAD_B(RB, ncgc_, nky_);                                                               \
+    if (WDMA) { SERL_RS_DMA_B(ncgc_, nky_, ((CG) * 3 + (KY) + 1) & 1) }                             \
     if ((KY) == 0) { SERL_RS_LOAD_A(RA, 0, sn_); } else if ((KY) == 1) { SERL_RS_LOAD_A(RA, 1, sn_); } else { SERL_RS_LOAD_A(RA, 2, sn_); } \
   }
 #define SERL_RS_STORES(C, CG, KY, RA, RB)                                                          \
@@ -1123,8 +1131,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
         alo[tm] = *reinterpret_cast<const f16x8*>(sa + A_REGION + arow[tm] + kx * 16);             \
       }                                                                                            \
       _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                          \
-        bhi[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + tn * 32 * 16);          \
-        blo[tn] = *reinterpret_cast<const f16x8*>(sb + boff + kx * B_TAP + B_PLANE + tn * 32 * 16); \
+        bhi[tn] = *reinterpret_cast<const f16x8*>(WDMA ? sb + kx * 4096 + wd_bhi[tn] : sb + boff + kx * B_TAP + tn * 32 * 16);          \
+        blo[tn] = *reinterpret_cast<const f16x8*>(WDMA ? sb + kx * 4096 + wd_blo[tn] : sb + boff + kx * B_TAP + B_PLANE + tn * 32 * 16); \
       }                                                                                            \
       _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                            \
         _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                        \
@@ -1152,7 +1160,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
     arow[tm] = 2 * lh * A_REGION + (y * pw + x) * 16;
   }
   const int boff = lh * B_HALF + li * 16;
+  int wd_bhi[TN], wd_blo[TN];   // WDMA: swizzled [cout][64 B] image of a tap's weights
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int row = tn * 32 + li, sw = (row >> 2) & 3;
+    wd_bhi[tn] = row * 64 + ((lh ^ sw) << 4);
+    wd_blo[tn] = row * 64 + (((2 + lh) ^ sw) << 4);
+  }
+  const uint8_t* wdsrc = reinterpret_cast<const uint8_t*>(ab.wdma) + (size_t)(n0 >> 6) * (9 * c16n) * 4096 + (tid >> 6) * 1024 + lane * 16;
   // prologue: slab 0 (three parts) and the weights of sub-chunk 0
+  if (WDMA) { SERL_RS_DMA_B(0, 0, 0) }
   SERL_RS_LOAD_B(rb, 0, 0);
 #pragma unroll
   for (int part = 0; part < 3; ++part) {
@@ -1173,11 +1190,151 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   }
 #undef SERL_RS_LOAD_A
 #undef SERL_RS_LOAD_B
+#undef SERL_RS_DMA_B
 #undef SERL_RS_STORE_A
 #undef SERL_RS_STORE_B
 #undef SERL_RS_LOADS
 #undef SERL_RS_STORES
 #undef SERL_RS_COMPUTE
+  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-slab kernel with LDS-DMA staging (round 5; default, SERL_SLAB_DMA=0 = the register-staged kernel): the tile geometry, the K order (16-channel
+// groups, per group three sub-chunks = kernel rows, three taps each) and the epilogue of conv3x3_rowslab_f16x3_kernel, but the
+// operands go HBM / L2 -> LDS by global_load_lds_dwordx4 as in the ring kernel -- no staging registers, no ds_write pass, no
+// per-unit zeroing selects.  Input must be split8 (no RAWIN: GroupNorm cannot be applied by a DMA).
+//   * slab image: [pixel][64 B] = the four 16-byte units of a 16-channel group (hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15), slot
+//     s of pixel (sy, sx) holding unit s ^ ((sx >> 2) & 3).  A swizzle by the COLUMN only: a tap shifts (sy, sx) by (ky, kx), so a
+//     lane's offsets for the three kernel rows differ by a constant and only depend on kx.  Conflict-free ds_read_b128 for every
+//     tap when a slab row starts on a multiple of four pixels or the map is 32 wide: pitch 34 (Wo = 32), 20 (Wo = 16, two pad
+//     pixels per row) -- checked by enumeration over the hardware's 16-lane groups (profiles/README.md round 5).
+//   * a DMA piece = 16 pixels x 4 slots, lane l fetching unit (l & 3) ^ ((sx >> 2) & 3) of pixel 16 p + (l >> 2) (source-side
+//     swizzle); pixels outside the image / the slab fetch a zero page.  23 pieces per slab, wave w takes pieces w, w + 4, ...;
+//     two per sub-chunk, into the slab buffer of the NEXT channel group;
+//   * weights: the LDS-DMA kernel's piece order (pack_dma_order_kernel: 4 KB per (64 couts, 16-wide K slot), swizzle baked in),
+//     slot (tap, cg) = tap * Cin / 16 + cg; a sub-chunk's three taps = 12 pieces, three per wave, one sub-chunk ahead.
+// One barrier per sub-chunk (36 MFMAs per wave), every DMA waited for with vmcnt(0) a whole sub-chunk after its issue.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSdPieces = 23;                          // 368 pixels >= 18 x 20 (Wo = 16) and >= 10 x 34 (Wo = 32)
+constexpr int kSdSlab = kSdPieces * 1024, kSdW = 3 * 4096;
+constexpr int kSlabDmaLds = 2 * kSdSlab + 2 * kSdW;    // 71,680 B: two workgroups per CU leave 16 KB for a chain GEMM workgroup
+
+__global__ __launch_bounds__(256, 2) void conv3x3_slabdma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
+  const ConvArgs& a = ab.c;
+  constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
+  uint8_t* const smS = smemb;
+  uint8_t* const smW = smemb + 2 * kSdSlab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (ab.stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)   // anti-phase start, see conv3x3_rowslab_f16x3_kernel
+    for (int i = 0; i < ab.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
+  const int bn = id % a.tiles_n, bm = id / a.tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int n_img = m0 / a.P, oy0 = (m0 - n_img * a.P) / a.Wo;
+  const int pw = a.Wo == 32 ? 34 : 20;
+  const int srows = BM / a.Wo + 2;
+  const int c16n = a.Cin >> 4, nchunks = 3 * c16n, nslots = 9 * c16n;
+  const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(a.in);
+  const uint8_t* zp = zero_page + (lane & 3) * 16;
+  unsigned sbase[6], sok = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pp = 16 * (wave + 4 * j) + (lane >> 2);
+    const int sy = pp / pw, sx = pp - sy * pw;
+    const int iy = oy0 - 1 + sy, ix = sx - 1;
+    const bool ok = sy < srows && sx < a.Wo + 2 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+    const int u = (lane & 3) ^ ((sx >> 2) & 3);
+    sbase[j] = ok ? (unsigned)((((long)(n_img * a.Hi + iy) * a.Wi + ix) * a.Cin) * 4 + u * 16) : 0u;
+    sok |= (ok ? 1u : 0u) << j;
+  }
+  const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(ab.wdma) + (size_t)(n0 >> 6) * nslots * 4096 + wave * 1024 + lane * 16;
+#define SERL_SD_SLAB(J, CG, SB)                                                                                       \
+  if (wave + 4 * (J) < kSdPieces) {                                                                                   \
+    const uint8_t* src_ = ((sok >> (J)) & 1u) ? in_bytes + (size_t)sbase[J] + ((CG) << 6) : zp;                       \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src_, (lds_void_t*)(smS + (SB) * kSdSlab + (wave + 4 * (J)) * 1024), 16, 0, 0); \
+  }
+#define SERL_SD_W1(CG, KY, WB, KX)                                                                                    \
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(wsrc + ((size_t)(((KY) * 3 + (KX)) * c16n + (CG)) << 12)),        \
+                                     (lds_void_t*)(smW + (WB) * kSdW + (KX) * 4096 + wave * 1024), 16, 0, 0);
+#define SERL_SD_W(CG, KY, WB) { SERL_SD_W1(CG, KY, WB, 0) SERL_SD_W1(CG, KY, WB, 1) SERL_SD_W1(CG, KY, WB, 2) }
+  f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accx[tm][tn][r] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  int ahi[TM][3], alo[TM][3];   // LDS byte offsets of this lane's pixel at kernel row 0, per tap column
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wave * WROWS + tm * 32 + li;
+    const int y = r / a.Wo, x = r - y * a.Wo;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int f = ((x + kx) >> 2) & 3, pa = y * pw + x + kx;
+      ahi[tm][kx] = pa * 64 + (((2 * lh) ^ f) << 4);
+      alo[tm][kx] = pa * 64 + (((2 * lh + 1) ^ f) << 4);
+    }
+  }
+  int bhi[TN], blo[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int row = tn * 32 + li, sw = (row >> 2) & 3;
+    bhi[tn] = row * 64 + ((lh ^ sw) << 4);
+    blo[tn] = row * 64 + (((2 + lh) ^ sw) << 4);
+  }
+  // prologue: the whole slab of channel group 0 and the weights of sub-chunk (0, 0)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) SERL_SD_SLAB(j, 0, 0)
+  SERL_SD_W(0, 0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  int cg = 0, ky = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    // in flight under this sub-chunk's MFMAs: the weights of the next sub-chunk, two pieces of the next group's slab
+    const int ncg = ky == 2 ? cg + 1 : cg, nky = ky == 2 ? 0 : ky + 1;
+    const int ncgc = min(ncg, c16n - 1), sn = min(cg + 1, c16n - 1);
+    // (all five pieces up front: one piece behind the first MFMA of each tile group -- the ring kernel's placement -- was measured
+    //  SLOWER here, 2.382 / 2.375 -> 2.405 / 2.400 ms per step: the late pieces have too few MFMAs left to land behind)
+    SERL_SD_W(ncgc, nky, (c + 1) & 1)
+    if (ky == 0) { SERL_SD_SLAB(0, sn, (cg + 1) & 1) SERL_SD_SLAB(1, sn, (cg + 1) & 1) }
+    else if (ky == 1) { SERL_SD_SLAB(2, sn, (cg + 1) & 1) SERL_SD_SLAB(3, sn, (cg + 1) & 1) }
+    else { SERL_SD_SLAB(4, sn, (cg + 1) & 1) SERL_SD_SLAB(5, sn, (cg + 1) & 1) }
+    const uint8_t* sa = smS + (cg & 1) * kSdSlab + ky * pw * 64;
+    const uint8_t* sb = smW + (c & 1) * kSdW;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      f16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        fah[tm] = *reinterpret_cast<const f16x8*>(sa + ahi[tm][kx]);
+        fal[tm] = *reinterpret_cast<const f16x8*>(sa + alo[tm][kx]);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        fbh[tn] = *reinterpret_cast<const f16x8*>(sb + kx * 4096 + bhi[tn]);
+        fbl[tn] = *reinterpret_cast<const f16x8*>(sb + kx * 4096 + blo[tn]);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[tm], fbh[tn], accx[tm][tn], 0, 0, 0);
+          accx[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbl[tn], accx[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    // every DMA issued above has had 36 MFMAs to land; the reads of this sub-chunk are done before anybody refills its buffers
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (++ky == 3) { ky = 0; ++cg; }
+  }
+#undef SERL_SD_SLAB
+#undef SERL_SD_W
   rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
 }
 
@@ -1997,7 +2154,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     // LDS-DMA kernel: everything else with at least 512 128-row tiles (32-bit byte offsets into the input)
     const bool dma_ok = (cfg == 0 || cfg == 4) && Cin % 32 == 0 && zero_page != nullptr && w.dma != nullptr &&
                         (long)N * Hi * Wi * Cin * 4 < (1L << 32);
-    bool fused = false;
+    bool fused = false, slab_dma_used = false;
     auto can_wait = [&](int G) { return fused_can_wait(stream, G); };
     if (slab_ok) {
       a.tiles_m = a.M / 256; a.tiles_n = Cout / 64;
@@ -2008,9 +2165,22 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       // step 2.5762 / 2.5747 -> 2.5523 / 2.5489 ms with 5; 3 and 8 (a quarter / three quarters of a tile) gave nothing
       static const int rs_stagger = []() { const char* e = getenv("SERL_RS_STAGGER"); return e ? atoi(e) : 5; }();
       ab.stagger = (fused && a.tiles_m * a.tiles_n >= 1024) ? rs_stagger : 0;
+      // (read per launch: the test flips it inside one process)
+      const char* sd_e = getenv("SERL_SLAB_DMA");
+      // LDS-DMA staging (default since round 5: pipelined step 2.432 / 2.418 -> 2.372 / 2.371 ms, serial 2.814 -> 2.770, same call):
+      // conv3x3_slabdma_f16x3_kernel for split8 inputs (b0_conv1, b1_conv1), weights by DMA for the raw-input kernel (b0_conv0)
+      const bool sd_on = !(sd_e && sd_e[0] == '0');
+      const bool slab_dma = sd_on && !raw_in && w.dma != nullptr && zero_page != nullptr && (long)N * Hi * Wi * Cin * 4 < (1L << 32);
       if (raw_in) {
         a.in = raw_in->raw; a.in_gn = raw_in->gn;
+        if (sd_on && w.dma != nullptr) {
+          hipLaunchKernelGGL((conv3x3_rowslab_f16x3_kernel<true, true>), dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+          slab_dma_used = true;
+        } else
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+      } else if (slab_dma) {
+        hipLaunchKernelGGL(conv3x3_slabdma_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kSlabDmaLds, stream, ab, zero_page);
+        slab_dma_used = true;
       } else {
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       }
@@ -2080,7 +2250,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
     if (fuse && !fused) fuse->mode = 0;
     if (plan) {
       plan->kern = slab_ok ? 'S' : (dma_ok ? 'D' : 'R');
-      plan->cfg = cfg; plan->pmode = pmode;
+      plan->cfg = slab_dma_used ? 9 : cfg; plan->pmode = pmode;   // (tile-config 9 = the row-slab kernel with LDS-DMA staging)
       plan->fused = fused ? (ab.fz.expected == 0 ? 2 : 1) : 0;
     }
   }

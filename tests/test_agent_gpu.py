@@ -78,6 +78,35 @@ def test_fused_projection(gpu, n, monkeypatch):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("n", [1024, 128, 6])
+def test_row_slab_kernel_with_lds_dma_staging(gpu, n, monkeypatch):
+    """Default since round 5 (SERL_SLAB_DMA=0 = the register-staged kernels): b0_conv1 and b1_conv1 on
+    conv3x3_slabdma_f16x3_kernel (operands by global_load_lds instead of through registers; same tiles, same K order, same
+    epilogue -- resnet_v1.py:129-156), b0_conv0 (raw input) with its weights by LDS-DMA.  Same products in the same order: features equal
+    the register-staged kernel's up to the order of the fp64 statistics atomics, and stay within 5e-6 of the fp64 oracle; the
+    plan reports tile-config 9 for the two layers."""
+    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=max(n // 2, 4), trunk_mode="f16x3")
+    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(6))
+    monkeypatch.setenv("SERL_SLAB_DMA", "0")
+    regs = core.trunk_forward(img).clone()
+    assert core.trunk_plan()["b0_conv1"][:2] == ("S", 1)
+    monkeypatch.delenv("SERL_SLAB_DMA")
+    for rep in range(3):
+        dma = core.trunk_forward(img).clone()
+        plan = core.trunk_plan()
+        assert plan["b0_conv1"][:2] == ("S", 9) and plan["b1_conv1"][:2] == ("S", 9) and plan["b0_conv0"][0] == "S", plan
+        if plan["raw_b0"]:
+            assert plan["b0_conv0"][:2] == ("S", 9), plan
+        scale = float(regs.abs().max())
+        assert float((dma - regs).abs().max()) / scale < 2e-6, rep
+    sel = list(range(min(n, 6))) + list(range(max(n - 6, 0), n))
+    ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
+    err = AH.rel_err(dma[sel].cpu().numpy(), ref)
+    print(f"LDS-DMA row-slab kernel n={n}: rel err vs fp64 = {err:.2e}; plan b0_conv1 {plan['b0_conv1']}, b1_conv1 {plan['b1_conv1']}")
+    assert err < 5e-6, err
+
+
 def _pretrained_like_trunk(trunk, seed=3):
     """Weight statistics a trained ImageNet ResNet with GroupNorm shows and kaiming-normal init does not: a wide
     per-output-channel spread of kernel magnitudes (nearly dead channels and a few very strong ones), first-layer
