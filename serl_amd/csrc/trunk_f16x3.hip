@@ -76,6 +76,8 @@ struct ConvArgsB {
   // row-slab kernel, fused epilogue: the SECOND workgroup of every CU (block ids 256..511 of the first round) starts
   // `stagger` x s_sleep(127) late (before it takes its tile ticket), see the kernel
   int stagger;
+  // row-slab kernels, fused epilogue: 1 = the tile goes through LDS once and is normalised / stored ROW-major (rowtile_epilogue_t)
+  int epi_t;
 };
 
 // LDS-DMA kernel, default since round 5 (SERL_PROJ_FUSE=0 switches it off): the block's 1x1 stride-2 projection computed by the SAME workgroup in front of its
@@ -971,6 +973,124 @@ __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&a
   }
 }
 
+// The fused GroupNorm (+ residual) + ReLU + split8 epilogue of a 256 x 64 row tile, ROW-MAJOR (round 5).  rowtile_epilogue above
+// stores from the MFMA C layout -- a lane owns ONE channel of 16 rows per 32 x 32 tile, i.e. 64 four-byte stores and (with a
+// residual) 64 four-byte loads per lane, half of the values traded with the neighbour lane by DPP: 2.7 TB/s on the store-only
+// epilogue of b0_conv0, issue-bound.  Here every wave writes its 64 x 64 accumulator tile to the (now idle) operand LDS once,
+// 16 KB per wave, and reads it back with a lane owning EIGHT consecutive channels of a row: the residual arrives as two 16-byte
+// loads, the split8 record (16 bytes of hi halves + 16 bytes of lo' halves) leaves as two 16-byte stores, eight lanes cover a
+// row's 256 contiguous bytes -- 16 + 16 wide memory instructions per lane instead of 64 + 64 narrow ones, no lane exchange.
+// Same arithmetic per element as fused_gn_store.  Statistics, arrival and wait are unchanged (taken from the registers first).
+__device__ __forceinline__ void rowtile_epilogue_t(const ConvArgsB& ab, f32x16 (&acc)[2][2], f32x16 (&accx)[2][2], int m0, int n0,
+                                                   int n_img, int wave, int lane, int sync_idx, uint8_t* lds) {
+  const ConvArgs& a = ab.c;
+  const FuseArgs& fz = ab.fz;
+  constexpr int TM = 2, TN = 2, WROWS = 64;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wrow0 = m0 + wave * WROWS;
+  float winv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + tn * 32 + li];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
+  {
+    const int gsize = a.Cout / kGnGroups;
+    double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s += v; q += v * v; }
+      stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
+    }
+  }
+  // the wave's tile -> LDS [row][64 floats] (every wave passed the main loop's last barrier: the operand buffers are idle)
+  float* tile = reinterpret_cast<float*>(lds) + wave * (64 * 64);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + tn * 32 + li] = acc[tm][tn][r];
+  // this lane's eight channels and its rows (8 lanes per row, 8 rows per pass); residual of the first passes requested before the wait
+  const int g8 = lane & 7, rsub = lane >> 3, c0 = n0 + 8 * g8;
+  const size_t rowb = (size_t)a.Cout * 4;
+  const uint8_t* res_base = fz.mode == 2 ? fz.res_split + (size_t)wrow0 * rowb + c0 * 4
+                                         : reinterpret_cast<const uint8_t*>(fz.res_raw) + (size_t)wrow0 * rowb + c0 * 4;
+  u32x4 rres[8][2];
+  if (fz.mode >= 2) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint8_t* q = res_base + (size_t)(8 * p + rsub) * rowb;
+      rres[p][0] = *reinterpret_cast<const u32x4*>(q);
+      rres[p][1] = *reinterpret_cast<const u32x4*>(q + 16);
+    }
+  }
+  fused_arrive_and_wait(fz.sync + sync_idx, fz.expected);
+  float sc[8], sh[8], rs[8], rh[8];
+  {
+    const double* st = fz.gn.stats + ((size_t)n_img * kGnGroups + c0 / fz.gn.gsize) * 2;   // (8 consecutive channels: one group)
+    const double s0 = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double s1 = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double mean = s0 * fz.gn.inv_count, m2 = s1 * fz.gn.inv_count;
+    const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+    const float rstd = rsqrtf(var + 1e-5f), mf = (float)mean;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = fz.gn.gamma[c0 + j] * rstd; sh[j] = fz.gn.beta[c0 + j] - mf * sc[j]; rs[j] = 0.f; rh[j] = 0.f; }
+    if (fz.mode >= 3) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gn_coef1<false>(fz.res_gn, n_img, c0 + j, rs[j], rh[j]);
+    }
+  }
+  uint8_t* out_base = fz.out_split + (size_t)wrow0 * rowb + c0 * 4;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 8 * p + rsub;
+    const float4 t0 = *reinterpret_cast<const float4*>(tile + row * 64 + 8 * g8);
+    const float4 t1 = *reinterpret_cast<const float4*>(tile + row * 64 + 8 * g8 + 4);
+    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (fz.mode == 2) {          // residual in split8 form: 8 hi halves | 8 lo' halves
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // (through scalars: __builtin_bit_cast applied to a vector-ELEMENT lvalue reads element 0 with this compiler)
+        const uint32_t wh = rres[p][0][j], wl = rres[p][1][j];
+        const h16x2 hh = __builtin_bit_cast(h16x2, wh), ll = __builtin_bit_cast(h16x2, wl);
+        v[2 * j] = ((float)hh[0] + (float)ll[0] * kLoInv) + v[2 * j];
+        v[2 * j + 1] = ((float)hh[1] + (float)ll[1] * kLoInv) + v[2 * j + 1];
+      }
+    } else if (fz.mode >= 3) {   // raw fp32 residual: GroupNorm of the projection (3) or relu(GroupNorm) of the block input (4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t wx = rres[p][j >> 2][j & 3];
+        const float x = __builtin_bit_cast(float, wx);
+        const float y = x * rs[j] + rh[j];
+        v[j] = (fz.mode == 4 ? fmaxf(y, 0.f) : y) + v[j];
+      }
+    }
+    u32x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a0 = fmaxf(v[2 * j], 0.f), a1 = fmaxf(v[2 * j + 1], 0.f);
+      const h16x2 hp = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+      const f32x2 rem = {(a0 - (float)hp[0]) * kLoScale, (a1 - (float)hp[1]) * kLoScale};
+      const f16x2 lp = __builtin_convertvector(rem, f16x2);
+      hi[j] = __builtin_bit_cast(uint32_t, hp);
+      lo[j] = __builtin_bit_cast(uint32_t, lp);
+    }
+    uint8_t* o = out_base + (size_t)row * rowb;
+    *reinterpret_cast<u32x4*>(o) = hi;
+    *reinterpret_cast<u32x4*>(o + 16) = lo;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-slab kernel for the stride-1 3x3 convs of stage 0 and b1_conv1 (the largest M and the smallest N, where an im2col
 // loader's 9x re-read of every input pixel through L2 -> LDS is the bound): 256 x 64 output tile = 256 / Wo whole output
@@ -991,7 +1111,7 @@ constexpr int kRowslabLds = 2 * 4 * (kRowslabPix * 16 + 32) + 2 * 3 * 2 * 2 * (6
 // WDMA (round 5): the WEIGHTS of a sub-chunk arrive by LDS-DMA in the LDS-DMA kernels' piece order (4 KB per tap, swizzled
 // [cout][64 B]: see conv3x3_slabdma_f16x3_kernel) one sub-chunk ahead -- three of a thread's five staging loads, their registers
 // and their ds_write_b128 disappear; the activations keep the register path (RAWIN applies GroupNorm + ReLU + split on the way).
-template <bool RAWIN, bool WDMA = false>
+template <bool RAWIN, bool WDMA = false, bool EPT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB ab) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
@@ -1196,7 +1316,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
 #undef SERL_RS_LOADS
 #undef SERL_RS_STORES
 #undef SERL_RS_COMPUTE
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
+  if (EPT) rowtile_epilogue_t(ab, acc, accx, m0, n0, n_img, wave, lane, n_img * a.tiles_n + bn, smemb);
+  else rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1220,6 +1341,7 @@ constexpr int kSdPieces = 23;                          // 368 pixels >= 18 x 20 
 constexpr int kSdSlab = kSdPieces * 1024, kSdW = 3 * 4096;
 constexpr int kSlabDmaLds = 2 * kSdSlab + 2 * kSdW;    // 71,680 B: two workgroups per CU leave 16 KB for a chain GEMM workgroup
 
+template <bool EPT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_slabdma_f16x3_kernel(ConvArgsB ab, const uint8_t* zero_page) {
   const ConvArgs& a = ab.c;
   constexpr int TM = 2, TN = 2, WROWS = 64, BM = 256, BN = 64;
@@ -1335,7 +1457,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_slabdma_f16x3_kernel(ConvArgsB
   }
 #undef SERL_SD_SLAB
 #undef SERL_SD_W
-  rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
+  if (EPT) rowtile_epilogue_t(ab, acc, accx, m0, n0, n_img, wave, lane, n_img * a.tiles_n + bn, smemb);
+  else rowtile_epilogue(ab, acc, accx, m0, n0, n_img, wave, li, lh, n_img * a.tiles_n + bn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2165,6 +2288,10 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       // step 2.5762 / 2.5747 -> 2.5523 / 2.5489 ms with 5; 3 and 8 (a quarter / three quarters of a tile) gave nothing
       static const int rs_stagger = []() { const char* e = getenv("SERL_RS_STAGGER"); return e ? atoi(e) : 5; }();
       ab.stagger = (fused && a.tiles_m * a.tiles_n >= 1024) ? rs_stagger : 0;
+      // Row-major fused epilogue (rowtile_epilogue_t), default since round 5: same-call pipelined step 2.494 / 2.497 -> 2.474 / 2.471 ms,
+      // serial 2.953 -> 2.936 (profiles/r05_ab_epilogue_t.txt).  SERL_EPI_T = a mask over the epilogue modes (bit mode - 1), 0 = the
+      // C-layout epilogue everywhere; read per launch (the test flips it inside one process)
+      { const char* e = getenv("SERL_EPI_T"); ab.epi_t = (fused && (((e ? atoi(e) : 15) >> (ab.fz.mode - 1)) & 1)) ? 1 : 0; }
       // (read per launch: the test flips it inside one process)
       const char* sd_e = getenv("SERL_SLAB_DMA");
       // LDS-DMA staging (default since round 5: pipelined step 2.432 / 2.418 -> 2.372 / 2.371 ms, serial 2.814 -> 2.770, same call):
@@ -2174,12 +2301,14 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
       if (raw_in) {
         a.in = raw_in->raw; a.in_gn = raw_in->gn;
         if (sd_on && w.dma != nullptr) {
-          hipLaunchKernelGGL((conv3x3_rowslab_f16x3_kernel<true, true>), dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+          if (ab.epi_t) hipLaunchKernelGGL((conv3x3_rowslab_f16x3_kernel<true, true, true>), dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
+          else hipLaunchKernelGGL((conv3x3_rowslab_f16x3_kernel<true, true>), dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
           slab_dma_used = true;
         } else
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);
       } else if (slab_dma) {
-        hipLaunchKernelGGL(conv3x3_slabdma_f16x3_kernel, dim3(a.tiles_m * a.tiles_n), block, (size_t)kSlabDmaLds, stream, ab, zero_page);
+        if (ab.epi_t) hipLaunchKernelGGL(conv3x3_slabdma_f16x3_kernel<true>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kSlabDmaLds, stream, ab, zero_page);
+        else hipLaunchKernelGGL(conv3x3_slabdma_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kSlabDmaLds, stream, ab, zero_page);
         slab_dma_used = true;
       } else {
         hipLaunchKernelGGL(conv3x3_rowslab_f16x3_kernel<false>, dim3(a.tiles_m * a.tiles_n), block, (size_t)kRowslabLds, stream, ab);

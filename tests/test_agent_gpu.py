@@ -107,6 +107,30 @@ def test_row_slab_kernel_with_lds_dma_staging(gpu, n, monkeypatch):
     assert err < 5e-6, err
 
 
+@pytest.mark.parametrize("n", [1024, 256, 6])
+def test_row_major_fused_epilogue(gpu, n, monkeypatch):
+    """SERL_EPI_T (a mask over the epilogue modes): the fused GroupNorm / residual / ReLU / split8 epilogue of the row-slab
+    kernels stores ROW-major (the tile passes through LDS once; 16-byte residual loads and record stores instead of 4-byte ones).
+    Same arithmetic per element as the C-layout epilogue (resnet_v1.py:129-156): features equal up to fma contraction and the
+    order of the statistics atomics -- every mode alone (1 GroupNorm, 2 + split8 residual, 3 + projection residual, 4 + raw block
+    input), then all together."""
+    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
+    st, core = AH.make_pair(cfg, B=max(n // 2, 4), trunk_mode="f16x3")
+    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+    monkeypatch.setenv("SERL_EPI_T", "0")
+    base = core.trunk_forward(img).clone()
+    scale = float(base.abs().max())
+    for mask in (1, 2, 4, 8, 15):
+        monkeypatch.setenv("SERL_EPI_T", str(mask))
+        for rep in range(2):
+            got = core.trunk_forward(img).clone()
+            assert float((got - base).abs().max()) / scale < 2e-6, (mask, rep)
+    sel = list(range(min(n, 6)))
+    ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
+    err = AH.rel_err(got[sel].cpu().numpy(), ref)
+    print(f"row-major epilogue n={n}: rel err vs fp64 = {err:.2e}; raw_b0 {core.trunk_plan()['raw_b0']}")
+    assert err < 5e-6, err
+
 def _pretrained_like_trunk(trunk, seed=3):
     """Weight statistics a trained ImageNet ResNet with GroupNorm shows and kaiming-normal init does not: a wide
     per-output-channel spread of kernel magnitudes (nearly dead channels and a few very strong ones), first-layer
