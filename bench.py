@@ -443,10 +443,10 @@ def main():
         # 3x the algorithmic FLOPs, and that executed rate is what the fp16-MFMA roofline bounds
         executed = 3.0 * achieved
         roofline = {"bound": "mfma",
-                    "kernel": (f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel (both stage-0 convs and "
-                               "b1_conv1) + conv_dma_f16x3_kernel (every other 3x3 conv; the three 1x1 projections ride on their block's conv0 launch "
+                    "kernel": (f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel (b0_conv0, raw input) + "
+                               "conv3x3_slabdma_f16x3_kernel (b0_conv1, b1_conv1: the same row-slab tile staged by LDS-DMA) + conv_dma_f16x3_kernel (every other 3x3 conv; the three 1x1 projections ride on their block's conv0 launch "
                                "unless SERL_PROJ_FUSE=0)" if Bl * len(KEYS) * 2 >= 1024 else
-                               f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel (stage 0, b1_conv1), "
+                               f"block convs of the frozen trunk, {11 - len(rider)} launches per pass: conv3x3_rowslab_f16x3_kernel / conv3x3_slabdma_f16x3_kernel (stage 0, b1_conv1), "
                                "conv_dma_f16x3_kernel where at least 512 128-row tiles exist, conv_igemm_f16x3_kernel (64x64 tiles) otherwise") +
                               "; split-fp16 MFMA implicit GEMM, fp32 accumulate",
                     "achieved": round(executed, 3), "peak": PEAK_F16_MFMA, "unit": "TFLOP/s",

@@ -12,7 +12,7 @@ flop_pass = sum(2.0 * m * n_img for t, m in macs.items() if t.startswith("conv_i
 conv_us, passes = 0.0, 0
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["kernel"]
-    if any(p in k for p in ("conv_dma_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_igemm_f16x3_kernel")):
+    if any(p in k for p in ("conv_dma_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv3x3_slabdma_f16x3_kernel", "conv_igemm_f16x3_kernel")):
         conv_us += float(r["total_us"])
     if "conv_init_u8_kernel" in k and "pack" not in k:   # one conv_init launch per trunk pass (NOT the one-off weight packing kernel)
         passes += int(r["calls"])

@@ -31,6 +31,7 @@ def load(d):
 
 
 FAMILIES = (("conv_dma_f16x3", ("conv_dma_f16x3_kernel",)), ("conv3x3_rowslab_f16x3", ("conv3x3_rowslab_f16x3_kernel",)),
+            ("conv3x3_slabdma_f16x3", ("conv3x3_slabdma_f16x3_kernel",)),
             ("conv_igemm_f16x3", ("conv_igemm_f16x3_kernel",)), ("conv_init_u8", ("conv_init_u8_kernel",)),
             ("gemm_f32", ("gemm_f32_kernel",)), ("gemm_bf16x3", ("gemm_bf16x3_kernel",)), ("gather_crop_rgb", ("gather_crop_rgb_kernel",)),
             # SmallEncoder passes (--encoder small): layer 0 on the u8 frames, the input-gradient scatter

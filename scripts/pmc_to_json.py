@@ -27,7 +27,7 @@ def family(tot, disp, pats):
 
 ft, fd = load(sys.argv[1])
 wt, wd = load(sys.argv[2])
-CONV16 = ("conv_igemm_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv_dma_f16x3_kernel")
+CONV16 = ("conv_igemm_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv3x3_slabdma_f16x3_kernel", "conv_dma_f16x3_kernel")
 out = {"units": "bytes; FETCH_SIZE/WRITE_SIZE are KiB counters, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
                 "request: MI355X_MICROARCH.md HBM section); mean over the dispatches of the family"}
 for name, pats in (("conv_igemm_f16x3", CONV16), ("conv_igemm_f32", ("conv_igemm_kernel",)), ("gather_crop", ("gather_crop_kernel", "gather_crop_rgb_kernel")),

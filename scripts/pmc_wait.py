@@ -10,6 +10,7 @@ for r in csv.DictReader(open(f)):
     tot[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
     disp[r["Kernel_Name"]].add(r["Dispatch_Id"])
 FAM = (("conv_dma_f16x3", "conv_dma_f16x3_kernel"), ("conv3x3_rowslab_f16x3", "conv3x3_rowslab_f16x3_kernel"),
+       ("conv3x3_slabdma_f16x3", "conv3x3_slabdma_f16x3_kernel"),
        ("conv_init_u8", "conv_init_u8_kernel<"), ("gemm_bf16x3", "gemm_bf16x3_kernel"), ("pool_finish_split", "pool_finish_split_kernel"))
 out = {"note": __doc__.strip()}
 for name, pat in FAM:

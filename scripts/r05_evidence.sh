@@ -46,6 +46,8 @@ timeout 100 python bench.py $NB --emulate-world 8 --force-collective 2> /dev/nul
 timeout 100 python bench.py $NB --trunk f32 --steps 40 > $O/bench_trunk_f32.json 2> /dev/null
 SERL_GN_FUSE=0 timeout 100 python bench.py $NB > $O/bench_unfused_gn.json 2> /dev/null
 SERL_PROJ_FUSE=0 timeout 100 python bench.py $NB > $O/bench_unfused_proj.json 2> /dev/null
+SERL_SLAB_DMA=0 timeout 100 python bench.py $NB > $O/bench_slab_regs.json 2> /dev/null
+SERL_EPI_T=0 timeout 100 python bench.py $NB > $O/bench_epilogue_c.json 2> /dev/null
 SERL_GEMM=f32 timeout 100 python bench.py $NB > $O/bench_gemm_f32.json 2> /dev/null
 timeout 100 python bench.py $NB --noise hash > $O/bench_noise_hash.json 2> /dev/null
 SERL_CHAIN_FUSE=0 timeout 100 python bench.py $NB > $O/bench_chain_unfused.json 2> /dev/null

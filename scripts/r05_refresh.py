@@ -48,7 +48,7 @@ rows = [
  f"| `{RD}_bench_drq_demos.json`, `{RD}_bench_peg.json`, `{RD}_bench_fwbw.json` | BASELINE configs[2..4]: {val('bench_drq_demos')} / {val('bench_peg')} / {val('bench_fwbw')} grad-steps/s |",
  f"| `{RD}_bench_small_encoder.json` | `--encoder small`: {val('bench_small_encoder')} grad-steps/s ({ms('bench_small_encoder')} ms) |",
  f"| `{RD}_bench_car4.json`, `{RD}_bench_collective_1rank.json` | CAR 4: {val('bench_car4')}; the N > 1 code path on one rank (RCCL all-reduces issued): {val('bench_collective_1rank')} grad-steps/s |",
- f"| `{RD}_bench_unfused_gn.json`, `{RD}_bench_unfused_proj.json`, `{RD}_bench_gemm_f32.json`, `{RD}_bench_trunk_f32.json`, `{RD}_bench_noise_hash.json`, `{RD}_bench_chain_unfused.json` | same-call variants of the official line: `SERL_GN_FUSE=0` {ms('bench_unfused_gn')} ms, `SERL_PROJ_FUSE=0` {ms('bench_unfused_proj')} ms, `SERL_GEMM=f32` {ms('bench_gemm_f32')} ms, `--trunk f32` {ms('bench_trunk_f32')} ms, `--noise hash` {ms('bench_noise_hash')} ms, `SERL_CHAIN_FUSE=0` {ms('bench_chain_unfused')} ms (default {b['ms_per_step']}) |",
+ f"| `{RD}_bench_unfused_gn.json`, `{RD}_bench_unfused_proj.json`, `{RD}_bench_slab_regs.json`, `{RD}_bench_epilogue_c.json`, `{RD}_bench_gemm_f32.json`, `{RD}_bench_trunk_f32.json`, `{RD}_bench_noise_hash.json`, `{RD}_bench_chain_unfused.json` | same-call variants of the official line: `SERL_GN_FUSE=0` {ms('bench_unfused_gn')} ms, `SERL_PROJ_FUSE=0` {ms('bench_unfused_proj')} ms, `SERL_SLAB_DMA=0` (register-staged row-slab kernels) {ms('bench_slab_regs')} ms, `SERL_EPI_T=0` (C-layout fused epilogue) {ms('bench_epilogue_c')} ms, `SERL_GEMM=f32` {ms('bench_gemm_f32')} ms, `--trunk f32` {ms('bench_trunk_f32')} ms, `--noise hash` {ms('bench_noise_hash')} ms, `SERL_CHAIN_FUSE=0` {ms('bench_chain_unfused')} ms (default {b['ms_per_step']}) |",
  f"| `pmc_traffic.json` | HBM traffic per launch (`--pmc FETCH_SIZE` / `WRITE_SIZE` in separate passes, FETCH doubled per the gfx950 note): {json.dumps(tr)[:600]} |",
  f"| `{RD}_actor_latency.json`, `{RD}_sac_state.json` | `sample_actions` on one observation: {J.get('actor_latency', {}).get('ms_per_call', J.get('actor_latency'))}; state-only SAC: {val('sac_state')} |",
 ]
