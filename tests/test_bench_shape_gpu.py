@@ -208,6 +208,7 @@ def _update_pair_checks(cfg, st, core, db, ref, Bt, what):
     assert core.step == st.step == 2
 
 
+@pytest.mark.slow   # (short forms: test_agent_gpu.py::test_baseline_config_shapes_match_oracle[C3_demos_car8 / C4_peg], the byte-exact two-buffer gather above)
 def test_two_buffer_update_at_bench_shape(gpu):
     """C3 / C4: 128 online + 128 demo samples, batch 256, 2 x 128x128 cameras."""
     cfg = _cfg(("wrist_1", "wrist_2"), 6)
@@ -218,6 +219,7 @@ def test_two_buffer_update_at_bench_shape(gpu):
     _update_pair_checks(cfg, st, core, db, ref, B, "two-buffer B=256")
 
 
+@pytest.mark.slow   # (short form: test_agent_gpu.py::test_baseline_config_shapes_match_oracle[C5_fwbw]; 70 s of fp64 oracle on 2048 images)
 def test_fwbw_batch_512_update(gpu):
     """C5 (async_bin_relocation_fwbw_drq): batch 512 = 256 online + 256 demo, keys front / wrist_1, A = 7: one trunk pass over
     2048 images, the update chain at 512 rows (5120 ensemble rows)."""
