@@ -92,6 +92,9 @@ class TorchPipelineSchedule:
         # not starved by the (throughput-bound) trunk kernels of the next batch
         self.side_stream = torch.cuda.Stream(device=device, priority=-1 if prioritise_trunk else 0)
         self.main_stream = torch.cuda.Stream(device=device, priority=-1) if prioritise_update else None
+        # (round 5: the update stream confined to a CU mask -- hipExtStreamCreateWithCUMask, first n bits -- so that the chain's
+        #  workgroups stretch fewer of the trunk's: 128 / 96 / 64 / 32 CUs -> 2.546 / 2.649 / 2.947 / 3.719 ms vs 2.409 / 2.434 unmasked,
+        #  same call; the stage-0 convs do get faster (b0_conv1 390 -> 355 us) but the chain becomes the critical path: removed)
         # (round 5: events created with hipEventDisableSystemFence -- these and every event of the library -- left the step and the
         #  idle time at the pass boundary unchanged: 2.4702 / 2.4698 -> 2.4790 / 2.4534 ms, profiles/README.md)
         self.ev_prod = [torch.cuda.Event() for _ in range(self.slots)]
