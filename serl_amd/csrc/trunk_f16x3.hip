@@ -43,6 +43,17 @@ constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
 // (a workgroup whose own XCD's range is used up takes from the next XCD's counter).  The launcher checks that bound
 // against the CUs the stream may use (resident_workgroups) and falls back to the separate elementwise pass otherwise;
 // the spin itself is bounded (trap) so a protocol error aborts the kernel instead of hanging the GPU.
+// Wave priority of the trunk's conv kernels (s_setprio 3).  In the pipelined step the frozen trunk's stream IS the critical path and the
+// update chain's workgroups share its SIMDs (they are sized to fit beside two trunk workgroups per CU): the arbiter then prefers the
+// trunk's waves.  Same-call A/B (profiles/r05_ab_wave_prio.txt): pipelined 2.4176 / 2.4124 -> 2.4004 / 2.3992 ms (stage-0 convs
+// -13 .. -22 us, conv_init -20 us; the chain's kernels move under the later convs, +6 .. +10 us there), serial unchanged, one rank of
+// eight (128 images per pass, where the CHAIN is the critical path) 0.6788 -> 0.6862: on from 512 images per pass, SERL_TRUNK_WPRIO=0 / 1
+// forces it.
+static int trunk_wave_prio(long images) {
+  static const int v = []() { const char* e = getenv("SERL_TRUNK_WPRIO"); return e ? atoi(e) : -1; }();
+  return v >= 0 ? v : (images >= 512 ? 1 : 0);
+}
+
 struct FuseArgs {
   int mode;                 // 0 off; 1 relu(GN(y)); 2 relu(GN(y) + res_split); 3 relu(GN(y) + GN_res(res_raw))
   int expected;             // arrivals per counter; 0 = LOCAL: a wave's 64 rows x 64 columns are exactly one (image, group), no
@@ -78,6 +89,7 @@ struct ConvArgsB {
   int stagger;
   // row-slab kernels, fused epilogue: 1 = the tile goes through LDS once and is normalised / stored ROW-major (rowtile_epilogue_t)
   int epi_t;
+  int wprio;   // wave priority (s_setprio) of the kernel's waves: the frozen trunk is the step's critical path, the chain's waves that share a SIMD are not
 };
 
 // LDS-DMA kernel, default since round 5 (SERL_PROJ_FUSE=0 switches it off): the block's 1x1 stride-2 projection computed by the SAME workgroup in front of its
@@ -733,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_f16x3_kernel(ConvArgsB ab, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smemb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  if (ab.wprio) __builtin_amdgcn_s_setprio(3);
   const int id = (ab.fz.mode && ab.fz.expected) ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
   const int bn = id % a.tiles_n, bm = id / a.tiles_n;
   const int m0 = bm * BM, n0 = bn * BN;
@@ -1136,6 +1149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_rowslab_f16x3_kernel(ConvArgsB
   // workgroup by about half a tile BEFORE it draws its ticket shifts half of the tiles by half a period for the rest of the
   // launch (a finished workgroup's slot is refilled at once, tickets are handed out in start order, so the tiles of one image
   // still start together and wait for nobody longer than before).
+  if (ab.wprio) __builtin_amdgcn_s_setprio(3);
   if (ab.stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)
     for (int i = 0; i < ab.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
@@ -1349,6 +1363,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_slabdma_f16x3_kernel(ConvArgsB
   uint8_t* const smS = smemb;
   uint8_t* const smW = smemb + 2 * kSdSlab;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (ab.wprio) __builtin_amdgcn_s_setprio(3);
   if (ab.stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)   // anti-phase start, see conv3x3_rowslab_f16x3_kernel
     for (int i = 0; i < ab.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const int id = ab.fz.mode ? fused_tile(ab.fz, gridDim.x) : xcd_remap((int)blockIdx.x, gridDim.x);
@@ -1480,6 +1495,7 @@ struct ConvInitArgsB {
   float* first_cols;    // [N][Ho][tiles_x][64] raw conv outputs of cols 0 mod 16
   int chunk;            // tiles per scheduling chunk (divides tiles_y * tiles_x)
   int* ticket;          // chunk ticket (zeroed per pass)
+  int wprio;            // wave priority (s_setprio), see ConvArgsB
   int ablate;           // TIMING EXPERIMENTS ONLY, compiled in with -DSERL_ABLATE (never in the shipped library; SERL_CINIT_ABLATE, results
                         // are wrong): 1 no patch fill, 2 no MFMAs, 4 no pooling epilogue, 8 no pixel fetch
 };
@@ -1537,6 +1553,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
   uint8_t* patch = smemb + 2 * kC8WBytes;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: `wave == 3` is a uniform branch)
   const int li = lane & 31, lh = lane >> 5;
+  if (a.wprio) __builtin_amdgcn_s_setprio(3);
   for (int v = tid; v < 2 * 64 * (kC8K / 8); v += 256) {   // resident weights: 64 rows x 28 16-byte slots per plane
     const int plane = v / (64 * 28), r = (v / 28) % 64, sl = v % 28;
     const uint4 val = *reinterpret_cast<const uint4*>((plane ? a.wlo : a.whi) + (size_t)r * kC8K + sl * 8);
@@ -1907,6 +1924,7 @@ int launch_conv_init_f16x3(const uint8_t* img, PackedConvWeights w, float* out, 
   ConvInitArgsB a{};
   a.img = img; a.whi = w.hi; a.wlo = w.lo; a.winv = w.inv; a.out = out; a.stats = stats;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.wprio = trunk_wave_prio(N);
   a.tiles_y = cdiv(Ho, 16); a.tiles_x = cdiv(Wo, 16);
   a.total_tiles = N * a.tiles_y * a.tiles_x;
   SERL_REQUIRE(ticket != nullptr, "conv_init needs a chunk ticket");
@@ -2237,6 +2255,7 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
   // on return fuse->mode is 0 when the kernel chosen for this shape cannot do it (the caller then runs the elementwise pass)
   SERL_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv channels unsupported (Cin %d, Cout %d)", Cin, Cout);
   ConvArgsB ab{};
+  ab.wprio = trunk_wave_prio(N);
   ConvArgs& a = ab.c;
   a.in = in_split; a.w = nullptr; a.out = out; a.stats = stats;
   a.N = N; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
