@@ -47,11 +47,13 @@ constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;  // 2^11
 // update chain's workgroups share its SIMDs (they are sized to fit beside two trunk workgroups per CU): the arbiter then prefers the
 // trunk's waves.  Same-call A/B (profiles/r05_ab_wave_prio.txt): pipelined 2.4176 / 2.4124 -> 2.4004 / 2.3992 ms (stage-0 convs
 // -13 .. -22 us, conv_init -20 us; the chain's kernels move under the later convs, +6 .. +10 us there), serial unchanged, one rank of
-// eight (128 images per pass, where the CHAIN is the critical path) 0.6788 -> 0.6862: on from 512 images per pass, SERL_TRUNK_WPRIO=0 / 1
-// forces it.
+// eight (128 images per pass, where the CHAIN is the critical path) 0.6788 -> 0.6862: on from 512 images per pass.  Value 2 (the default
+// when on): 3 in the main loop, 1 in the block convs' epilogues -- an epilogue (HBM traffic, conversions, the wait for the image's other
+// tiles) then yields the SIMD to the main loop of the CU's other workgroup: 2.391 / 2.4062 (flat 3) -> 2.3824 / 2.3987, same call.
+// SERL_TRUNK_WPRIO = 0 / 1 / 2 forces off / flat / main-loop-over-epilogue.
 static int trunk_wave_prio(long images) {
   static const int v = []() { const char* e = getenv("SERL_TRUNK_WPRIO"); return e ? atoi(e) : -1; }();
-  return v >= 0 ? v : (images >= 512 ? 1 : 0);
+  return v >= 0 ? v : (images >= 512 ? 2 : 0);
 }
 
 struct FuseArgs {
@@ -574,6 +576,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
   constexpr int TM = 2, WROWS = 64, WCOLS = 32 * TN;
   const ConvArgs& a = ab.c;
   const int wrow0 = m0 + wm * WROWS;
+  if (ab.wprio == 2) __builtin_amdgcn_s_setprio(1);
   float winv[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + wn * WCOLS + tn * 32 + li];
@@ -1001,6 +1004,7 @@ __device__ __forceinline__ void rowtile_epilogue_t(const ConvArgsB& ab, f32x16 (
   constexpr int TM = 2, TN = 2, WROWS = 64;
   const int li = lane & 31, lh = lane >> 5;
   const int wrow0 = m0 + wave * WROWS;
+  if (ab.wprio == 2) __builtin_amdgcn_s_setprio(1);   // (the epilogue yields to the main loop of the CU's other workgroup)
   float winv[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) winv[tn] = ab.winv[n0 + tn * 32 + li];
