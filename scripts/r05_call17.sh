@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 17: s_setprio 3 in the trunk's conv kernels (SERL_TRUNK_WPRIO=1): the trunk is the critical path, the update
 # chain's waves that share a SIMD with it are not -- does the arbiter's preference shrink the co-run stretch?
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call17b; rm -rf $O; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call17d; rm -rf $O; mkdir -p $O; cd $R
 NB="--no-cpu-baseline --no-verify --steps 110 --repeats 3"
 run() {
   tag=$1; shift
@@ -17,4 +17,5 @@ except Exception as e:
     print("$tag FAILED", e, open("$O/$tag.err").read()[-600:])
 PY
 }
-for v in 1 2 1 2 0; do ENVV="SERL_TRUNK_WPRIO=$v"; run wprio_$v; done
+for v in 2 3 2 3; do ENVV="SERL_TRUNK_WPRIO=$v"; run wprio_$v; done
+
