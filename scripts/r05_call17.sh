@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 17: s_setprio 3 in the trunk's conv kernels (SERL_TRUNK_WPRIO=1): the trunk is the critical path, the update
 # chain's waves that share a SIMD with it are not -- does the arbiter's preference shrink the co-run stretch?
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call17d; rm -rf $O; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call17e; rm -rf $O; mkdir -p $O; cd $R
 NB="--no-cpu-baseline --no-verify --steps 110 --repeats 3"
 run() {
   tag=$1; shift
@@ -17,5 +17,12 @@ except Exception as e:
     print("$tag FAILED", e, open("$O/$tag.err").read()[-600:])
 PY
 }
-for v in 2 3 2 3; do ENVV="SERL_TRUNK_WPRIO=$v"; run wprio_$v; done
+ENVV="X=0"
+run prio_trunk --prio trunk
+run prio_none --prio none
+run prio_update --prio update
+run prio_trunk --prio trunk
+for b in 128 512 1024; do ENVV="SERL_SPLIT_BUDGET=$b"; run budget_$b; done
+ENVV="X=0"; run uas_0 --update-after-stage 0
+run uas_1 --update-after-stage 1
 
