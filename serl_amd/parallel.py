@@ -57,6 +57,9 @@ class SerialSchedule:
         import contextlib
         return contextlib.nullcontext()
 
+    def gathered(self, slot, fn):
+        return fn()
+
     def produced(self, slot):
         pass
 
@@ -99,9 +102,28 @@ class TorchPipelineSchedule:
         #  idle time at the pass boundary unchanged: 2.4702 / 2.4698 -> 2.4790 / 2.4534 ms, profiles/README.md)
         self.ev_prod = [torch.cuda.Event() for _ in range(self.slots)]
         self.ev_cons = [None] * self.slots
+        # sample -> gather -> augment of batch i+2 runs on a THIRD stream: the host issues it while the trunk pass of batch i+1 is still
+        # running, so the pass of batch i+2 starts at conv_init instead of behind a 22 us (37 us co-running) gather, and its index /
+        # offset upload is off the trunk stream too.  Same-call A/B (profiles/r05_ab_gather_stream.txt): 2.422 / 2.404 -> 2.339 / 2.347 ms
+        # per step (-2.9 %), features verified against a serial re-encode.  The slot's buffers are free by then: the host has waited for
+        # update(i-1), the last reader of that slot.  SERL_GATHER_STREAM=0 puts the gather back on the trunk stream.
+        import os
+        self.gather_stream = torch.cuda.Stream(device=device) if os.environ.get("SERL_GATHER_STREAM", "1") != "0" else None
+        self.ev_gather = [torch.cuda.Event() for _ in range(self.slots)]
 
     def side(self):
         return self.torch.cuda.stream(self.side_stream)
+
+    def gathered(self, slot, fn):
+        """run the gather `fn` (called with the side stream current) -- on the gather stream when there is one, the side stream then
+        waits for it"""
+        if self.gather_stream is None:
+            return fn()
+        with self.torch.cuda.stream(self.gather_stream):
+            out = fn()
+            self.ev_gather[slot].record(self.gather_stream)
+        self.side_stream.wait_event(self.ev_gather[slot])
+        return out
 
     def main(self):
         import contextlib
@@ -209,7 +231,7 @@ class DataParallelLearner:
         self.sched.wait_consumed(slot)
         split = getattr(self.sched, "update_after_stage", None)
         with self.sched.side():
-            db = self.gather(local, co[lo:hi], cn[lo:hi], slot)
+            db = self.sched.gathered(slot, lambda: self.gather(local, co[lo:hi], cn[lo:hi], slot))
             if split is None or not hasattr(self.core, "encode_slot_range"):
                 self.core.encode_slot(db, slot)
             else:   # two pieces with an event between them (see TorchPipelineSchedule)
