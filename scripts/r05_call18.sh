@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 17: s_setprio 3 in the trunk's conv kernels (SERL_TRUNK_WPRIO=1): the trunk is the critical path, the update
 # chain's waves that share a SIMD with it are not -- does the arbiter's preference shrink the co-run stretch?
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call18; rm -rf $O; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_call18b; rm -rf $O; mkdir -p $O; cd $R
 NB="--no-cpu-baseline --no-verify --steps 110 --repeats 3"
 run() {
   tag=$1; shift
@@ -18,4 +18,3 @@ except Exception as e:
 PY
 }
 for v in 0 1 0 1; do ENVV="SERL_GATHER_STREAM=$v"; run gstream_$v; done
-SERL_GATHER_STREAM=1 timeout 200 python bench.py --no-cpu-baseline --steps 60 --repeats 1 2> $O/verify.err | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('verify', d.get('verify'), d['ms_per_step'])"

@@ -401,21 +401,26 @@ class DrQAgent:
     def _slot_batch(self, slot, B):
         c = self.core.cfg
         if self._slot_batches[slot] is None or self._slot_batches[slot].batch != B:
-            if self._sched is not None:     # the side stream may still be reading the buffers about to be freed
+            if self._sched is not None:     # the side / gather streams may still be using the buffers about to be freed
                 self._sched.side_stream.synchronize()
+                if getattr(self._sched, "gather_stream", None) is not None:
+                    self._sched.gather_stream.synchronize()
             self._slot_batches[slot] = DeviceBatch(B, c.n_cam, c.H, c.W, 3, c.state_dim, c.act_dim, c.device)
         return self._slot_batches[slot]
 
     def _produce(self, batch: LazyBatch, slot, db, rng=None):
-        """gather + crop and the frozen trunk on the side stream.  (Round 2 gathered on the caller's stream and made the side
-        stream wait for it: a dependency that crosses streams costs 60-100 us on this stack, at every pass.  An actor-side
-        insert that overwrites a slot waits ON THE COPY STREAM for the gathers in flight, never on the host.)"""
+        """gather + crop on the schedule's gather stream, the frozen trunk on the side stream.  (Round 2 gathered on the CALLER's
+        stream at the moment the pass needed it and made the side stream wait: a dependency that crosses streams and actually
+        blocks costs 60-100 us on this stack, at every pass.  Since round 5 the gather of the NEXT batch runs on a third stream while
+        the previous pass is still computing -- the side stream's wait is satisfied long before it is reached -- and the pass starts
+        at conv_init: parallel.py TorchPipelineSchedule.gathered.  An actor-side insert that overwrites a slot waits ON THE COPY
+        STREAM for the gathers in flight, never on the host.)"""
         sch = self._sched
         co, cn = self._draw_crops(db.batch, rng)      # rng: state.rng at the entry of the call that will consume this batch
         self._slot_crops[slot] = (co, cn)
         sch.wait_consumed(slot)     # host side: the update that used this slot ended two passes ago
         with sch.side():
-            gather_crop(batch.parts, co, cn, db)
+            sch.gathered(slot, lambda: gather_crop(batch.parts, co, cn, db))
             self.core.encode_slot(db, slot)
         sch.produced(slot)
 

@@ -104,8 +104,8 @@ class TorchPipelineSchedule:
         self.ev_cons = [None] * self.slots
         # sample -> gather -> augment of batch i+2 runs on a THIRD stream: the host issues it while the trunk pass of batch i+1 is still
         # running, so the pass of batch i+2 starts at conv_init instead of behind a 22 us (37 us co-running) gather, and its index /
-        # offset upload is off the trunk stream too.  Same-call A/B (profiles/r05_ab_gather_stream.txt): 2.422 / 2.404 -> 2.339 / 2.347 ms
-        # per step (-2.9 %), features verified against a serial re-encode.  The slot's buffers are free by then: the host has waited for
+        # offset upload is off the trunk stream too.  Same-call A/Bs on three boxes (profiles/r05_ab_gather_stream.txt): -2.9 % (2.422 / 2.404 -> 2.339 /
+        # 2.347 ms per step), +0.25 % (noise) and -0.4 %: never slower beyond noise; features verified against a serial re-encode.  The slot's buffers are free by then: the host has waited for
         # update(i-1), the last reader of that slot.  SERL_GATHER_STREAM=0 puts the gather back on the trunk stream.
         import os
         self.gather_stream = torch.cuda.Stream(device=device) if os.environ.get("SERL_GATHER_STREAM", "1") != "0" else None
@@ -419,7 +419,7 @@ class TrunkFarmLearner(DataParallelLearner):
         self.last_draws["crops"] = (co, cn)
         self.sched.wait_consumed(slot)
         with self.sched.side():
-            db = self.gather(parts, co, cn, slot)
+            db = self.sched.gathered(slot, lambda: self.gather(parts, co, cn, slot))
             if self.role == "worker":
                 self._wait_transfer(slot)      # (this stream: the previous send out of this slot's feature buffer has completed)
                 self.core.encode_slot(db, slot)
