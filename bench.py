@@ -505,7 +505,10 @@ def main():
                    "random_stream": ("jax.random threefry2x32 with the reference's key schedule: crop offsets, REDQ indices"
                                      + (", policy noise, Dropout masks" if learner.device_noise == "threefry" else "; policy noise / Dropout masks hashed on the device")),
                    "encoder": args.encoder, "trunk_passes_per_grad_step": 0 if small else 2, "trunk_arithmetic": "f32" if small else args.trunk,
-                   "schedule": "serial" if args.no_pipeline else "trunk(i+1) overlapped with update(i) on a 2nd stream"},
+                   "schedule": "serial" if args.no_pipeline else (
+                       "trunk(i+1) overlapped with update(i) on a 2nd stream" + ("; gather(i+2) on a 3rd" if getattr(sched, "gather_stream", None) is not None else "")),
+                   # (every SERL_* switch set for this run: a variant line says so itself)
+                   "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("SERL_")}},
         "roofline": roofline,
         "repeats": len(dts), "ms_per_step_runs": [round(1e3 * x / args.steps, 4) for x in dts],
         "last_info": {k: round(float(v), 6) for k, v in info.items()},
