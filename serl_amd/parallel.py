@@ -74,7 +74,7 @@ class SerialSchedule:
 
 
 class TorchPipelineSchedule:
-    """Two HIP streams + events: producer (gather + trunk) on `side`, consumer on the current stream.
+    """HIP streams + events: producer (trunk) on `side`, its gather one batch ahead on `gather_stream`, consumer on the current stream.
 
     THREE batch slots: the pass of batch i+2 reuses the slot of batch i-1, and the host confirms that update(i-1) is done
     with a host-side event wait (normally already complete: the host then runs at most two updates ahead of the device)
