@@ -357,7 +357,8 @@ int serl_classifier_logits(serl_classifier* c, const uint8_t* dev_frames, int n,
  * policy noise (sac.py:118-132,197-201,224-227) and Dropout masks from jax.random and advances `state.rng` as
  * common/common.py:197-209, sac.py:287-289 and agents/continuous/drq.py:276-318 do.  These entry points reproduce that stream:
  * keys, integers and the 32-bit draws behind every sample are bit-exact; normals follow XLA's float32 erf_inv polynomial.
- * A key is uint32[2] (jax.random.PRNGKey(seed) = {seed >> 32, seed & 0xffffffff}).  The host functions need no device.
+ * A key is uint32[2]; jax.random.PRNGKey(seed) = {0, seed & 0xffffffff} as the reference runs JAX (x64 disabled: the seed is an
+ * int32, PRNGKey(-1) = {0, 0xffffffff}).  The host functions need no device.
  * --------------------------------------------------------------------------------------------- */
 int serl_jax_prngkey(uint64_t seed, uint32_t key_out[2]);                              /* jax.random.PRNGKey */
 int serl_jax_split(const uint32_t key[2], int num, uint32_t* keys_out /* [num][2] */); /* jax.random.split */

@@ -55,8 +55,8 @@ def threefry_2x32(key, count):
 
 
 def PRNGKey(seed):
-    s = int(seed)
-    return np.array([(s >> 32) & 0xFFFFFFFF, s & 0xFFFFFFFF], np.uint32)
+    # x64 disabled (the reference's setting): the seed is canonicalised to int32 and the key's high word is 0
+    return np.array([0, int(seed) & 0xFFFFFFFF], np.uint32)
 
 
 def split(key, num=2):
@@ -93,7 +93,7 @@ def randint(key, shape, minval, maxval):
     hi_bits, lo_bits = random_bits(k1, shape).astype(np.uint64), random_bits(k2, shape).astype(np.uint64)
     span = np.uint64(max(int(maxval) - int(minval), 1))
     mult = np.uint64(1 << 16) % span
-    mult = (mult * mult) % span
+    mult = ((mult * mult) & _M32) % span      # lax.mul on uint32 wraps (matters for span > 65536)
     with np.errstate(over="ignore"):
         off = (((hi_bits % span) * mult) & _M32) + (lo_bits % span)      # uint32 arithmetic (wraps like lax.mul / lax.add)
         off = (off & _M32) % span

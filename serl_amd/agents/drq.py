@@ -436,7 +436,14 @@ class DrQAgent:
                 self.core.set_chain_budget(256)      # the chain now runs beside the trunk pass (see parallel.py)
         sch, B = self._sched, batch.batch_size
         key = self._lazy_key(batch)
-        if self._prefetched is not None and self._prefetched[0] == key:
+        hit = self._prefetched is not None and self._prefetched[0] == key
+        if hit and self.rng_impl == "threefry" and self._prefetched[3] is not None \
+                and not np.array_equal(self._prefetched[3], self._rng_key):
+            # The slot's crop offsets were drawn from the state.rng this call was EXPECTED to enter with.  state.rng moved in
+            # between (state.replace(rng=...) after a checkpoint restore / reseed, or an update on a non-lazy batch): the
+            # reference would crop with the current key, so the slot is stale -- produce it again.
+            hit = False
+        if hit:
             slot = self._prefetched[1]
             sch.wait_produced(slot)
             db = self._slot_batches[slot]
@@ -455,7 +462,7 @@ class DrQAgent:
             self._produce(nxt, s2, self._slot_batch(s2, B), next_rng)
             # (the parts are kept alive with the key: a freed index array's address could otherwise be reused by a
             # later sample and false-match)
-            self._prefetched = (self._lazy_key(nxt), s2, list(nxt.parts))
+            self._prefetched = (self._lazy_key(nxt), s2, list(nxt.parts), None if next_rng is None else np.array(next_rng, np.uint32))
         self.core.select_slot(slot)
         return slot, db
 

@@ -58,7 +58,7 @@ static void randint_host(const uint32_t key[2], int64_t n, int32_t lo, int32_t h
   split_host(key, 2, ks);
   const uint32_t span = (uint32_t)((int64_t)hi - (int64_t)lo > 0 ? (int64_t)hi - (int64_t)lo : 1);
   uint32_t mult = (uint32_t)(65536u % span);
-  mult = (uint32_t)(((uint64_t)mult * mult) % span);
+  mult = (uint32_t)(mult * mult) % span;   // lax.mul on uint32 WRAPS (span > 65536: e.g. span 2^31 - 1 gives 0, not 2) -- jax._src.random._randint
   for (int64_t e = 0; e < n; ++e) {
     const uint32_t hb = random_bits_at(ks[0], ks[1], (uint64_t)n, (uint64_t)e);
     const uint32_t lb = random_bits_at(ks[2], ks[3], (uint64_t)n, (uint64_t)e);
@@ -73,7 +73,8 @@ extern "C" {
 
 int serl_jax_prngkey(uint64_t seed, uint32_t key_out[2]) {
   SERL_REQUIRE(key_out, "NULL argument");
-  key_out[0] = (uint32_t)(seed >> 32);
+  // the reference runs JAX with x64 disabled: the seed is an int32, the high word of the key is always 0 (threefry_seed)
+  key_out[0] = 0u;
   key_out[1] = (uint32_t)(seed & 0xFFFFFFFFull);
   return SERL_OK;
 }

@@ -50,9 +50,10 @@ def is_key(x) -> bool:
 
 
 def prngkey(seed: int) -> np.ndarray:
-    """jax.random.PRNGKey(seed)"""
+    """jax.random.PRNGKey(seed) as the reference runs it (x64 disabled: the seed is canonicalised to int32, so the key is
+    [0, seed & 0xffffffff] -- PRNGKey(-1) = [0, 0xffffffff], PRNGKey(2**32 + 5) = PRNGKey(5); jax._src.prng.threefry_seed)"""
     out = np.zeros(2, np.uint32)
-    _lib.check(_lib.lib().serl_jax_prngkey(C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _kp(out)))
+    _lib.check(_lib.lib().serl_jax_prngkey(C.c_uint64(int(seed) & 0xFFFFFFFF), _kp(out)))
     return out
 
 
@@ -101,15 +102,28 @@ class UpdateKeys:
     """Every key one learner call derives from state.rng (serl_jax_update_keys; order documented in the header)."""
 
     def __init__(self, rng, drq_aug: bool, n_critic: int, has_actor_temp: bool, combined: bool = False):
-        if n_critic > MAX_UTD:
-            raise ValueError(f"utd_ratio {n_critic} exceeds SERL_JAX_MAX_UTD = {MAX_UTD}")
-        k, s = _key(rng), _UpdateKeys()
-        _lib.check(_lib.lib().serl_jax_update_keys(_kp(k), int(bool(drq_aug)), int(n_critic), int(bool(has_actor_temp)), int(bool(combined)), C.byref(s)))
+        # The C struct holds SERL_JAX_MAX_UTD critic slots; the schedule is a chain (every update derives its keys from the running
+        # rng and advances it), so a larger utd_ratio -- the reference accepts any divisor of the batch (sac.py:544-596) -- is the
+        # same call made on consecutive windows of <= MAX_UTD critic updates, the actor/temperature update riding on the last one.
+        k = _key(rng)
         a = lambda f: np.array(list(f), np.uint32)
-        self.rng_in, self.rng_out = k.copy(), a(s.rng_out)
-        self.k_obs, self.k_next = a(s.k_obs), a(s.k_next)
-        self.k_next_action = [a(s.k_next_action[i]) for i in range(n_critic)]
-        self.k_subsample = [a(s.k_subsample[i]) for i in range(n_critic)]
+        self.rng_in = k.copy()
+        self.k_next_action, self.k_subsample = [], []
+        done, first, cur = 0, True, k
+        while True:
+            n = min(n_critic - done, MAX_UTD)
+            last = done + n == n_critic
+            s = _UpdateKeys()
+            _lib.check(_lib.lib().serl_jax_update_keys(_kp(cur), int(bool(drq_aug) and first), int(n), int(bool(has_actor_temp) and last),
+                                                       int(bool(combined)), C.byref(s)))
+            if first:
+                self.k_obs, self.k_next = a(s.k_obs), a(s.k_next)
+            self.k_next_action += [a(s.k_next_action[i]) for i in range(n)]
+            self.k_subsample += [a(s.k_subsample[i]) for i in range(n)]
+            cur, done, first = a(s.rng_out), done + n, False
+            if last:
+                break
+        self.rng_out = cur
         self.k_policy, self.k_sample, self.k_temp = a(s.k_policy), a(s.k_sample), a(s.k_temp)
         self.n_critic, self.has_actor_temp = n_critic, bool(has_actor_temp)
 

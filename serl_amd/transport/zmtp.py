@@ -141,15 +141,19 @@ class _Peer:
         with self.slock:
             self._send(data, timeout)
 
-    def send_or_drop(self, data: bytes, stall: float = 1.0) -> bool:
+    def send_or_drop(self, data: bytes, stall: float = 1.0, min_rate: float = 1e6) -> bool:
         """PUB semantics (libzmq never blocks a publisher: it drops WHOLE messages at the high-water mark): if the socket is
         not writable right now the message is dropped and the stream stays intact.  Once the first byte of a frame is on the
         wire the rest must follow; the connection is given up only when the subscriber accepts NO byte for `stall` seconds
         (the timer restarts on every byte of progress, so a slow link or a busy subscriber that keeps reading -- 20 MB of
         parameters over 1 GbE take 160 ms -- is never cut off); a peer that stopped reading mid-frame cannot be resynchronised,
-        so its connection is closed and the SUB side reconnects (Socket._pump).  -> True if the message went out."""
+        so its connection is closed and the SUB side reconnects (Socket._pump).  The whole message also has a deadline,
+        `stall + len(data) / min_rate` seconds (1 MB/s: 20 MB of parameters get 21 s): a subscriber that trickle-reads a few bytes
+        inside every stall window would otherwise hold this publisher -- and every peer served after it -- for ever (ADVICE r5;
+        libzmq's PUB never blocks at all).  -> True if the message went out."""
         with self.slock:
             view, started, last = memoryview(data), False, 0.0
+            deadline = time.time() + stall + len(data) / max(min_rate, 1.0)
             while len(view):
                 try:
                     n = self.conn.send(view)
@@ -159,8 +163,8 @@ class _Peer:
                 except (BlockingIOError, InterruptedError):
                     if not started:
                         return False                 # nothing sent yet: drop the whole message
-                    if time.time() - last > stall:
-                        self.close()                 # mid-frame and no progress at all: never leave a partial frame behind
+                    if time.time() - last > stall or time.time() > deadline:
+                        self.close()                 # mid-frame and no (or hopelessly slow) progress: never leave a partial frame behind
                         return False
                     select.select([], [self.conn], [], 0.02)
                 except OSError:

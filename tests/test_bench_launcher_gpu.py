@@ -24,6 +24,10 @@ def test_one_rank_through_the_launcher(gpu, overlap, n_ar):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 3
+    # --parallel auto (the default) is north_star's partition for every N: batch-sharded DP + RCCL all-reduce;
+    # the trunk farm is only ever an explicit --parallel farm
+    assert out["config"]["parallelism"] == "dp1"
+    assert set(out["projection"]["by_n_gpus"]) == {"2", "4", "8"} and "not this run" in out["projection"]["source"]
     c = out["collective"]
     assert c["world_size"] == 1 and c["launcher"] == "torch.distributed.run" and c["backend"].startswith("nccl")
     # per step (CAR = 1): the critic gradients (default: one all-reduce on the update stream; opt-in: two overlapped buckets

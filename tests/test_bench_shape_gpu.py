@@ -46,9 +46,8 @@ def _assert_grads(worst, worst_el, what):
     print(f"{what}: worst leaf {max(worst.values()):.2e}, worst element (>1e-3 of max) {max(worst_el.values()):.2e}")
 
 
-# C2 (headline) in every run; C4/C5-style keys and A = 7 at the full shape is the long variant (their small-shape form is
-# tests/test_agent_gpu.py::test_baseline_config_shapes_match_oracle)
-@pytest.mark.parametrize("keys,A", [(KEYS, 6), pytest.param(("wrist_1", "wrist_2"), 7, marks=pytest.mark.slow)])
+# C2 (headline) and the C4/C5-style keys with A = 7, both at the full shape, in every run (round 6: no longer behind SERL_SLOW)
+@pytest.mark.parametrize("keys,A", [(KEYS, 6), (("wrist_1", "wrist_2"), 7)])
 def test_update_critics_at_bench_shape(gpu, keys, A):
     cfg = _cfg(keys, A)
     st, core = AH.make_pair(cfg, B)
@@ -208,7 +207,6 @@ def _update_pair_checks(cfg, st, core, db, ref, Bt, what):
     assert core.step == st.step == 2
 
 
-@pytest.mark.slow   # (short forms: test_agent_gpu.py::test_baseline_config_shapes_match_oracle[C3_demos_car8 / C4_peg], the byte-exact two-buffer gather above)
 def test_two_buffer_update_at_bench_shape(gpu):
     """C3 / C4: 128 online + 128 demo samples, batch 256, 2 x 128x128 cameras."""
     cfg = _cfg(("wrist_1", "wrist_2"), 6)
@@ -219,7 +217,6 @@ def test_two_buffer_update_at_bench_shape(gpu):
     _update_pair_checks(cfg, st, core, db, ref, B, "two-buffer B=256")
 
 
-@pytest.mark.slow   # (short form: test_agent_gpu.py::test_baseline_config_shapes_match_oracle[C5_fwbw]; 70 s of fp64 oracle on 2048 images)
 def test_fwbw_batch_512_update(gpu):
     """C5 (async_bin_relocation_fwbw_drq): batch 512 = 256 online + 256 demo, keys front / wrist_1, A = 7: one trunk pass over
     2048 images, the update chain at 512 rows (5120 ensemble rows)."""

@@ -174,6 +174,30 @@ def test_iterator_prefetch_is_transparent(gpu):
     assert all(np.isfinite(v) for v in info.resolve()["critic"].values()) and agent.state.step == 3
 
 
+def test_prefetched_slot_is_dropped_when_state_rng_moves(gpu):
+    """The next batch's crop offsets are drawn one call ahead from the state.rng the consuming call is EXPECTED to enter with.  A
+    state.replace(rng=...) in between (checkpoint restore, reseed) makes that slot stale: the reference crops with the key it enters
+    the call with (drq.py:276-281), so the slot must be produced again."""
+    from serl_amd import jaxrng as J
+    env, rb, agent = _setup(B=16)
+    it = rb.get_iterator(sample_args={"batch_size": 16, "pack_obs_and_next_obs": True, "lazy": True})
+    agent.update_critics(next(it))
+    assert agent._prefetched is not None and np.array_equal(agent._prefetched[3], agent.state.rng)   # expected entry key of the next call
+    stale = agent._slot_crops[agent._prefetched[1]]
+    new = J.split(J.prngkey(999))[1]
+    agent.state.replace(rng=new)
+    agent.update_critics(next(it))
+    k = J.split(new, 3)
+    assert np.array_equal(agent.last_draws["crop_obs"], J.crop_offsets(k[1], 16, 4))
+    assert np.array_equal(agent.last_draws["crop_next"], J.crop_offsets(k[2], 16, 4))
+    assert not np.array_equal(agent.last_draws["crop_obs"], stale[0])
+    # undisturbed, the prefetched slot IS used and carries the draws of the entry key
+    k = J.split(agent.state.rng, 3)
+    want = J.crop_offsets(k[1], 16, 4)
+    agent.update_critics(next(it))
+    assert np.array_equal(agent.last_draws["crop_obs"], want)
+
+
 def test_state_replace_loads_trees_into_hbm(gpu):
     """agent.state.replace(params=...) / agent.replace(state=<restored dict>) of the reference: the trees land in HBM."""
     env, rb, src = _setup(B=8)

@@ -25,7 +25,7 @@ def test_threefry_known_answers_through_the_library():
 
 def test_keys_and_integers_are_bit_exact():
     rng = np.random.default_rng(0)
-    for seed in (0, 1, 42, 2**31 - 1, 2**32 + 7):
+    for seed in (0, 1, 42, 2**31 - 1, 2**32 + 7, -1):
         k = J.prngkey(seed)
         assert np.array_equal(k, T.PRNGKey(seed))
         for num in (1, 2, 3, 4, 7, 256):
@@ -37,6 +37,56 @@ def test_keys_and_integers_are_bit_exact():
                 assert np.array_equal(J.randint(k, n, lo, hi), T.randint(k, (n,), lo, hi)), (seed, lo, hi, n)
         d = int(rng.integers(0, 2**32))
         assert np.array_equal(J.fold_in(k, d), T.fold_in(k, d))
+
+
+def test_prngkey_follows_jax_with_x64_disabled():
+    """jax._src.prng.threefry_seed on an int32 seed (the reference never enables x64): high word 0, low word the seed's 32 bits
+    (a 64-bit split of the seed started the learner from another state.rng for seed = -1 or seed >= 2**32)."""
+    for seed, want in ((0, [0, 0]), (42, [0, 42]), (-1, [0, 0xFFFFFFFF]), (2**32 + 5, [0, 5]), (2**31, [0, 2**31])):
+        assert J.prngkey(seed).tolist() == want
+        assert T.PRNGKey(seed).tolist() == want
+
+
+def test_randint_multiplier_wraps_in_uint32_for_large_spans():
+    """jax._src.random._randint: multiplier = (2**16 % span)**2 % span with lax.mul on uint32, which WRAPS (the product
+    was taken in 64 bits).  span = 2**31 - 1: 65536**2 = 2**32 wraps to 0, so a draw is minval + lower_bits % span -- checked
+    from the raw bits, independently of both randint implementations; span = 100000: (65536**2 mod 2**32) % span = 0 as well,
+    span = 70000: 65536 % 70000 = 65536 again."""
+    k = T.PRNGKey(123)
+    k1, k2 = T.split(k)
+    n = 64
+    lb = T.random_bits(k2, (n,)).astype(np.uint64)
+    for lo, span in ((0, 2**31 - 1), (-5, 100000), (7, 70000)):
+        want = (lo + (lb % np.uint64(span)).astype(np.int64)).astype(np.int32)
+        assert np.array_equal(J.randint(k, n, lo, lo + span), want), span
+        assert np.array_equal(T.randint(k, (n,), lo, lo + span), want), span
+    # a span below 2**16 keeps a non-zero multiplier: hb contributes
+    hb = T.random_bits(k1, (n,)).astype(np.uint64)
+    span = np.uint64(1000)
+    mult = (np.uint64(65536) % span) ** 2 % span
+    want = (((hb % span) * mult + lb % span) % span).astype(np.int32)
+    assert np.array_equal(J.randint(k, n, 0, 1000), want)
+
+
+def test_update_keys_chain_beyond_the_struct_capacity():
+    """utd_ratio > SERL_JAX_MAX_UTD (the reference takes any divisor of the batch, sac.py:544-596): the schedule is a chain, so 40
+    critic updates + the actor update = the 40-update prefix of the same rng followed by the rest."""
+    rng = T.split(T.PRNGKey(17))[0]
+    big = J.UpdateKeys(rng, True, 40, True)
+    head = J.UpdateKeys(rng, True, 32, False)
+    tail = J.UpdateKeys(head.rng_out, False, 8, True)
+    assert len(big.k_next_action) == 40 and len(big.k_subsample) == 40
+    for i in range(32):
+        assert np.array_equal(big.k_next_action[i], head.k_next_action[i]) and np.array_equal(big.k_subsample[i], head.k_subsample[i])
+    for i in range(8):
+        assert np.array_equal(big.k_next_action[32 + i], tail.k_next_action[i]) and np.array_equal(big.k_subsample[32 + i], tail.k_subsample[i])
+    assert np.array_equal(big.k_obs, head.k_obs) and np.array_equal(big.k_policy, tail.k_policy) and np.array_equal(big.k_temp, tail.k_temp)
+    assert np.array_equal(big.rng_out, tail.rng_out)
+    # and the written-out schedule: 41 x (rng = split(rng)[0]) after the 3-way augmentation split
+    r = T.split(rng, 3)[0]
+    for _ in range(41):
+        r = T.split(r)[0]
+    assert np.array_equal(big.rng_out, r)
 
 
 def test_crop_offsets_follow_batched_random_crop():

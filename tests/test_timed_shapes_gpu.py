@@ -157,9 +157,9 @@ def test_state_sac_at_the_timed_shape(gpu):
     assert core.step == st.step == 2 * (utd + 1)
 
 
-@pytest.mark.parametrize("car", [4, pytest.param(8, marks=pytest.mark.slow)])   # (8 = the drq_demos / peg workloads' ratio: the long variant)
+@pytest.mark.parametrize("car", [4, 8])   # (8 = the drq_demos / peg workloads' ratio)
 def test_car_iteration_at_bench_shape(gpu, car):
-    """critic_actor_ratio = 4 (8: SERL_SLOW=1) at 128x128 / B=256: (car - 1) x update_critics + update_high_utd(utd_ratio=1).  The oracle's frozen-trunk
+    """critic_actor_ratio = 4 and 8 at 128x128 / B=256: (car - 1) x update_critics + update_high_utd(utd_ratio=1).  The oracle's frozen-trunk
     features are computed once per frame set (two sets, alternating) -- the trunk is frozen, so that only saves host time;
     the HIP side runs the whole path (trunk + update) on every step."""
     cfg = _cfg()

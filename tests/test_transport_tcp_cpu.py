@@ -275,6 +275,44 @@ def test_pub_delivers_large_messages_to_a_slow_but_reading_subscriber():
     sub.close()
 
 
+def test_pub_gives_up_on_a_trickle_reading_subscriber_within_the_message_deadline():
+    """the stall timer restarts on every byte of progress, so a peer that reads a few KB inside every stall window
+    would hold the publisher (and every peer served after it) for ever.  The message as a whole has a deadline
+    (stall + len / min_rate); past it the connection is closed like any mid-frame stall."""
+    import socket as pysock
+    from serl_amd.transport import zmtp
+    lst = pysock.socket()
+    lst.bind(("127.0.0.1", 0))
+    lst.listen(1)
+    cli = pysock.create_connection(lst.getsockname())
+    srv, _ = lst.accept()
+    srv.setblocking(False)
+    srv.setsockopt(pysock.SOL_SOCKET, pysock.SO_SNDBUF, 1 << 16)
+    cli.setsockopt(pysock.SOL_SOCKET, pysock.SO_RCVBUF, 1 << 16)
+    peer = zmtp._Peer.__new__(zmtp._Peer)
+    peer.conn, peer.alive, peer.slock = srv, True, threading.Lock()
+    stop = threading.Event()
+
+    def trickle():                      # 4 KB every 50 ms: always "progress" inside a 0.5 s stall window, 80 KB/s overall
+        while not stop.is_set():
+            try:
+                if not cli.recv(4096):
+                    return
+            except OSError:
+                return
+            time.sleep(0.05)
+
+    th = threading.Thread(target=trickle, daemon=True)
+    th.start()
+    t0 = time.time()
+    ok = peer.send_or_drop(b"x" * (8 << 20), stall=0.5, min_rate=8e6)    # deadline 0.5 + 1.0 s; the trickle would need ~100 s
+    dt = time.time() - t0
+    stop.set()
+    assert ok is False and not peer.alive and dt < 5.0, (ok, peer.alive, dt)
+    cli.close()
+    lst.close()
+
+
 def test_sub_reconnects_after_the_publisher_dropped_it():
     """ADVICE r4 (high, second half): a SUB whose connection was closed must dial again and re-send its subscriptions
     (libzmq does); before, the dead peer was removed and the endpoint never returned to the pending list."""
