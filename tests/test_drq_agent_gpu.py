@@ -262,6 +262,70 @@ def test_load_resnet10_params_from_a_synthetic_pickle(gpu, tmp_path):
     assert np.array_equal(other.core.trunk_forward(frames).cpu().numpy(), feat1)
 
 
+def test_pickle_with_imagenet_like_weight_ranges_through_the_f16x3_trunk(gpu, tmp_path):
+    """the split-fp16 trunk scales every output channel's weights by a power of two (pack_weights_kernel,
+    pack_conv_init_u8_kernel) and has only ever met kaiming-normal pickles.  A pickle shaped like resnet10_params.pkl
+    (train_utils.py:69-130) whose per-output-channel kernel magnitudes span EIGHT decades (1e-7 .. 10 of the init scale), with the
+    power-of-two edge cases pinned -- channels whose max |w| is exactly 2^-20, exactly 2^-24 - 1 ulp (just below a binade), an
+    all-zero channel, a channel with one weight and nothing else, weights inside a channel spanning 1e-6 .. 1 -- loaded with
+    load_resnet10_params and run through the DEFAULT (f16x3) trunk against the fp64 oracle and against plain fp32 on the CPU."""
+    import pickle
+    from oracle import drq_oracle as O
+    import agent_helpers as AH
+    from serl_amd.agents.flax_tree import _trunk_paths
+    from serl_amd.utils import init as pinit
+    from serl_amd.utils.train_utils import load_resnet10_params
+    env, rb, agent = _setup(B=8)
+    agent.core.set_trunk_mode("f16x3")      # (the default; named here because this test is about its weight scaling)
+    rng = np.random.default_rng(11)
+    new = pinit.init_trunk(seed=78)
+    for leaf, v in new.items():
+        if v.ndim != 4:
+            if leaf.endswith("scale"):
+                new[leaf] = rng.uniform(0.2, 3.0, v.shape).astype(np.float32)
+            else:
+                new[leaf] = rng.uniform(-1.0, 1.0, v.shape).astype(np.float32)
+            continue
+        co = v.shape[-1]
+        g = (10.0 ** rng.uniform(-7.0, 1.0, co)).astype(np.float32)          # eight decades across output channels
+        w = v * g
+        flat = w.reshape(-1, co)
+        flat[:, 0] *= np.float32(2.0 ** -20) / np.abs(flat[:, 0]).max()        # max |w| == 2^-20 exactly
+        flat[:, 1] *= np.nextafter(np.float32(2.0 ** -24), np.float32(0)) / np.abs(flat[:, 1]).max()   # one ulp below a binade
+        flat[:, 2] = 0.0                                                       # dead channel
+        flat[:, 3] = 0.0
+        flat[rng.integers(0, flat.shape[0]), 3] = 0.75                         # a single tap
+        flat[:, 4] *= (10.0 ** rng.uniform(-6.0, 0.0, flat.shape[0])).astype(np.float32)   # six decades INSIDE one channel
+        flat[:, 5] *= np.float32(3000.0) / np.abs(flat[:, 5]).max()            # a very strong filter (fp16 overflow without the scale)
+        new[leaf] = flat.reshape(v.shape).astype(np.float32)
+    tree = {}
+    for leaf, sub in _trunk_paths().items():
+        d = tree
+        for q in sub[:-1]:
+            d = d.setdefault(q, {})
+        d[sub[-1]] = new[leaf]
+    f = tmp_path / "resnet10_params.pkl"
+    pickle.dump(tree, open(f, "wb"))
+    load_resnet10_params(agent, KEYS, file_path=str(f))
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([rng.integers(0, 256, (H, W, 3)), rng.integers(0, 256, (H, W, 3)), np.repeat((xx * 4)[..., None], 3, -1),
+                    rng.integers(0, 2, (H, W, 3)) * 255, rng.integers(100, 140, (H, W, 3)),
+                    np.repeat((((yy // 4 + xx // 4) & 1) * 255)[..., None], 3, -1)]).astype(np.uint8)
+    t64 = {k: torch.tensor(v, dtype=torch.float64) for k, v in new.items()}
+    ref = O.trunk_forward(t64, torch.tensor(img), torch.float64).numpy()
+    ref32 = O.trunk_forward({k: v.float() for k, v in t64.items()}, torch.tensor(img), torch.float32).numpy()
+    got = agent.core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(ref).max() > 1e-3
+    for i in range(len(img)):
+        err, err32 = AH.rel_err(got[i], ref[i]), AH.rel_err(ref32[i], ref[i])
+        print(f"wide-range pickle, frame {i}: f16x3 rel err vs fp64 {err:.2e} (plain fp32 on the CPU {err32:.2e})")
+        assert err < max(5e-6, 4.0 * err32), (i, err, err32)
+    # the exact-fp32 MFMA trunk on the same pickle agrees with the split arithmetic
+    agent.core.set_trunk_mode("f32")
+    got32 = agent.core.trunk_forward(torch.tensor(img, device="cuda")).cpu().numpy()
+    assert AH.rel_err(got32, got) < 1e-5
+
+
 def test_zero_learning_rate_is_honoured(gpu):
     """optax accepts learning_rate=0.0 (e.g. to freeze the temperature, common/optimizers.py:23-30): the kernel must train
     that optimizer's leaves at 0, not fall back to the default 3e-4, and the info dict / exported hyperparams say 0 too."""
