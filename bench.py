@@ -130,7 +130,7 @@ def main():
                          "chain has slack there: 3.48 -> 3.44 ms), the latency-bound update chain at small ones")
     ap.add_argument("--update-after-stage", type=int, default=None,
                     help="start update(i) only when the trunk pass of batch i+1 has finished this residual stage (0..2; -1 = conv_init + pool); "
-                         "default: SERL_UPDATE_AFTER_STAGE or off")
+                         "default: off (measured slower, profiles/README.md)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: one-rank RCCL group, issue both all-reduces per step (launch-latency floor of the collectives)")
     ap.add_argument("--overlap-reduce", choices=["on", "off"], default="off",
@@ -239,8 +239,7 @@ def main():
         return dbs[slot]
 
     from serl_amd.parallel import DataParallelLearner, SerialSchedule, TorchPipelineSchedule
-    uas = args.update_after_stage if args.update_after_stage is not None else (
-        int(os.environ["SERL_UPDATE_AFTER_STAGE"]) if os.environ.get("SERL_UPDATE_AFTER_STAGE", "") != "" else None)
+    uas = args.update_after_stage
     if uas is not None and (uas < -1 or uas > 2 or args.trunk != "f16x3"):
         uas = None
     prio = args.prio if args.prio != "auto" else ("trunk" if Bl >= 128 else "update")

@@ -389,8 +389,7 @@ size_t carve(serl_agent* a, void* base) {
 // `agent_budget` is the calling agent's own serl_agent_set_chain_budget value (0 = default): no process-global state, so two
 // agents (or sample_actions on another thread) never see each other's budget.
 int split_for(long agent_budget, int M, int N, int groups, int smax, long budget = 0) {
-  static const long env_budget = []() { const char* e = getenv("SERL_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
-  if (budget <= 0) budget = env_budget > 0 ? env_budget : (agent_budget > 0 ? agent_budget : 512L);
+  if (budget <= 0) budget = agent_budget > 0 ? agent_budget : 512L;
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64) * groups;
   int s = smax;
   while (s > 1 && tiles * s > budget) s >>= 1;
@@ -431,8 +430,7 @@ int encode_multi(serl_agent* a, const EncJob* jobs, int n, int off, int cnt, hip
   GemmDesc gd[3];
   LnFwdArgs lv[3];
   ProprioArgs pv[3];
-  static const long enc_budget = []() { const char* e = getenv("SERL_ENC_SPLIT_BUDGET"); return e ? atol(e) : 0L; }();
-  const int S = split_for(a->split_budget, cnt, c.bottleneck, c.n_cam * n, 32, enc_budget);  // K = 4096: up to 32 slices of 128
+  const int S = split_for(a->split_budget, cnt, c.bottleneck, c.n_cam * n, 32);  // K = 4096: up to 32 slices of 128
   for (int i = 0; i < n; ++i) {
     const EncJob& j = jobs[i];
     EncBuf& e = *j.e;

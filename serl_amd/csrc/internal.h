@@ -62,7 +62,7 @@ size_t trunk_workspace_bytes(int max_images, int H, int W);
 int trunk_workspace_bind(TrunkWorkspace& ws, void* mem, int max_images, int H, int W);
 // split-fp16 copies of the 3x3 / 1x1 conv kernels (trunk_f16x3.hip): fp16 [Cout][K] hi and scaled-lo planes
 struct TrunkPacked {
-  struct W { uint16_t *hi, *lo; float* inv; uint16_t* slab; uint16_t* dma; } blk[kTrunkStages][3]{};  // slab / dma: copies in the fetch order of the row-slab / LDS-DMA kernel, or nullptr
+  struct W { uint16_t *hi, *lo; float* inv; uint16_t* dma; } blk[kTrunkStages][3]{};  // dma: copy in the piece order of the LDS-DMA / row-slab kernels, or nullptr
    // [stage][conv0, conv1, proj]; inv = per-output-channel 1/scale
   W init{};                                                   // conv_init planes
   const uint8_t* zero = nullptr;                              // 256 zero bytes (source of out-of-image taps for LDS-DMA loads)

@@ -549,10 +549,6 @@ static void conv_dims(int i, int which, int& K, int& Cout) {
   K = which == 0 ? 9 * cin : (which == 1 ? 9 * f : cin);
 }
 
-// layers the row-slab kernel may take (stride-1 3x3, at most 128 output channels): they get a second copy of the packed
-// planes in that kernel's fetch order
-static bool slab_copy(int i, int which) { return which != 2 && kStageFilters[i] <= 128 && (which == 1 || kStageStride[i] == 1); }
-
 // layers the LDS-DMA kernel may take (at least 128 output channels, K a multiple of 32)
 static bool dma_copy(int i, int which) { return kStageFilters[i] >= 128 || (i == 0 && which <= 1); }   // (+ block 0: the row-slab kernels' LDS-DMA weight / operand staging)
 
@@ -564,7 +560,6 @@ size_t trunk_packed_bytes() {
       int K, Cout;
       conv_dims(i, k, K, Cout);
       off += 2 * al256((size_t)K * Cout * 2) + al256((size_t)Cout * 4);
-      if (slab_copy(i, k)) off += al256((size_t)2 * K * Cout * 2);
       if (dma_copy(i, k)) off += al256((size_t)2 * K * Cout * 2);
     }
   off += 2 * al256((size_t)64 * 224 * 2) + al256(64 * 4);   // conv_init planes (u8 variant: [64][224]; the 3-product variant uses [64][176] of it)
@@ -584,8 +579,6 @@ int trunk_packed_bind(TrunkPacked& p, void* mem) {
       p.blk[i][k].hi = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
       p.blk[i][k].lo = (uint16_t*)(b + off); off += al256((size_t)K * Cout * 2);
       p.blk[i][k].inv = (float*)(b + off); off += al256((size_t)Cout * 4);
-      p.blk[i][k].slab = nullptr;
-      if (slab_copy(i, k)) { p.blk[i][k].slab = (uint16_t*)(b + off); off += al256((size_t)2 * K * Cout * 2); }
       p.blk[i][k].dma = nullptr;
       if (dma_copy(i, k)) { p.blk[i][k].dma = (uint16_t*)(b + off); off += al256((size_t)2 * K * Cout * 2); }
     }
@@ -606,7 +599,6 @@ static int trunk_pack(const TrunkWeights& w, TrunkPacked& p, hipStream_t stream)
       conv_dims(i, k, K, Cout);
       int rc = pack_conv_weights_f16x3(src, p.blk[i][k].hi, p.blk[i][k].lo, p.blk[i][k].inv, K, Cout, stream);
       if (rc) return rc;
-      if (p.blk[i][k].slab && (rc = pack_slab_order_f16x3(p.blk[i][k].hi, p.blk[i][k].lo, p.blk[i][k].slab, K / 9, Cout, stream))) return rc;
       if (p.blk[i][k].dma && (rc = pack_dma_order_f16x3(p.blk[i][k].hi, p.blk[i][k].lo, p.blk[i][k].dma, K, Cout, stream))) return rc;
     }
   {

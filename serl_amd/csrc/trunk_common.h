@@ -87,13 +87,10 @@ struct PackedConvWeights {
   const uint16_t* hi;  // fp16 [Cout][K]  (K = kh*kw*Cin contiguous) of w * s_n
   const uint16_t* lo;  // fp16 [Cout][K]  (w * s_n - float(hi)) * 2^11
   const float* inv;    // [Cout] 1 / s_n
-  const uint16_t* slab = nullptr;  // optional copy in the row-slab kernel's fetch order (pack_slab_order_f16x3)
   const uint16_t* dma = nullptr;   // optional copy in the LDS-DMA kernel's piece order (pack_dma_order_f16x3)
 };
 // w [K][Cout] fp32 (HWIO) -> hi / lo' fp16 [Cout][K], inv [Cout]
 int pack_conv_weights_f16x3(const float* w, uint16_t* hi, uint16_t* lo, float* inv, int K, int Cout, hipStream_t stream);
-// hi / lo' planes [Cout][9*Cin] -> [Cout/64][Cin/16][9 taps][plane][64 cout][2 k-halves][8] (4 KB per (tile, group, tap))
-int pack_slab_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* slab, int Cin, int Cout, hipStream_t stream);
 // hi / lo' planes [Cout][K] -> [Cout/64][K/32 chunks][plane][64 rows][4 swizzled 16-byte slots]: a 16-row LDS-DMA weight piece is
 // then 1 KB of consecutive bytes in lane order
 int pack_dma_order_f16x3(const uint16_t* hi, const uint16_t* lo, uint16_t* dma, int K, int Cout, hipStream_t stream);

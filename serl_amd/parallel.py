@@ -106,9 +106,8 @@ class TorchPipelineSchedule:
         # running, so the pass of batch i+2 starts at conv_init instead of behind a 22 us (37 us co-running) gather, and its index /
         # offset upload is off the trunk stream too.  Same-call A/Bs on three boxes (profiles/r05_ab_gather_stream.txt): -2.9 % (2.422 / 2.404 -> 2.339 /
         # 2.347 ms per step), +0.25 % (noise) and -0.4 %: never slower beyond noise; features verified against a serial re-encode.  The slot's buffers are free by then: the host has waited for
-        # update(i-1), the last reader of that slot.  SERL_GATHER_STREAM=0 puts the gather back on the trunk stream.
-        import os
-        self.gather_stream = torch.cuda.Stream(device=device) if os.environ.get("SERL_GATHER_STREAM", "1") != "0" else None
+        # update(i-1), the last reader of that slot.
+        self.gather_stream = torch.cuda.Stream(device=device)
         self.ev_gather = [torch.cuda.Event() for _ in range(self.slots)]
 
     def side(self):

@@ -79,57 +79,40 @@ def test_fused_projection(gpu, n, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [1024, 128, 6])
-def test_row_slab_kernel_with_lds_dma_staging(gpu, n, monkeypatch):
-    """Default since round 5 (SERL_SLAB_DMA=0 = the register-staged kernels): b0_conv1 and b1_conv1 on
-    conv3x3_slabdma_f16x3_kernel (operands by global_load_lds instead of through registers; same tiles, same K order, same
-    epilogue -- resnet_v1.py:129-156), b0_conv0 (raw input) with its weights by LDS-DMA.  Same products in the same order: features equal
-    the register-staged kernel's up to the order of the fp64 statistics atomics, and stay within 5e-6 of the fp64 oracle; the
-    plan reports tile-config 9 for the two layers."""
+def test_row_slab_kernels_fused_and_unfused(gpu, n, monkeypatch):
+    """The stride-1 3x3 convs of stage 0 and b1_conv1 run on the row-slab kernels (resnet_v1.py:129-156): b0_conv0 on
+    conv3x3_rowslab_f16x3_kernel when conv_init hands over its raw pooled output (GroupNorm + ReLU + split while a slab is staged,
+    weights by LDS-DMA), b0_conv1 / b1_conv1 on conv3x3_slabdma_f16x3_kernel (slab and weights by global_load_lds); a fused launch
+    stores through the row-major epilogue (rowtile_epilogue_t), an unfused one (SERL_GN_FUSE=0: the reference arithmetic of the
+    fused GroupNorm exchange) the raw tile.  The plan reports tile-config 9 for these layers in both modes; fused and unfused
+    features agree to the order of the fp64 statistics atomics and fma contraction, and both stay within 5e-6 of the fp64 oracle.
+    (Round 6 removed the register-staged split8 row-slab kernel and the C-layout fused epilogue together with their switches
+    SERL_SLAB_DMA / SERL_EPI_T: both had lost their same-call A/Bs twice, profiles/README.md.)"""
     cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
     st, core = AH.make_pair(cfg, B=max(n // 2, 4), trunk_mode="f16x3")
     img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(6))
-    monkeypatch.setenv("SERL_SLAB_DMA", "0")
-    regs = core.trunk_forward(img).clone()
-    assert core.trunk_plan()["b0_conv1"][:2] == ("S", 1)
-    monkeypatch.delenv("SERL_SLAB_DMA")
+    monkeypatch.setenv("SERL_GN_FUSE", "0")
+    plain = core.trunk_forward(img).clone()
+    plan = core.trunk_plan()
+    assert plan["b0_conv1"][:2] == ("S", 9) and plan["b1_conv1"][:2] == ("S", 9) and plan["b0_conv1"][3] == 0, plan
+    monkeypatch.delenv("SERL_GN_FUSE")
+    scale = float(plain.abs().max())
     for rep in range(3):
-        dma = core.trunk_forward(img).clone()
+        fused = core.trunk_forward(img).clone()
         plan = core.trunk_plan()
         assert plan["b0_conv1"][:2] == ("S", 9) and plan["b1_conv1"][:2] == ("S", 9) and plan["b0_conv0"][0] == "S", plan
         if plan["raw_b0"]:
             assert plan["b0_conv0"][:2] == ("S", 9), plan
-        scale = float(regs.abs().max())
-        assert float((dma - regs).abs().max()) / scale < 2e-6, rep
+        if n >= 128:
+            assert plan["b0_conv1"][3] == 1, plan      # the fused (row-major) epilogue ran
+        assert float((fused - plain).abs().max()) / scale < 2e-6, rep
     sel = list(range(min(n, 6))) + list(range(max(n - 6, 0), n))
     ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
-    err = AH.rel_err(dma[sel].cpu().numpy(), ref)
-    print(f"LDS-DMA row-slab kernel n={n}: rel err vs fp64 = {err:.2e}; plan b0_conv1 {plan['b0_conv1']}, b1_conv1 {plan['b1_conv1']}")
-    assert err < 5e-6, err
+    for name, got in (("fused", fused), ("unfused", plain)):
+        err = AH.rel_err(got[sel].cpu().numpy(), ref)
+        print(f"row-slab kernels n={n} {name}: rel err vs fp64 = {err:.2e}; plan b0_conv0 {plan['b0_conv0']}, b0_conv1 {plan['b0_conv1']}, b1_conv1 {plan['b1_conv1']}")
+        assert err < 5e-6, (name, err)
 
-
-@pytest.mark.parametrize("n", [1024, 256, 6])
-def test_row_major_fused_epilogue(gpu, n, monkeypatch):
-    """SERL_EPI_T (a mask over the epilogue modes): the fused GroupNorm / residual / ReLU / split8 epilogue of the row-slab
-    kernels stores ROW-major (the tile passes through LDS once; 16-byte residual loads and record stores instead of 4-byte ones).
-    Same arithmetic per element as the C-layout epilogue (resnet_v1.py:129-156): features equal up to fma contraction and the
-    order of the statistics atomics -- every mode alone (1 GroupNorm, 2 + split8 residual, 3 + projection residual, 4 + raw block
-    input), then all together."""
-    cfg = O.Config(image_keys=("a",), H=128, W=128, S=4, A=2)
-    st, core = AH.make_pair(cfg, B=max(n // 2, 4), trunk_mode="f16x3")
-    img = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
-    monkeypatch.setenv("SERL_EPI_T", "0")
-    base = core.trunk_forward(img).clone()
-    scale = float(base.abs().max())
-    for mask in (1, 2, 4, 8, 15):
-        monkeypatch.setenv("SERL_EPI_T", str(mask))
-        for rep in range(2):
-            got = core.trunk_forward(img).clone()
-            assert float((got - base).abs().max()) / scale < 2e-6, (mask, rep)
-    sel = list(range(min(n, 6)))
-    ref = O.trunk_forward(st.trunk, img[sel].cpu(), torch.float64).numpy()
-    err = AH.rel_err(got[sel].cpu().numpy(), ref)
-    print(f"row-major epilogue n={n}: rel err vs fp64 = {err:.2e}; raw_b0 {core.trunk_plan()['raw_b0']}")
-    assert err < 5e-6, err
 
 def _pretrained_like_trunk(trunk, seed=3):
     """Weight statistics a trained ImageNet ResNet with GroupNorm shows and kaiming-normal init does not: a wide
