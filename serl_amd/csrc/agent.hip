@@ -1618,6 +1618,20 @@ int serl_agent_debug_get(serl_agent* a, const char* what, float* host_out, int64
   const float* p = nullptr;
   long n = 0;
   const serl_agent_cfg& c = a->cfg;
+  if (w == "ctr_nonzero") {
+    // The last-arriver epilogues (heads.hip) rest on ONE invariant across launches: every arrival counter is zero when a launch
+    // starts (the workgroup that draws the last ticket re-zeroes it with a memory-side store).  A lost arrival, a double ticket or a
+    // late re-zero leaves a counter non-zero for the NEXT launch, which then never (or twice) reduces a tile.  host_out[0] = the
+    // number of non-zero counters after a device synchronise: 0 at every quiescent point (the stress tests assert it).
+    SERL_REQUIRE(count == 1, "tap 'ctr_nonzero' holds one value");
+    SERL_HIP(hipDeviceSynchronize());
+    std::vector<int> h((size_t)kCtrPerLane * kCtrLanes);
+    SERL_HIP(hipMemcpy(h.data(), a->ctr, sizeof(int) * h.size(), hipMemcpyDeviceToHost));
+    long nz = 0;
+    for (int v : h) nz += v != 0;
+    host_out[0] = (float)nz;
+    return SERL_OK;
+  }
   if (w == "g_critic") { p = a->Gc; n = o.Pc; }
   else if (w == "g_actor") { p = a->Ga; n = o.Pa1 - o.Pa0; }
   else if (w == "scalars") { p = a->SC; n = kScalars; }
