@@ -432,22 +432,27 @@ def main():
         per_kernel[tag] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ent.items()}
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     # HBM bytes per launch of the family from the PMC counters.  NOT measured by this process: rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE passes (scripts/collect_evidence.sh, serial schedule, possibly another box) leave them in profiles/pmc_traffic.json;
-    # `traffic_source` says so in the line.  The rocprof-derived fraction (profiles/r05_frac_from_stats.txt) rides along the same way.
+    # WRITE_SIZE passes (scripts/r06_evidence.sh, serial schedule, possibly another box) leave them in profiles/pmc_traffic.json;
+    # `traffic_source` says so in the line, with the commit the passes ran on.  The rocprof-derived fraction (profiles/r06_frac_from_stats.txt) rides along the same way.
     traffic, traffic_source, frac_rocprof = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"conv_igemm_{args.trunk}_bytes_per_launch")
-            traffic_source = "profiles/pmc_traffic.json: separate rocprofv3 --pmc passes (serial schedule), not this run"
+            pj = json.load(open(pmc))
+            traffic = pj.get(f"conv_igemm_{args.trunk}_bytes_per_launch")
+            traffic_source = (f"profiles/pmc_traffic.json (commit {pj.get('commit')}): separate rocprofv3 --pmc passes (scripts/r06_evidence.sh, serial "
+                              "schedule, another box), not this run")
         except Exception:
             traffic = None
     try:
         import re as _re
-        txt = open(os.path.join(ROOT, "profiles", "r05_frac_from_stats.txt")).read()
-        vals = [float(m) for m in _re.findall(r"frac ([0-9.]+)", txt)]     # line 1: pipelined schedule, line 2: serial
+        ff = next(f for f in ("r06_frac_from_stats.txt", "r05_frac_from_stats.txt") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        txt = open(os.path.join(ROOT, "profiles", ff)).read()
+        vals = [float(m) for m in _re.findall(r"frac ([0-9.]+)", txt)]     # first: pipelined schedule, second: serial
         frac_rocprof = dict(zip(("pipelined", "serial"), vals))
-        frac_rocprof["source"] = "profiles/r05_frac_from_stats.txt (rocprofv3 --kernel-trace --stats CSVs, scripts/frac_from_stats.py), not this run"
+        cm = _re.search(r"# commit (\S+)", txt)
+        frac_rocprof["source"] = (f"profiles/{ff} (commit {cm.group(1) if cm else 'of round 5'}; rocprofv3 --kernel-trace --stats CSVs, "
+                                  "scripts/frac_from_stats.py), not this run")
     except Exception:
         frac_rocprof = None
     n_launch = max(1, sum(c for t, (m, c) in prof.items() if t.startswith("conv_igemm")))

@@ -1,4 +1,4 @@
-"""profiles/r02_mfma_counters.json from two rocprofv3 --pmc passes (scripts/collect_evidence.sh):
+"""profiles/r0N_mfma_counters.json from two rocprofv3 --pmc passes (scripts/r06_evidence.sh):
   pass 1: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES      pass 2: SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE,
   SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY.
 usage: python scripts/pmc_counters.py <dir pass 1> <dir pass 2> <out.json>

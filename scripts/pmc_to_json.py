@@ -1,6 +1,6 @@
-"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; scripts/collect_evidence.sh).
+"""profiles/pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; scripts/r06_evidence.sh).
 
-usage: python scripts/pmc_to_json.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>
+usage: python scripts/pmc_to_json.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [commit the passes ran on]
 
 Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB; on gfx950
 FETCH_SIZE counts 64 B per 128-B request, so it is doubled.  "per launch" = mean over the dispatches of the
@@ -28,7 +28,8 @@ def family(tot, disp, pats):
 ft, fd = load(sys.argv[1])
 wt, wd = load(sys.argv[2])
 CONV16 = ("conv_igemm_f16x3_kernel", "conv3x3_rowslab_f16x3_kernel", "conv3x3_slabdma_f16x3_kernel", "conv_dma_f16x3_kernel")
-out = {"units": "bytes; FETCH_SIZE/WRITE_SIZE are KiB counters, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
+out = {"commit": sys.argv[4] if len(sys.argv) > 4 else None,
+       "units": "bytes; FETCH_SIZE/WRITE_SIZE are KiB counters, FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
                 "request: MI355X_MICROARCH.md HBM section); mean over the dispatches of the family"}
 for name, pats in (("conv_igemm_f16x3", CONV16), ("conv_igemm_f32", ("conv_igemm_kernel",)), ("gather_crop", ("gather_crop_kernel", "gather_crop_rgb_kernel")),
                    ("conv_init_f16x3", ("conv_init_f16x3_kernel", "conv_init_u8_kernel")), ("gn_relu_maxpool", ("gn_relu_maxpool", "pool_finish_split")),
