@@ -76,6 +76,13 @@ __device__ __forceinline__ void rowtile_epilogue_t(const ConvArgsB& ab, f32x16 (
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
   {
+    // Statistics: the four waves of the tile cover the SAME 64 channels of the SAME image, so their partial sums are added in the
+    // workgroup first (through LDS, in wave order, in fp64) and ONE wave issues the returning atomics: 8 per tile instead of 32.  The
+    // atomics are contended at the memory side -- 4 tiles x 4 waves x 8 on the eight (sum, sumsq) words of an image -- and the timing
+    // ablation without them ran the stage-0 convs 22-37 us shorter; issuing a wave's four at once instead of two and two made the
+    // kernels SLOWER (profiles/README.md round 6), fewer of them is what helps.  Ordering as before: the results are consumed before
+    // the barrier in front of the arrival (fused_arrive_and_wait).
+    __shared__ float s_part[4][8];   // [wave][(tn * 2 + 16-channel segment) * 2 + {sum, sumsq}]
     const int gsize = a.Cout / kGnGroups;
     double* stp = a.stats + (size_t)n_img * kGnGroups * 2;
 #pragma unroll
@@ -85,7 +92,23 @@ __device__ __forceinline__ void rowtile_epilogue_t(const ConvArgsB& ab, f32x16 (
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s += v; q += v * v; }
-      stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if ((lane & 15) == 0 && lane < 32) {
+        s_part[wave][(tn * 2 + (lane >> 4)) * 2] = s;
+        s_part[wave][(tn * 2 + (lane >> 4)) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 4) {   // lane = tn * 2 + segment
+      const double ss = (((double)s_part[0][2 * lane] + (double)s_part[1][2 * lane]) + (double)s_part[2][2 * lane]) + (double)s_part[3][2 * lane];
+      const double qq = (((double)s_part[0][2 * lane + 1] + (double)s_part[1][2 * lane + 1]) + (double)s_part[2][2 * lane + 1]) + (double)s_part[3][2 * lane + 1];
+      const int g = (n0 + 16 * lane) / gsize;
+      const double o0 = __hip_atomic_fetch_add(&stp[2 * g], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const double o1 = __hip_atomic_fetch_add(&stp[2 * g + 1], qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("" ::"v"(o0), "v"(o1));
     }
   }
   // the wave's tile -> LDS [row][64 floats] (every wave passed the main loop's last barrier: the operand buffers are idle)
