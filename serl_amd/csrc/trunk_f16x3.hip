@@ -143,6 +143,8 @@ static int launch_conv_f16x3(const char* tag, const float* in_split, PackedConvW
         ab.fz = *fuse; ab.fz.expected = a.P / 128; ab.fz.group = a.P / 128 * a.tiles_n; fused = true;
       } else if (fuse && fuse->mode && pmode == 0 && a.P == 64 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 64) {
         ab.fz = *fuse; ab.fz.expected = 0; fused = true;   // LOCAL: a wave = one (image, group), no exchange
+      } else if (fuse && fuse->mode && pmode == 2 && a.P == 16 && a.M % 128 == 0 && tn == 2 && Cout / kGnGroups == 128) {
+        ab.fz = *fuse; ab.fz.expected = 0; fused = true;   // LOCAL, stage 3: a 128 x 128 tile = eight whole images of one group (dma_tile_epilogue)
       }
 #define SERL_LAUNCH_DMA(KERN, TN_, ...)                                                                              \
   do {                                                                                                              \
@@ -398,9 +400,12 @@ int trunk_forward_f16x3(const TrunkWeights& w, TrunkWorkspace& ws, TrunkPacked& 
       SERL_HIP(hipGetLastError());
     }
     const bool last = i == kTrunkStages - 1;
-    FuseArgs fz1 = fz_of(l1, last ? 0 : (has_proj ? 3 : (raw_in ? 4 : 2)));
+    // (the last block's conv1 writes the trunk's features: plain fp32 -- out_f32 -- where its kernel has a fused epilogue for the shape: the
+    //  LOCAL stage-3 form of dma_tile_epilogue since round 6; block_out below otherwise)
+    FuseArgs fz1 = fz_of(l1, has_proj ? 3 : (raw_in ? 4 : 2));
     fz1.gn = gn_ref_b(st_of(l1), bw.gn1_s, bw.gn1_b, P, f);
-    fz1.out_split = reinterpret_cast<uint8_t*>(outp);
+    fz1.out_split = last ? nullptr : reinterpret_cast<uint8_t*>(outp);
+    fz1.out_f32 = last ? feats_out + (size_t)out_img * out_px : nullptr;
     if (has_proj) {
       fz1.res_raw = rawp;
       fz1.res_gn = gn_ref_b(st_of(lp), bw.gnp_s, bw.gnp_b, P, f);

@@ -52,6 +52,7 @@ struct FuseArgs {
   const uint8_t* res_split; // mode 2: the block input (split8)
   const float* res_raw;     // mode 3: raw projection output
   uint8_t* out_split;       // split8 output
+  float* out_f32;           // instead of out_split when set: plain fp32 NHWC output (the last block's conv1 writes the trunk's features)
 };
 
 struct ConvArgsB {
@@ -217,10 +218,12 @@ __device__ __forceinline__ void fused_load_residual(const ConvArgsB& ab, FusedRe
     }
 }
 
-template <int TM, int TN>
+// NSLOT = 4 (stage 3, images of 16 pixels): the wave's 64 rows are FOUR images, slot s = rows 16 s .. 16 s + 15 = image n_img + s, each with
+// its own statistics (local_mean / local_rstd then point at NSLOT values); NSLOT = 1: the whole block lies in image n_img.
+template <int TM, int TN, int NSLOT = 1>
 __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16 (&acc)[TM][TN],
                                                const FusedResidual<TM, TN>& res, int n_img, int wrow0, int col0, int li, int lh,
-                                               bool local = false, float local_mean = 0.f, float local_rstd = 0.f) {
+                                               bool local = false, const float* local_mean = nullptr, const float* local_rstd = nullptr) {
   const FuseArgs& fz = ab.fz;
   const int Cout = ab.c.Cout;
   const bool odd = li & 1;
@@ -231,21 +234,26 @@ __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int c = col0 + tn * 32 + li;
-    float sc, sh, rs = 0.f, rh = 0.f;
-    if (local) {   // statistics of this wave's own 64 x 64 block = the whole (image, group)
-      sc = fz.gn.gamma[c] * local_rstd;
-      sh = fz.gn.beta[c] - local_mean * sc;
-    } else {
-      gn_coef1<true>(fz.gn, n_img, c, sc, sh);
+    float scs[NSLOT], shs[NSLOT], rss[NSLOT], rhs[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      rss[sl] = 0.f; rhs[sl] = 0.f;
+      if (local) {   // statistics of this wave's (or, NSLOT = 4, this workgroup's) own block = the whole (image, group)
+        scs[sl] = fz.gn.gamma[c] * local_rstd[sl];
+        shs[sl] = fz.gn.beta[c] - local_mean[sl] * scs[sl];
+      } else {
+        gn_coef1<true>(fz.gn, n_img + sl, c, scs[sl], shs[sl]);
+      }
+      if (fz.mode >= 3) gn_coef1<false>(fz.res_gn, n_img + sl, c, rss[sl], rhs[sl]);
     }
-    if (fz.mode >= 3) gn_coef1<false>(fz.res_gn, n_img, c, rs, rh);
     const int cbyte = (c & ~7) * 4 + (odd ? 16 : 0) + (c & 6) * 2;
-    const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh}, rs2 = {rs, rs}, rh2 = {rh, rh};
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int rp = 0; rp < 8; ++rp) {
-        const int r0 = 2 * rp, r1 = r0 + 1;   // rows m and m + 1
+        const int r0 = 2 * rp, r1 = r0 + 1;   // rows m and m + 1 (same 16-row slot)
+        const int sl = NSLOT == 1 ? 0 : 2 * tm + (r0 >> 3);
+        const f32x2 sc2 = {scs[sl], scs[sl]}, sh2 = {shs[sl], shs[sl]}, rs2 = {rss[sl], rss[sl]}, rh2 = {rhs[sl], rhs[sl]};
         const int m = wrow0 + tm * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lh;
         f32x2 v = (f32x2){acc[tm][tn][r0], acc[tm][tn][r1]} * sc2 + sh2;
         if (fz.mode == 2) {
@@ -267,6 +275,12 @@ __device__ __forceinline__ void fused_gn_store(const ConvArgsB& ab, const f32x16
           v = (f32x2){fmaxf(y[0], 0.f), fmaxf(y[1], 0.f)} + v;
         }
         v = (f32x2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+        if (fz.out_f32) {   // (uniform) plain fp32 output: the trunk's features
+          float* o32 = fz.out_f32 + (size_t)m * Cout + c;
+          o32[0] = v[0];
+          o32[Cout] = v[1];
+          continue;
+        }
         const h16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
         const f32x2 hf = {(float)hp[0], (float)hp[1]};
         const f16x2 lp = __builtin_convertvector((v - hf) * (f32x2){kLoScale, kLoScale}, f16x2);

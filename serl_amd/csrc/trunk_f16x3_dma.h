@@ -25,7 +25,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = (acc[tm][tn][r] + accx[tm][tn][r] * kLoInv) * winv[tn];
   FusedResidual<TM, TN> fres;
-  if (PMODE == 0 && ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0 + wn * WCOLS, li, lh);
+  if ((PMODE == 0 || PMODE == 2) && ab.fz.mode) fused_load_residual<TM, TN>(ab, fres, wrow0, n0 + wn * WCOLS, li, lh);
   if (!ab.fz.mode) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -86,7 +86,42 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
     for (int off = 1; off < 64; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
     const double mean = s * ab.fz.gn.inv_count, m2 = q * ab.fz.gn.inv_count;
     const float var = fmaxf((float)(m2 - mean * mean), 0.f);
-    fused_gn_store<TM, TN>(ab, acc, fres, wrow0 / a.P, wrow0, n0 + wn * WCOLS, li, lh, true, (float)mean, rsqrtf(var + 1e-5f));
+    const float lmean = (float)mean, lrstd = rsqrtf(var + 1e-5f);
+    fused_gn_store<TM, TN>(ab, acc, fres, wrow0 / a.P, wrow0, n0 + wn * WCOLS, li, lh, true, &lmean, &lrstd);
+  } else if (PMODE == 2 && ab.fz.mode) {
+    // LOCAL, stage 3 (round 6): images of 16 pixels, 128 channels per group.  The workgroup's 128 x 128 tile holds EIGHT whole images of ONE
+    // group; a wave holds four of them (16-row slots) over half the group's channels, so the statistics of an (image, group) are this wave's
+    // partial sums plus those of the wave next to it (wn ^ 1), exchanged through LDS -- no atomics, no arrival, no wait, and the two
+    // elementwise launches that used to normalise this stage (gn_relu_split, block_out) are gone.
+    __shared__ double s_x[4][4][2];   // [wave][slot][sum, sumsq]
+    double s4[4], q4[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      float ps = 0.f, pq = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 8 * (sl & 1); r < 8 * (sl & 1) + 8; ++r) { const float v = acc[sl >> 1][tn][r]; ps += v; pq += v * v; }
+      s4[sl] = (double)ps; q4[sl] = (double)pq;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { s4[sl] += __shfl_xor(s4[sl], off); q4[sl] += __shfl_xor(q4[sl], off); }
+    }
+    const int wave = wm * 2 + wn;
+    if (li == 0 && lh == 0) {
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) { s_x[wave][sl][0] = s4[sl]; s_x[wave][sl][1] = q4[sl]; }
+    }
+    __syncthreads();
+    float lmean[4], lrstd[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      // (the two halves are added in column order on both waves: identical statistics for the whole group)
+      const double ss = s_x[wm * 2][sl][0] + s_x[wm * 2 + 1][sl][0], qq = s_x[wm * 2][sl][1] + s_x[wm * 2 + 1][sl][1];
+      const double mean = ss * ab.fz.gn.inv_count, m2 = qq * ab.fz.gn.inv_count;
+      const float var = fmaxf((float)(m2 - mean * mean), 0.f);
+      lmean[sl] = (float)mean; lrstd[sl] = rsqrtf(var + 1e-5f);
+    }
+    fused_gn_store<TM, TN, 4>(ab, acc, fres, wrow0 / a.P, wrow0, n0 + wn * WCOLS, li, lh, true, lmean, lrstd);
   }
 }
 
