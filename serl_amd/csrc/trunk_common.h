@@ -17,8 +17,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 
 // GroupNorm statistics: 64-lane reduction of per-lane partial (sum, sumsq) in 16-lane channel
 // segments (+ the two row halves), then one fp64 atomic per 16-channel segment.
+// wait = false: the sums are read by a LATER kernel only (unfused launches, the fused projection's tile, conv_init) -- the atomics are issued
+// and not waited for (the end of the kernel completes them): no memory round trip in the workgroup's tail.  wait = true (fused exchanges
+// inside the launch): see below.
 __device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /* [G][2] of image */,
-                                            int chan, int gsize, bool valid) {
+                                            int chan, int gsize, bool valid, bool wait = true) {
 #pragma unroll
   for (int off = 1; off < 16; off <<= 1) {
     s += __shfl_xor(s, off);
@@ -36,7 +39,7 @@ __device__ __forceinline__ void stats_flush(float s, float q, double* stats_ng /
     const double o0 = __hip_atomic_fetch_add(&stats_ng[2 * g], (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const double o1 = __hip_atomic_fetch_add(&stats_ng[2 * g + 1], (double)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifndef SERL_STATS_NORETURN   // (development switch: the racy no-return variant, to prove the stress test catches it)
-    asm volatile("" ::"v"(o0), "v"(o1));
+    if (wait) asm volatile("" ::"v"(o0), "v"(o1));
 #else
     (void)o0; (void)o1;
 #endif

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_init_u8_kernel(ConvInitArgsB a) {
     if (++tile == t_end) {   // last tile of the chunk (a chunk lies in one image)
       double* st = a.stats + (size_t)n * kGnGroups * 2;
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true);
+      for (int tn = 0; tn < 2; ++tn) stats_flush(s[tn], q[tn], st, tn * 32 + li, 16, true, false);   // (read by block 0's kernels: no wait)
       s[0] = s[1] = q[0] = q[1] = 0.f;
       chunk = next_chunk;
       tile = chunk * a.chunk;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const ConvArgsB& ab, f32x16 (&
               q += v * v;
             }
           }
-        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid, ab.fz.mode != 0);   // (unfused: a later kernel reads them)
       }
     }
   }
@@ -177,7 +177,7 @@ __device__ __forceinline__ void dma_proj_epilogue(const ConvArgsB& ab, const Con
             q += v * v;
           }
         }
-      stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+      stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid, false);   // (the projection's statistics are conv1's residual GroupNorm: a later kernel)
     }
   }
 }

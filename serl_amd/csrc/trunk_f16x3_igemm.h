@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(ConvArgsB ab) 
               q += v * v;
             }
           }
-        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid);
+        stats_flush(s, q, stp, n0 + wn * WCOLS + tn * 32 + li, gsize, valid, false);   // (never a fused launch: a later kernel reads them)
       }
     }
   }

@@ -46,7 +46,7 @@ __device__ __forceinline__ void rowtile_epilogue(const ConvArgsB& ab, f32x16 (&a
         s += v;
         q += v * v;
       }
-    stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true);
+    stats_flush(s, q, stp, n0 + tn * 32 + li, gsize, true, false);   // (unfused: a later kernel reads them)
   }
 }
 
