@@ -34,7 +34,6 @@ import importlib
 import os
 import sys
 import tempfile
-import threading
 import time
 
 import numpy as np
