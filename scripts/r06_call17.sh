@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round 6, GPU call 17: fused-projection ring kernel: conv0 first NS slots requested BEFORE the projection epilogue (one round trip fewer per tile)
+# against the library of the previous commit (serl_amd/lib/libserl_mi355_head.so), pipelined and serial, alternating
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_call17; rm -rf $O; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_agent_gpu.py -m gpu -q -x -k "trunk or race_free or row_slab or fused_projection or pipelined or full_size or k_split" > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -5 $O/pytest.log | cut -c1-250
+NB="--no-cpu-baseline --steps 110 --repeats 3"
+run() { tag=$1; shift; timeout 200 python bench.py $NB "$@" > $O/$tag.json 2> $O/$tag.err; python -c "
+import json
+try:
+    d=json.load(open('$O/$tag.json')); pk=d['roofline']['per_kernel']
+    print('$tag', d.get('ms_per_step'), d['ms_per_step_runs'], {k.split('/')[-1]: round(v['avg_us']) for k, v in pk.items() if 'conv' in k or 'block_out' in k or 'gn_relu' in k}, d.get('verify', {}).get('worst_rel_diff'))
+except Exception as e: print('$tag FAILED', e, open('$O/$tag.err').read()[-600:])"; }
+for rep in 1 2; do
+  SERL_MI355_LIB=$R/serl_amd/lib/libserl_mi355_head.so run head_pipe_$rep
+  run new_pipe_$rep
+  SERL_MI355_LIB=$R/serl_amd/lib/libserl_mi355_head.so run head_serial_$rep --no-pipeline
+  run new_serial_$rep --no-pipeline
+done
+SERL_MI355_LIB=$R/serl_amd/lib/libserl_mi355_head.so run head_emu8 --emulate-world 8
+run new_emu8 --emulate-world 8
